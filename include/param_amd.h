@@ -1,0 +1,151 @@
+/*
+ * include/param_amd.h -- C ABI of libparam_amd.so (MI355X / gfx950).
+ *
+ * The drop-in boundary of the build.  The reference
+ * (facebookresearch/param) is 100 % Python and reaches its kernels through
+ * torch / fbgemm_gpu Python calls, so "the reference's FFI for this path" is
+ * the set of Python call sites below; each entry point names the call site it
+ * replaces (paths relative to the reference root).  Plain pointers and sizes
+ * only: no torch types, no allocation inside, stream-ordered and asynchronous,
+ * re-entrant across distinct streams.  Every function returns 0 on success or
+ * a negative PM_ERR_* code; pm_last_error() gives the message of the calling
+ * thread's last failure.
+ *
+ * All device pointers are caller-owned HBM addresses on the current device.
+ * pm_stream_t is a hipStream_t passed as an opaque pointer (NULL = the null
+ * stream).
+ */
+#ifndef PARAM_AMD_H
+#define PARAM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PM_ABI_VERSION 1
+
+typedef void* pm_stream_t;
+
+/* element types */
+enum {
+    PM_F32 = 0,
+    PM_BF16 = 1,
+    PM_F16 = 2,
+    PM_I32 = 10,
+    PM_I64 = 11
+};
+
+/* error codes */
+enum {
+    PM_OK = 0,
+    PM_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, bad dtype) */
+    PM_ERR_UNSUPPORTED = -2, /* valid but not implemented (e.g. dim not a multiple of the vector width) */
+    PM_ERR_HIP = -3,         /* a HIP runtime call failed; message carries hipGetErrorString */
+    PM_ERR_INDEX = -4        /* pm_embbag_check found an out-of-range index or a bad offset */
+};
+
+/*
+ * One batched (multi-table) EmbeddingBag request, TBE layout
+ * (train/compute/python/workloads/pytorch/split_table_batched_embeddings_ops.py:93-135,
+ * 191-208): `indices` holds the per-table index lists concatenated table-major;
+ * `offsets` has num_tables*batch entries (a trailing num_tables*batch+1-th entry
+ * equal to num_indices is tolerated and never read); bag (t,b) spans
+ * [offsets[t*batch+b], offsets[t*batch+b+1]) and the very last bag ends at
+ * num_indices (torch include_last_offset=False rule, train/compute/pt/pytorch_emb.py:172-174).
+ * A single nn.EmbeddingBag call is the num_tables == 1 case.
+ *
+ * Output / gradient addressing: the D_t floats of bag (t,b) live at
+ *     base + out_offsets[t] + b * out_stride            (element units)
+ * so out_offsets[t] = sum_{u<t} D_u, out_stride = sum_t D_t is the TBE layout
+ * [batch, sum D] (pytorch_dist_backend.py:224-228) and out_offsets[t] = t*batch*D,
+ * out_stride = D is dlrm.py's torch.stack layout [T, batch, D] (dlrm.py:384-387).
+ *
+ * [bag_begin, bag_begin+bag_count) selects a slice of the batch dimension so a
+ * caller can pipeline chunks of the batch against the all-to-all
+ * (pytorch_dist_backend.py:214-234 is the reference's per-op pipelining site).
+ */
+typedef struct pm_embbag_batch {
+    int32_t num_tables;           /* T >= 1 */
+    int32_t weight_dtype;         /* PM_F32 | PM_BF16 | PM_F16 : element type of every table */
+    int32_t index_dtype;          /* PM_I64 | PM_I32 : element type of indices AND offsets */
+    int32_t max_dim;              /* max_t dims[t]; every dims[t] must be a multiple of 4 (f32) / 8 (16-bit) */
+    int64_t batch;                /* B: bags per table */
+    int64_t num_indices;          /* N: total length of `indices` */
+    int64_t bag_begin;            /* first bag (per table) to process, 0 <= bag_begin <= batch */
+    int64_t bag_count;            /* bags (per table) to process; bag_begin+bag_count <= batch */
+    const void* const* tables;    /* device [T]: base pointer of table t, row-major [rows[t], dims[t]] */
+    const int64_t* rows;          /* device [T] */
+    const int32_t* dims;          /* device [T] */
+    const int64_t* out_offsets;   /* device [T], element units (see above) */
+    int64_t out_stride;           /* element units (see above) */
+    const void* indices;          /* device [N] */
+    const void* offsets;          /* device [T*B] or [T*B+1] */
+    const float* per_sample_weights; /* device [N] or NULL */
+} pm_embbag_batch;
+
+/* ABI / build identification. */
+int pm_abi_version(void);
+const char* pm_build_info(void); /* "gfx950 ... " static string */
+const char* pm_last_error(void); /* thread-local; "" if none */
+
+/*
+ * Forward: out(t,b)[:] = sum_{j in bag (t,b)} psw[j] * table_t[indices[j], :]
+ * fp32 accumulation in index order (bit-identical to a sequential fp32 sum;
+ * with per_sample_weights each step is one fused multiply-add), fp32 output.
+ * Replaces: nn.EmbeddingBag.__call__ at train/compute/pt/pytorch_emb.py:40,61 and
+ * train/comms/pt/dlrm.py:380 (T=1 each / one launch for all local tables), and the
+ * fbgemm TBE forward at train/comms/pt/pytorch_dist_backend.py:221,845-849 and
+ * split_table_batched_embeddings_ops.py:312.
+ */
+int pm_embbag_fwd(const pm_embbag_batch* op, float* out, pm_stream_t stream);
+
+/*
+ * Backward scatter-add:
+ *     dst_t[indices[j], :] += alpha * psw[j] * grad(t, bag(j))[:]
+ * `grad` is addressed like `out` above.  dst_tables is a device array [T] of
+ * destination base pointers with element type dst_dtype and the tables' shapes:
+ *   - a dense fp32 gradient buffer with alpha = 1  == torch's dense EmbeddingBag
+ *     backward (aten::_embedding_bag_dense_backward; autograd of pytorch_emb.py:179);
+ *   - the tables themselves with alpha = -lr       == the fused in-place update the
+ *     reference reaches through fbgemm (pytorch_dist_backend.py:854-857,
+ *     split_table_batched_embeddings_ops.py:318-324), plain SGD form.
+ * Accumulation uses hardware float atomics (order not fixed; duplicates allowed).
+ * dst_dtype: PM_F32, or PM_BF16 / PM_F16 (packed 16-bit atomics, one rounding per add).
+ */
+int pm_embbag_bwd(const pm_embbag_batch* op, const float* grad, void* const* dst_tables,
+                  int32_t dst_dtype, float alpha, pm_stream_t stream);
+
+/*
+ * Validate a request on the device: every index in [0, rows[t]) and offsets
+ * monotone within [0, num_indices].  Writes the number of violations to
+ * *d_error_count (device int32, caller-zeroed is NOT required: the call zeroes
+ * it first).  torch raises on such inputs (CPU) / device-asserts (GPU); the
+ * forward/backward kernels themselves do not check.
+ */
+int pm_embbag_check(const pm_embbag_batch* op, int32_t* d_error_count, pm_stream_t stream);
+
+/*
+ * Fill a buffer with counter-based pseudo-random values at HBM write speed:
+ *   dist 0: uniform in [lo, hi)    (dlrm tables: U(-1/sqrt(n), 1/sqrt(n)),
+ *                                   train/comms/pt/pytorch_dist_backend.py:923-934)
+ *   dist 1: normal(mean=lo, std=hi) (nn.EmbeddingBag default N(0,1), pytorch_emb.py:179)
+ * Element i depends only on (seed, i): reproducible for any launch geometry.
+ * The values are the build's own stream, not torch's generator.
+ */
+int pm_fill_random(void* dst, int64_t count, int32_t dtype, int32_t dist, float lo, float hi,
+                   uint64_t seed, pm_stream_t stream);
+
+/*
+ * Tuning knobs of the forward/backward launch (process-wide, mainly for bench
+ * sweeps): unroll = rows in flight per lane group (1,2,4,8; 0 = default),
+ * bags_per_block (0 = default), xcd_affine = 1 maps table t to XCD t%8 when
+ * num_tables%8==0 (keeps each table's hot rows in one L2), -1 = default.
+ */
+int pm_set_tuning(int32_t unroll, int32_t bags_per_block, int32_t xcd_affine, int32_t nt_loads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARAM_AMD_H */

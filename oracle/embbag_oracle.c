@@ -1,0 +1,219 @@
+/*
+ * oracle/embbag_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A plain-C, single-threaded CPU restatement of the arithmetic that PARAM's
+ * embedding hot path reaches through torch:
+ *
+ *   forward   out[b,:] = sum_{j in bag b} W[idx[j],:]          (mode="sum")
+ *             call sites: train/compute/pt/pytorch_emb.py:179 (module built),
+ *             :40 / :61 (invoked); train/comms/pt/dlrm.py:380 (one call per
+ *             local table); batched form = fbgemm TBE call sites
+ *             train/comms/pt/pytorch_dist_backend.py:221,845 and
+ *             train/compute/python/workloads/pytorch/
+ *             split_table_batched_embeddings_ops.py:312 (output [B, sum_t D_t]).
+ *   backward  dW[idx[j],:] += alpha * g[bag(j),:]              (scatter-add)
+ *             call sites: split_table_batched_embeddings_ops.py:318-324,
+ *             pytorch_dist_backend.py:854-857; torch dense-grad semantics
+ *             (aten::_embedding_bag_dense_backward).
+ *
+ * The arithmetic itself lives in third-party torch (unpinned in the reference's
+ * requirements.txt:1; 2.10.0 in the survey container).  Published semantics
+ * restated here (and pinned against torch by tests/golden/, see
+ * tests/golden/gen_golden.py and tests/test_oracle.py):
+ *   - offsets has B entries (include_last_offset=False); bag b spans
+ *     [off[b], off[b+1]) and the last bag ends at N = len(indices);
+ *   - an empty bag yields zeros;
+ *   - fp32 pooling is sequential left-to-right in index order (bit-identical
+ *     to torch's CPU kernel in the survey probe);
+ *     with per_sample_weights each step is one fused multiply-add;
+ *   - 16-bit tables (bf16 / fp16) are widened to fp32, accumulated in fp32,
+ *     output fp32 (the build's definition, SURVEY.md section 8c "bf16 note").
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * call this file.  The product path (param_amd/) never links or imports it.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#define ORACLE_OK 0
+#define ORACLE_ERR_INDEX (-1)   /* index out of [0, rows)            */
+#define ORACLE_ERR_OFFSET (-2)  /* offsets not monotone / out of [0,N] */
+#define ORACLE_ERR_DTYPE (-3)
+
+enum { ORACLE_F32 = 0, ORACLE_BF16 = 1, ORACLE_F16 = 2 };
+
+static inline float bf16_to_f32(uint16_t h) {
+    uint32_t u = ((uint32_t)h) << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+static inline float f16_to_f32(uint16_t h) {
+    uint32_t sign = ((uint32_t)(h & 0x8000u)) << 16;
+    uint32_t exp = (h >> 10) & 0x1fu;
+    uint32_t man = h & 0x3ffu;
+    uint32_t u;
+    if (exp == 0) {
+        if (man == 0) {
+            u = sign;
+        } else { /* subnormal: normalise */
+            int e = -1;
+            do { man <<= 1; ++e; } while ((man & 0x400u) == 0);
+            man &= 0x3ffu;
+            u = sign | ((uint32_t)(127 - 15 - e) << 23) | (man << 13);
+        }
+    } else if (exp == 31) {
+        u = sign | 0x7f800000u | (man << 13);
+    } else {
+        u = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    }
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+/* round-to-nearest-even fp32 -> bf16 (NaN kept quiet) */
+static inline uint16_t f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    uint32_t lsb = (u >> 16) & 1u;
+    u += 0x7fffu + lsb;
+    return (uint16_t)(u >> 16);
+}
+
+static inline float load_elem(const void* W, int dtype, int64_t i) {
+    switch (dtype) {
+        case ORACLE_F32: return ((const float*)W)[i];
+        case ORACLE_BF16: return bf16_to_f32(((const uint16_t*)W)[i]);
+        default: return f16_to_f32(((const uint16_t*)W)[i]);
+    }
+}
+
+static inline int64_t bag_end(const int64_t* off, int64_t b, int64_t B, int64_t N) {
+    return (b + 1 < B) ? off[b + 1] : N;
+}
+
+/*
+ * Single-table EmbeddingBag(mode="sum") forward.
+ *   W        [rows, dim] row-major, dtype in {f32,bf16,f16}
+ *   idx      [N] int64, off [B] int64 (or [B+1] with off[B]==N: the extra entry
+ *            is never read), psw [N] float or NULL
+ *   out      fp32, bag b written at out + b*out_stride, dim elements
+ * Follows torch.nn.functional.embedding_bag semantics as exercised at
+ * pytorch_emb.py:40,61 and dlrm.py:380.
+ */
+int oracle_embbag_fwd(const void* W, int dtype, int64_t rows, int32_t dim,
+                      const int64_t* idx, int64_t N, const int64_t* off, int64_t B,
+                      const float* psw, float* out, int64_t out_stride) {
+    if (dtype < 0 || dtype > 2) return ORACLE_ERR_DTYPE;
+    for (int64_t b = 0; b < B; ++b) {
+        const int64_t s = off[b], e = bag_end(off, b, B, N);
+        if (s < 0 || e < s || e > N) return ORACLE_ERR_OFFSET;
+        float* o = out + b * out_stride;
+        for (int32_t d = 0; d < dim; ++d) o[d] = 0.0f;
+        for (int64_t j = s; j < e; ++j) {
+            const int64_t r = idx[j];
+            if (r < 0 || r >= rows) return ORACLE_ERR_INDEX;
+            const int64_t base = r * (int64_t)dim;
+            if (psw) {
+                const float w = psw[j];
+                /* fused multiply-add, one rounding: bit-identical to torch's CPU
+                 * kernel on the psw_d64 golden (a separate mul+add is not) */
+                for (int32_t d = 0; d < dim; ++d) o[d] = fmaf(w, load_elem(W, dtype, base + d), o[d]);
+            } else {
+                for (int32_t d = 0; d < dim; ++d) o[d] = o[d] + load_elem(W, dtype, base + d);
+            }
+        }
+    }
+    return ORACLE_OK;
+}
+
+/*
+ * Batched (multi-table) forward, TBE request layout
+ * (split_table_batched_embeddings_ops.py:93-135,191-208): indices are the
+ * per-table index lists concatenated table-major, offsets has T*B (or T*B+1)
+ * entries running on across tables; bag (t,b) = offsets[t*B+b].  The output
+ * row of bag (t,b) starts at out + out_offsets[t] + b*out_stride, i.e.
+ * out_offsets[t]=sum_{u<t} D_u, out_stride=sum_t D_t gives the TBE layout
+ * [B, sum D] and out_offsets[t]=t*B*D, out_stride=D gives dlrm.py's
+ * torch.stack layout [T, B, D] (dlrm.py:384-387).
+ */
+int oracle_embbag_fwd_batched(const void* const* tables, int dtype, const int64_t* rows,
+                              const int32_t* dims, int32_t T, const int64_t* idx, int64_t N,
+                              const int64_t* off, int64_t B, const float* psw, float* out,
+                              const int64_t* out_offsets, int64_t out_stride) {
+    const int64_t TB = (int64_t)T * B;
+    for (int32_t t = 0; t < T; ++t) {
+        for (int64_t b = 0; b < B; ++b) {
+            const int64_t g = (int64_t)t * B + b;
+            const int64_t s = off[g], e = bag_end(off, g, TB, N);
+            if (s < 0 || e < s || e > N) return ORACLE_ERR_OFFSET;
+            /* reuse the single-table routine on one bag */
+            const int64_t one_off = 0;
+            int rc = oracle_embbag_fwd(tables[t], dtype, rows[t], dims[t], idx + s, e - s,
+                                       &one_off, 1, psw ? psw + s : 0,
+                                       out + out_offsets[t] + b * out_stride, 0);
+            if (rc != ORACLE_OK) return rc;
+        }
+    }
+    return ORACLE_OK;
+}
+
+/*
+ * Backward scatter-add into an fp32 destination (a dense gradient buffer, or
+ * the fp32 table itself with alpha=-lr for the fused in-place SGD form):
+ *   dst[idx[j], :] += alpha * psw[j] * grad[bag(j), :]     sequential in j.
+ * grad row of bag b starts at grad + b*grad_stride.
+ */
+int oracle_embbag_bwd_f32(float* dst, int64_t rows, int32_t dim, const int64_t* idx, int64_t N,
+                          const int64_t* off, int64_t B, const float* psw, const float* grad,
+                          int64_t grad_stride, float alpha) {
+    for (int64_t b = 0; b < B; ++b) {
+        const int64_t s = off[b], e = bag_end(off, b, B, N);
+        if (s < 0 || e < s || e > N) return ORACLE_ERR_OFFSET;
+        const float* g = grad + b * grad_stride;
+        for (int64_t j = s; j < e; ++j) {
+            const int64_t r = idx[j];
+            if (r < 0 || r >= rows) return ORACLE_ERR_INDEX;
+            float* w = dst + r * (int64_t)dim;
+            const float scale = psw ? alpha * psw[j] : alpha;
+            for (int32_t d = 0; d < dim; ++d) {
+                volatile float prod = scale * g[d];
+                w[d] = w[d] + prod;
+            }
+        }
+    }
+    return ORACLE_OK;
+}
+
+/*
+ * Backward scatter-add into a bf16 table, defined as: accumulate the whole
+ * update of each destination row in fp32 on top of the widened old value,
+ * round once at the end (the order-independent definition the GPU path is
+ * compared against, with a tolerance of one bf16 ulp per contributing add).
+ * scratch must hold rows*dim floats.
+ */
+int oracle_embbag_bwd_bf16(uint16_t* dst, float* scratch, int64_t rows, int32_t dim,
+                           const int64_t* idx, int64_t N, const int64_t* off, int64_t B,
+                           const float* psw, const float* grad, int64_t grad_stride, float alpha) {
+    const int64_t n = rows * (int64_t)dim;
+    for (int64_t i = 0; i < n; ++i) scratch[i] = bf16_to_f32(dst[i]);
+    int rc = oracle_embbag_bwd_f32(scratch, rows, dim, idx, N, off, B, psw, grad, grad_stride, alpha);
+    if (rc != ORACLE_OK) return rc;
+    for (int64_t i = 0; i < n; ++i) dst[i] = f32_to_bf16(scratch[i]);
+    return ORACLE_OK;
+}
+
+/* widen helpers exported for the tests */
+void oracle_bf16_to_f32(const uint16_t* src, float* dst, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) dst[i] = bf16_to_f32(src[i]);
+}
+void oracle_f16_to_f32(const uint16_t* src, float* dst, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) dst[i] = f16_to_f32(src[i]);
+}
+void oracle_f32_to_bf16(const float* src, uint16_t* dst, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) dst[i] = f32_to_bf16(src[i]);
+}

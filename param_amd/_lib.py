@@ -1,0 +1,113 @@
+"""ctypes binding of libparam_amd.so (C ABI: include/param_amd.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent the
+import of the binding raises, and every op raises on a non-ROCm tensor.  Build the
+library with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C param_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+PM_F32, PM_BF16, PM_F16, PM_I32, PM_I64 = 0, 1, 2, 10, 11
+PM_OK, PM_ERR_INVALID, PM_ERR_UNSUPPORTED, PM_ERR_HIP, PM_ERR_INDEX = 0, -1, -2, -3, -4
+PM_ABI_VERSION = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libparam_amd.so")
+
+# every symbol include/param_amd.h declares (tests/test_capi_symbols.py parses the header
+# and checks this list and the loaded library against it)
+EXPORTED_SYMBOLS = (
+    "pm_abi_version",
+    "pm_build_info",
+    "pm_last_error",
+    "pm_embbag_fwd",
+    "pm_embbag_bwd",
+    "pm_embbag_check",
+    "pm_fill_random",
+    "pm_set_tuning",
+)
+
+
+class pm_embbag_batch(ctypes.Structure):
+    """Mirror of ``struct pm_embbag_batch`` (include/param_amd.h)."""
+
+    _fields_ = [
+        ("num_tables", ctypes.c_int32),
+        ("weight_dtype", ctypes.c_int32),
+        ("index_dtype", ctypes.c_int32),
+        ("max_dim", ctypes.c_int32),
+        ("batch", ctypes.c_int64),
+        ("num_indices", ctypes.c_int64),
+        ("bag_begin", ctypes.c_int64),
+        ("bag_count", ctypes.c_int64),
+        ("tables", ctypes.c_void_p),
+        ("rows", ctypes.c_void_p),
+        ("dims", ctypes.c_void_p),
+        ("out_offsets", ctypes.c_void_p),
+        ("out_stride", ctypes.c_int64),
+        ("indices", ctypes.c_void_p),
+        ("offsets", ctypes.c_void_p),
+        ("per_sample_weights", ctypes.c_void_p),
+    ]
+
+
+class ParamAmdError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libparam_amd error {code}: {msg}")
+        self.code = code
+
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libparam_amd.so once; raise ImportError (loudly) if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is not built. There is no CPU/eager fallback for the MI355X "
+                "embedding path: run `make -C param_amd/csrc` (hipcc --offload-arch=gfx950) first.")
+        L = ctypes.CDLL(LIB_PATH)
+        missing = [s for s in EXPORTED_SYMBOLS if not hasattr(L, s)]
+        if missing:
+            raise ImportError(f"{LIB_PATH} lacks symbols {missing}; rebuild it")
+        vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+        L.pm_abi_version.restype = ctypes.c_int
+        L.pm_abi_version.argtypes = []
+        L.pm_build_info.restype = ctypes.c_char_p
+        L.pm_build_info.argtypes = []
+        L.pm_last_error.restype = ctypes.c_char_p
+        L.pm_last_error.argtypes = []
+        L.pm_embbag_fwd.restype = ctypes.c_int
+        L.pm_embbag_fwd.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp]
+        L.pm_embbag_bwd.restype = ctypes.c_int
+        L.pm_embbag_bwd.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, ctypes.c_float, vp]
+        L.pm_embbag_check.restype = ctypes.c_int
+        L.pm_embbag_check.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp]
+        L.pm_fill_random.restype = ctypes.c_int
+        L.pm_fill_random.argtypes = [vp, i64, i32, i32, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, vp]
+        L.pm_set_tuning.restype = ctypes.c_int
+        L.pm_set_tuning.argtypes = [i32, i32, i32, i32]
+        if L.pm_abi_version() != PM_ABI_VERSION:
+            raise ImportError(f"{LIB_PATH}: ABI version {L.pm_abi_version()} != {PM_ABI_VERSION}")
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != PM_OK:
+        raise ParamAmdError(rc, load().pm_last_error().decode())
+
+
+def set_tuning(unroll: int = 0, bags_per_block: int = 0, xcd_affine: int = -1, nt_loads: int = -1) -> None:
+    check(load().pm_set_tuning(unroll, bags_per_block, xcd_affine, nt_loads))

@@ -1,0 +1,165 @@
+// param_amd/csrc/capi.hip -- extern "C" entry points of libparam_amd.so (include/param_amd.h).
+#include <atomic>
+#include <cstdio>
+#include <string>
+
+#include "common.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+std::atomic<int> g_unroll{0};
+std::atomic<int> g_bags_per_block{0};
+std::atomic<int> g_xcd_affine{-1};
+std::atomic<int> g_nt_loads{-1};
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+int hip_fail(hipError_t rc, const char* what) {
+    return fail(PM_ERR_HIP, std::string(what) + ": " + hipGetErrorString(rc));
+}
+
+bool dtype_is_weight(int d) { return d == PM_F32 || d == PM_BF16 || d == PM_F16; }
+
+// Validate the host-visible part of a request and derive the launch geometry.
+int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p) {
+    if (!op) return fail(PM_ERR_INVALID, "op is NULL");
+    if (op->num_tables < 1) return fail(PM_ERR_INVALID, "num_tables must be >= 1");
+    if (!dtype_is_weight(elem_dtype)) return fail(PM_ERR_INVALID, "weight/dst dtype must be PM_F32, PM_BF16 or PM_F16");
+    if (op->index_dtype != PM_I64 && op->index_dtype != PM_I32)
+        return fail(PM_ERR_INVALID, "index_dtype must be PM_I64 or PM_I32");
+    if (op->batch < 0 || op->num_indices < 0) return fail(PM_ERR_INVALID, "negative batch / num_indices");
+    if (op->bag_begin < 0 || op->bag_count < 0 || op->bag_begin + op->bag_count > op->batch)
+        return fail(PM_ERR_INVALID, "bag_begin/bag_count outside [0, batch]");
+    if (!op->tables || !op->rows || !op->dims || !op->out_offsets)
+        return fail(PM_ERR_INVALID, "tables/rows/dims/out_offsets must be device pointers");
+    if (op->bag_count > 0 && !op->offsets) return fail(PM_ERR_INVALID, "offsets is NULL");
+    if (op->num_indices > 0 && !op->indices) return fail(PM_ERR_INVALID, "indices is NULL");
+    const int vec = (elem_dtype == PM_F32) ? 4 : 8;
+    if (op->max_dim < 1 || op->max_dim % vec != 0)
+        return fail(PM_ERR_UNSUPPORTED, "every dims[t] (and max_dim) must be a multiple of " +
+                                            std::to_string(vec) + " for this element type");
+    if (op->out_stride % 4 != 0) return fail(PM_ERR_UNSUPPORTED, "out_stride must be a multiple of 4 elements");
+
+    const int G = pm::group_lanes(op->max_dim, vec);
+    const int NG = pm::kBlock / G;
+    int bpb = g_bags_per_block.load();
+    if (bpb <= 0) bpb = 4 * NG;
+    if (bpb < NG) bpb = NG;
+    if (bpb > 1024) bpb = 1024;
+
+    const int64_t tiles = (op->bag_count + bpb - 1) / bpb;
+    if (tiles * op->num_tables > 0x7fffffffLL) return fail(PM_ERR_UNSUPPORTED, "grid too large");
+
+    const int64_t total_bags = static_cast<int64_t>(op->num_tables) * op->batch;
+    const int64_t avg_l = total_bags > 0 ? (op->num_indices + total_bags - 1) / total_bags : 0;
+    int64_t cap = 2 * bpb * avg_l;
+    cap = (cap + 255) / 256 * 256;
+    if (cap < 1024) cap = 1024;
+    if (cap > 4096) cap = 4096;
+
+    p.tables = op->tables;
+    p.rows = op->rows;
+    p.dims = op->dims;
+    p.out_offsets = op->out_offsets;
+    p.indices = op->indices;
+    p.offsets = op->offsets;
+    p.psw = op->per_sample_weights;
+    p.io = nullptr;
+    p.out_stride = op->out_stride;
+    p.B = op->batch;
+    p.N = op->num_indices;
+    p.bag_begin = op->bag_begin;
+    p.bag_count = op->bag_count;
+    p.T = op->num_tables;
+    p.tiles_per_table = static_cast<int32_t>(tiles);
+    p.bags_per_block = bpb;
+    p.idx_cap = static_cast<int32_t>(cap);
+    p.idx64 = op->index_dtype == PM_I64 ? 1 : 0;
+    const int xa = g_xcd_affine.load();
+    p.xcd_affine = (op->num_tables % pm::kXcds == 0 && xa != 0) ? 1 : 0;
+    const int nt = g_nt_loads.load();
+    p.nt_loads = nt > 0 ? 1 : 0;
+    p.alpha = 1.0f;
+    return PM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pm_abi_version(void) { return PM_ABI_VERSION; }
+
+const char* pm_build_info(void) {
+    return "libparam_amd gfx950 (CDNA4, wave64) hip " __VERSION__;
+}
+
+const char* pm_last_error(void) { return g_last_error.c_str(); }
+
+int pm_set_tuning(int32_t unroll, int32_t bags_per_block, int32_t xcd_affine, int32_t nt_loads) {
+    if (unroll != 0 && unroll != 2 && unroll != 4 && unroll != 8)
+        return fail(PM_ERR_INVALID, "unroll must be 0, 2, 4 or 8");
+    if (bags_per_block < 0) return fail(PM_ERR_INVALID, "bags_per_block must be >= 0");
+    g_unroll.store(unroll);
+    g_bags_per_block.store(bags_per_block);
+    g_xcd_affine.store(xcd_affine);
+    g_nt_loads.store(nt_loads);
+    return PM_OK;
+}
+
+int pm_embbag_fwd(const pm_embbag_batch* op, float* out, pm_stream_t stream) {
+    pm::KParams p;
+    int rc = make_params(op, op ? op->weight_dtype : -1, p);
+    if (rc != PM_OK) return rc;
+    if (p.bag_count == 0) return PM_OK;
+    if (!out) return fail(PM_ERR_INVALID, "out is NULL");
+    p.io = out;
+    int unroll = g_unroll.load();
+    if (unroll == 0) unroll = 8;
+    hipError_t h = pm::launch_embbag_fwd(p, op->weight_dtype, op->max_dim, unroll, static_cast<hipStream_t>(stream));
+    if (h != hipSuccess) return hip_fail(h, "pm_embbag_fwd launch");
+    return PM_OK;
+}
+
+int pm_embbag_bwd(const pm_embbag_batch* op, const float* grad, void* const* dst_tables, int32_t dst_dtype,
+                  float alpha, pm_stream_t stream) {
+    pm::KParams p;
+    int rc = make_params(op, dst_dtype, p);
+    if (rc != PM_OK) return rc;
+    if (p.bag_count == 0 || p.N == 0) return PM_OK;
+    if (!grad || !dst_tables) return fail(PM_ERR_INVALID, "grad / dst_tables is NULL");
+    p.io = const_cast<float*>(grad);
+    p.tables = const_cast<const void* const*>(dst_tables);
+    p.alpha = alpha;
+    hipError_t h = pm::launch_embbag_bwd(p, dst_dtype, op->max_dim, static_cast<hipStream_t>(stream));
+    if (h != hipSuccess) return hip_fail(h, "pm_embbag_bwd launch");
+    return PM_OK;
+}
+
+int pm_embbag_check(const pm_embbag_batch* op, int32_t* d_error_count, pm_stream_t stream) {
+    pm::KParams p;
+    int rc = make_params(op, op ? op->weight_dtype : -1, p);
+    if (rc != PM_OK) return rc;
+    if (!d_error_count) return fail(PM_ERR_INVALID, "d_error_count is NULL");
+    hipError_t h = pm::launch_embbag_check(p, d_error_count, static_cast<hipStream_t>(stream));
+    if (h != hipSuccess) return hip_fail(h, "pm_embbag_check launch");
+    return PM_OK;
+}
+
+int pm_fill_random(void* dst, int64_t count, int32_t dtype, int32_t dist, float lo, float hi, uint64_t seed,
+                   pm_stream_t stream) {
+    if (count < 0) return fail(PM_ERR_INVALID, "negative count");
+    if (count > 0 && !dst) return fail(PM_ERR_INVALID, "dst is NULL");
+    if (!dtype_is_weight(dtype)) return fail(PM_ERR_INVALID, "dtype must be PM_F32, PM_BF16 or PM_F16");
+    if (dist != 0 && dist != 1) return fail(PM_ERR_INVALID, "dist must be 0 (uniform) or 1 (normal)");
+    if ((reinterpret_cast<uintptr_t>(dst) & 15u) != 0) return fail(PM_ERR_INVALID, "dst must be 16-byte aligned");
+    hipError_t h = pm::launch_fill_random(dst, count, dtype, dist, lo, hi, seed, static_cast<hipStream_t>(stream));
+    if (h != hipSuccess) return hip_fail(h, "pm_fill_random launch");
+    return PM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,124 @@
+// param_amd/csrc/common.h -- shared device/host declarations for libparam_amd.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "param_amd.h"
+
+namespace pm {
+
+constexpr int kBlock = 256;  // 4 wave64 per workgroup
+constexpr int kWave = 64;
+constexpr int kXcds = 8;     // MI355X: 8 XCDs, block b is dispatched to XCD b % 8 (speed only)
+
+// native clang vector types (the nontemporal builtins reject HIP_vector_type wrappers)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Kernel-argument block shared by forward / backward / check (passed by value: SGPRs).
+struct KParams {
+    const void* const* tables;   // fwd: source tables; bwd: destination tables
+    const int64_t* rows;
+    const int32_t* dims;
+    const int64_t* out_offsets;
+    const void* indices;
+    const void* offsets;
+    const float* psw;
+    float* io;                   // fwd: out ; bwd: grad (read-only)
+    int64_t out_stride;
+    int64_t B;                   // bags per table
+    int64_t N;                   // total indices
+    int64_t bag_begin;
+    int64_t bag_count;
+    int32_t T;
+    int32_t tiles_per_table;     // ceil(bag_count / bags_per_block)
+    int32_t bags_per_block;
+    int32_t idx_cap;             // LDS index-tile capacity (entries)
+    int32_t idx64;               // 1: int64 indices/offsets, 0: int32
+    int32_t xcd_affine;          // 1: table t is served by XCD t % 8 (requires T % 8 == 0)
+    int32_t nt_loads;            // 1: non-temporal table-row loads
+    float alpha;                 // bwd scale
+};
+
+__device__ __forceinline__ int64_t load_index(const void* p, int64_t i, int idx64) {
+    return idx64 ? reinterpret_cast<const int64_t*>(p)[i]
+                 : static_cast<int64_t>(reinterpret_cast<const int32_t*>(p)[i]);
+}
+
+// End of global bag g (g in [0, T*B)): next offset, or N for the very last bag
+// (include_last_offset=False rule; a trailing offsets[T*B] entry is never read).
+__device__ __forceinline__ int64_t bag_start_or_end(const KParams& p, int64_t g) {
+    const int64_t TB = static_cast<int64_t>(p.T) * p.B;
+    return (g < TB) ? load_index(p.offsets, g, p.idx64) : p.N;
+}
+
+// blockIdx -> (table, bag tile).  With xcd_affine the 8 XCDs each own the tables
+// t == xcd (mod 8), so one table's hot rows live in exactly one XCD's 4 MiB L2
+// instead of being replicated in all eight (placement is a speed matter only).
+__device__ __forceinline__ void block_to_tile(const KParams& p, int& t, int& tile) {
+    const int bid = blockIdx.x;
+    if (p.xcd_affine) {
+        const int xcd = bid % kXcds;
+        const int slot = bid / kXcds;
+        t = xcd + kXcds * (slot / p.tiles_per_table);
+        tile = slot % p.tiles_per_table;
+    } else {
+        t = bid / p.tiles_per_table;
+        tile = bid % p.tiles_per_table;
+    }
+}
+
+// Stage the tile's offsets (absolute, int64) and -- when the tile's index range fits --
+// its indices (narrowed to int32; rows < 2^31 is checked on the host) and per-sample
+// weights into LDS with coalesced loads.  Returns true if indices were staged.
+// LDS layout: int64 s_off[bags_per_block + 1] | int32 s_idx[idx_cap] | float s_w[idx_cap]
+template <bool WEIGHTED>
+__device__ __forceinline__ bool stage_tile(const KParams& p, int t, int tile, char* smem, int& nb,
+                                           int64_t*& s_off, int32_t*& s_idx, float*& s_w) {
+    const int64_t bag0 = p.bag_begin + static_cast<int64_t>(tile) * p.bags_per_block;
+    const int64_t left = p.bag_begin + p.bag_count - bag0;
+    nb = left < p.bags_per_block ? static_cast<int>(left) : p.bags_per_block;
+    const int64_t g0 = static_cast<int64_t>(t) * p.B + bag0;
+
+    s_off = reinterpret_cast<int64_t*>(smem);
+    s_idx = reinterpret_cast<int32_t*>(smem + (static_cast<size_t>(p.bags_per_block + 2) / 2 * 2) * sizeof(int64_t));
+    s_w = reinterpret_cast<float*>(s_idx + p.idx_cap);
+
+    for (int i = threadIdx.x; i <= nb; i += kBlock) s_off[i] = bag_start_or_end(p, g0 + i);
+    __syncthreads();
+    const int64_t base = s_off[0];
+    const int64_t cnt = s_off[nb] - base;
+    const bool staged = cnt <= p.idx_cap;
+    if (staged) {
+        for (int i = threadIdx.x; i < static_cast<int>(cnt); i += kBlock) {
+            s_idx[i] = static_cast<int32_t>(load_index(p.indices, base + i, p.idx64));
+            if (WEIGHTED) s_w[i] = p.psw[base + i];
+        }
+        __syncthreads();
+    }
+    return staged;
+}
+
+inline size_t tile_lds_bytes(int bags_per_block, int idx_cap, bool weighted) {
+    return (static_cast<size_t>(bags_per_block + 2) / 2 * 2) * sizeof(int64_t) +
+           static_cast<size_t>(idx_cap) * 4 * (weighted ? 2 : 1);
+}
+
+// ---- host-side launchers implemented in the kernel files ----------------------------------
+hipError_t launch_embbag_fwd(const KParams& p, int weight_dtype, int max_dim, int unroll,
+                             hipStream_t stream);
+hipError_t launch_embbag_bwd(const KParams& p, int dst_dtype, int max_dim, hipStream_t stream);
+hipError_t launch_embbag_check(const KParams& p, int32_t* d_err, hipStream_t stream);
+hipError_t launch_fill_random(void* dst, int64_t count, int dtype, int dist, float lo, float hi,
+                              uint64_t seed, hipStream_t stream);
+
+// lanes per bag for a given widest row: next power of two >= max_dim / vec, clamped to [8, 64]
+inline int group_lanes(int max_dim, int vec) {
+    int need = (max_dim + vec - 1) / vec;
+    int g = 8;
+    while (g < need && g < 64) g <<= 1;
+    return g;
+}
+
+}  // namespace pm

@@ -1,0 +1,203 @@
+// param_amd/csrc/embbag_fwd.hip -- batched EmbeddingBag(sum) forward for CDNA4 / gfx950.
+//
+// Replaces the kernels the reference reaches at train/compute/pt/pytorch_emb.py:40,61,
+// train/comms/pt/dlrm.py:380 (aten::_embedding_bag) and pytorch_dist_backend.py:221,845 /
+// split_table_batched_embeddings_ops.py:312 (fbgemm TBE forward).
+//
+// Memory-bound gather: no MFMA.  Design:
+//   * one 256-thread workgroup owns a tile of `bags_per_block` consecutive bags of ONE table;
+//     the tile's offsets and its index range are staged into LDS with coalesced loads
+//     (indices narrowed to int32), so the dependent row loads never wait on a scattered
+//     index load;
+//   * a group of G lanes (G*16 B >= one row) owns a bag: each lane keeps a 16-byte column
+//     slice of the fp32 accumulator in registers and issues one global_load_dwordx4 per
+//     lookup, so a wave64 reads 64/G whole rows per instruction, fully coalesced;
+//   * UNROLL independent row loads are issued back to back before the first add
+//     (memory-level parallelism: UNROLL KiB in flight per wave at G=32/64);
+//   * adds happen in index order per lane => the pooled fp32 result is bit-identical to a
+//     sequential sum (and to torch's CPU kernel); no cross-lane reduction is needed;
+//   * output rows are written with non-temporal 16-byte stores (never re-read by this kernel);
+//   * blockIdx -> (table, tile) can be XCD-affine (common.h) so a table's hot rows stay in
+//     one XCD's L2 under Zipf-skewed indices.
+#include "common.h"
+
+namespace pm {
+namespace {
+
+struct bf16_t { uint16_t v; };
+struct f16_t { uint16_t v; };
+
+template <typename WT> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int kVec = 4;
+    __device__ static __forceinline__ void widen(const u32x4& raw, float (&f)[4]) {
+        f[0] = __uint_as_float(raw.x); f[1] = __uint_as_float(raw.y);
+        f[2] = __uint_as_float(raw.z); f[3] = __uint_as_float(raw.w);
+    }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int kVec = 8;
+    __device__ static __forceinline__ void widen(const u32x4& raw, float (&f)[8]) {
+        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(w[i] << 16);
+            f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+};
+template <> struct Elem<f16_t> {
+    static constexpr int kVec = 8;
+    __device__ static __forceinline__ void widen(const u32x4& raw, float (&f)[8]) {
+        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(w[i] & 0xffffu)));
+            f[2 * i + 1] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(w[i] >> 16)));
+        }
+    }
+};
+
+__device__ __forceinline__ u32x4 load16(const char* p, bool nt) {
+    const u32x4* q = reinterpret_cast<const u32x4*>(p);
+    return nt ? __builtin_nontemporal_load(q) : *q;
+}
+
+template <typename WT, int G, int UNROLL, bool WEIGHTED>
+__global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
+    constexpr int VEC = Elem<WT>::kVec;
+    constexpr int NG = kBlock / G;  // bags processed concurrently per workgroup
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    int t, tile;
+    block_to_tile(p, t, tile);
+    if (t >= p.T) return;
+
+    int nb;
+    int64_t* s_off;
+    int32_t* s_idx;
+    float* s_w;
+    const bool staged = stage_tile<WEIGHTED>(p, t, tile, smem, nb, s_off, s_idx, s_w);
+    const int64_t base = s_off[0];
+
+    const int gid = threadIdx.x / G;
+    const int lig = threadIdx.x % G;
+    const int D = p.dims[t];
+    constexpr int ES = 16 / VEC;  // bytes per table element
+    const int64_t row_bytes = static_cast<int64_t>(D) * ES;
+    const char* W = reinterpret_cast<const char*>(p.tables[t]);
+    const int64_t bag0 = p.bag_begin + static_cast<int64_t>(tile) * p.bags_per_block;
+    float* out_t = p.io + p.out_offsets[t];
+    const bool nt = p.nt_loads != 0;
+
+    for (int bg = gid; bg < nb; bg += NG) {
+        const int64_t s = s_off[bg];
+        const int64_t e = s_off[bg + 1];
+        float* orow = out_t + (bag0 + bg) * p.out_stride;
+
+        for (int c = lig * VEC; c < D; c += G * VEC) {
+            const char* Wc = W + static_cast<int64_t>(c) * ES;
+            float acc[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+
+            int64_t j = s;
+            // full batches: UNROLL independent row loads in flight, then ordered adds
+            for (; j + UNROLL <= e; j += UNROLL) {
+                u32x4 raw[UNROLL];
+                float w[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const int64_t jj = j + u;
+                    const int64_t r = staged ? static_cast<int64_t>(s_idx[jj - base])
+                                             : load_index(p.indices, jj, p.idx64);
+                    if (WEIGHTED) w[u] = staged ? s_w[jj - base] : p.psw[jj];
+                    raw[u] = load16(Wc + r * row_bytes, nt);
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    float f[VEC];
+                    Elem<WT>::widen(raw[u], f);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[k] = WEIGHTED ? fmaf(w[u], f[k], acc[k]) : acc[k] + f[k];
+                }
+            }
+            // tail (< UNROLL lookups): exec-masked loads, same order
+            if (j < e) {
+                u32x4 raw[UNROLL];
+                float w[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL - 1; ++u) {
+                    const int64_t jj = j + u;
+                    if (jj < e) {
+                        const int64_t r = staged ? static_cast<int64_t>(s_idx[jj - base])
+                                                 : load_index(p.indices, jj, p.idx64);
+                        if (WEIGHTED) w[u] = staged ? s_w[jj - base] : p.psw[jj];
+                        raw[u] = load16(Wc + r * row_bytes, nt);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL - 1; ++u) {
+                    if (j + u < e) {
+                        float f[VEC];
+                        Elem<WT>::widen(raw[u], f);
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) acc[k] = WEIGHTED ? fmaf(w[u], f[k], acc[k]) : acc[k] + f[k];
+                    }
+                }
+            }
+
+            // streaming stores: the pooled row is consumed by another kernel / the all-to-all
+            f32x4* o4 = reinterpret_cast<f32x4*>(orow + c);
+#pragma unroll
+            for (int k = 0; k < VEC; k += 4) {
+                f32x4 v = {acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+                __builtin_nontemporal_store(v, o4 + k / 4);
+            }
+        }
+    }
+}
+
+template <typename WT, int G, int UNROLL>
+hipError_t launch_w(const KParams& p, hipStream_t stream) {
+    const bool weighted = p.psw != nullptr;
+    const int grid = p.T * p.tiles_per_table;
+    const size_t lds = tile_lds_bytes(p.bags_per_block, p.idx_cap, weighted);
+    if (weighted)
+        hipLaunchKernelGGL((embbag_fwd_kernel<WT, G, UNROLL, true>), dim3(grid), dim3(kBlock), lds, stream, p);
+    else
+        hipLaunchKernelGGL((embbag_fwd_kernel<WT, G, UNROLL, false>), dim3(grid), dim3(kBlock), lds, stream, p);
+    return hipGetLastError();
+}
+
+template <typename WT, int G>
+hipError_t launch_u(const KParams& p, int unroll, hipStream_t stream) {
+    switch (unroll) {
+        case 2: return launch_w<WT, G, 2>(p, stream);
+        case 4: return launch_w<WT, G, 4>(p, stream);
+        default: return launch_w<WT, G, 8>(p, stream);
+    }
+}
+
+template <typename WT>
+hipError_t launch_g(const KParams& p, int max_dim, int unroll, hipStream_t stream) {
+    switch (group_lanes(max_dim, Elem<WT>::kVec)) {
+        case 8: return launch_u<WT, 8>(p, unroll, stream);
+        case 16: return launch_u<WT, 16>(p, unroll, stream);
+        case 32: return launch_u<WT, 32>(p, unroll, stream);
+        default: return launch_u<WT, 64>(p, unroll, stream);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_embbag_fwd(const KParams& p, int weight_dtype, int max_dim, int unroll,
+                             hipStream_t stream) {
+    switch (weight_dtype) {
+        case PM_F32: return launch_g<float>(p, max_dim, unroll, stream);
+        case PM_BF16: return launch_g<bf16_t>(p, max_dim, unroll, stream);
+        default: return launch_g<f16_t>(p, max_dim, unroll, stream);
+    }
+}
+
+}  // namespace pm

@@ -1,0 +1,350 @@
+"""Host-side (PyTorch-ROCm) mirror of the reference's EmbeddingBag operator surface.
+
+* :class:`EmbeddingBagMI355`      -- drop-in for ``torch.nn.EmbeddingBag(n, m, mode="sum")`` as
+  used at reference ``train/compute/pt/pytorch_emb.py:179,40,61`` and
+  ``train/comms/pt/pytorch_dist_backend.py:923-934`` / ``dlrm.py:380``: ``forward(indices,
+  offsets)``, ``.weight`` parameter, survives ``.to("cuda:0")``.
+* :class:`BatchedEmbeddingBagMI355` -- the multi-table (TBE) form the reference reaches through
+  ``fbgemm_gpu.SplitTableBatchedEmbeddingBagsCodegen`` (``comms_utils.py:1994-2017``,
+  ``pytorch_dist_backend.py:221,845-857``, ``split_table_batched_embeddings_ops.py:279-324``):
+  ``forward(indices, offsets, per_sample_weights)`` -> ``[B, sum D]``; ``backward`` applies the
+  fused in-place scatter-add update (plain SGD form).
+
+PyTorch is plumbing here (device memory, streams, autograd glue); all arithmetic runs in the
+hand-written HIP kernels behind the C ABI (include/param_amd.h).  There is no CPU path: a
+tensor that is not on a ROCm device raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+_WDTYPE = {torch.float32: _lib.PM_F32, torch.bfloat16: _lib.PM_BF16, torch.float16: _lib.PM_F16}
+_IDTYPE = {torch.int64: _lib.PM_I64, torch.int32: _lib.PM_I32}
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_device(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"param_amd: {what} is on '{t.device}'. The MI355X EmbeddingBag path runs only on a "
+            "ROCm device (no CPU fallback); move the module and its inputs to cuda.")
+
+
+def fill_random_(t: torch.Tensor, dist: str = "normal", a: float = 0.0, b: float = 1.0, seed: int = 0) -> torch.Tensor:
+    """In-place counter-based fill at HBM speed (``pm_fill_random``): ``dist="normal"`` ->
+    N(mean=a, std=b) (nn.EmbeddingBag's default init, pytorch_emb.py:179), ``"uniform"`` ->
+    U[a, b) (dlrm table init, pytorch_dist_backend.py:923-934)."""
+    _require_device(t, "tensor")
+    if not t.is_contiguous():
+        raise ValueError("fill_random_ needs a contiguous tensor")
+    _lib.check(_lib.load().pm_fill_random(t.data_ptr(), t.numel(), _WDTYPE[t.dtype],
+                                          1 if dist == "normal" else 0, float(a), float(b),
+                                          int(seed) & (2**64 - 1), _stream_ptr()))
+    return t
+
+
+class _TableSet:
+    """Device-side description of T tables (pointer / rows / dims / output-offset arrays)."""
+
+    def __init__(self, tables: Sequence[torch.Tensor], layout: str = "bd"):
+        assert layout in ("bd", "tbd")
+        t0 = tables[0]
+        for t in tables:
+            _require_device(t, "embedding table")
+            if t.dtype != t0.dtype or t.dim() != 2 or not t.is_contiguous():
+                raise ValueError("tables must be contiguous 2-D tensors of one dtype")
+            if t.shape[0] >= 2**31:
+                raise ValueError("tables with >= 2^31 rows are not supported")
+        if t0.dtype not in _WDTYPE:
+            raise TypeError(f"unsupported table dtype {t0.dtype}")
+        self.device = t0.device
+        self.dtype = t0.dtype
+        self.layout = layout
+        self.rows = [int(t.shape[0]) for t in tables]
+        self.dims = [int(t.shape[1]) for t in tables]
+        vec = 4 if t0.dtype == torch.float32 else 8
+        for d in self.dims:
+            if d % vec:
+                raise ValueError(f"embedding dim {d} must be a multiple of {vec} for dtype {t0.dtype}")
+        if layout == "tbd" and len(set(self.dims)) != 1:
+            raise ValueError('layout "tbd" needs one common embedding dim')
+        self.T = len(tables)
+        self.max_dim = max(self.dims)
+        self.total_dim = sum(self.dims)
+        self.ptrs = [t.data_ptr() for t in tables]
+        self.d_ptrs = torch.tensor(self.ptrs, dtype=torch.int64, device=self.device)
+        self.d_rows = torch.tensor(self.rows, dtype=torch.int64, device=self.device)
+        self.d_dims = torch.tensor(self.dims, dtype=torch.int32, device=self.device)
+        col0 = [0]
+        for d in self.dims[:-1]:
+            col0.append(col0[-1] + d)
+        self.col0 = col0
+        self.d_col0 = torch.tensor(col0, dtype=torch.int64, device=self.device)
+        self._tbd_cache: dict[int, torch.Tensor] = {}
+
+    def out_desc(self, B: int):
+        """(out_offsets device tensor, out_stride, output shape) for a batch of B bags."""
+        if self.layout == "bd":
+            return self.d_col0, self.total_dim, (B, self.total_dim)
+        D = self.dims[0]
+        if B not in self._tbd_cache:
+            self._tbd_cache[B] = torch.arange(self.T, dtype=torch.int64, device=self.device) * (B * D)
+        return self._tbd_cache[B], D, (self.T, B, D)
+
+    def request(self, indices, offsets, B, psw, bag_begin, bag_count, d_ptrs=None) -> _lib.pm_embbag_batch:
+        _require_device(indices, "indices")
+        _require_device(offsets, "offsets")
+        if indices.dtype != offsets.dtype or indices.dtype not in _IDTYPE:
+            raise TypeError("indices and offsets must both be int64 or both int32")
+        if not (indices.is_contiguous() and offsets.is_contiguous()):
+            raise ValueError("indices/offsets must be contiguous")
+        n_off = offsets.numel()
+        if n_off not in (self.T * B, self.T * B + 1):
+            raise ValueError(f"offsets has {n_off} entries, expected T*B={self.T * B} (or T*B+1)")
+        if psw is not None:
+            _require_device(psw, "per_sample_weights")
+            if psw.dtype != torch.float32 or psw.numel() != indices.numel() or not psw.is_contiguous():
+                raise ValueError("per_sample_weights must be contiguous float32 with one entry per index")
+        off_t, stride, _ = self.out_desc(B)
+        op = _lib.pm_embbag_batch()
+        op.num_tables = self.T
+        op.weight_dtype = _WDTYPE[self.dtype]
+        op.index_dtype = _IDTYPE[indices.dtype]
+        op.max_dim = self.max_dim
+        op.batch = B
+        op.num_indices = indices.numel()
+        op.bag_begin = bag_begin
+        op.bag_count = B - bag_begin if bag_count is None else bag_count
+        op.tables = (self.d_ptrs if d_ptrs is None else d_ptrs).data_ptr()
+        op.rows = self.d_rows.data_ptr()
+        op.dims = self.d_dims.data_ptr()
+        op.out_offsets = off_t.data_ptr()
+        op.out_stride = stride
+        op.indices = indices.data_ptr()
+        op.offsets = offsets.data_ptr()
+        op.per_sample_weights = None if psw is None else psw.data_ptr()
+        return op
+
+
+def _fwd(ts: _TableSet, indices, offsets, B, psw=None, out=None, bag_begin=0, bag_count=None):
+    op = ts.request(indices, offsets, B, psw, bag_begin, bag_count)
+    _, _, shape = ts.out_desc(B)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=ts.device)
+    elif out.dtype != torch.float32 or tuple(out.shape) != tuple(shape) or not out.is_contiguous():
+        raise ValueError(f"out must be a contiguous float32 tensor of shape {shape}")
+    _lib.check(_lib.load().pm_embbag_fwd(ctypes.byref(op), out.data_ptr(), _stream_ptr()))
+    return out
+
+
+def _bwd(ts: _TableSet, grad, indices, offsets, B, dst_ptrs_dev, dst_dtype, alpha, psw=None,
+         bag_begin=0, bag_count=None):
+    _require_device(grad, "grad")
+    _, _, shape = ts.out_desc(B)
+    if grad.dtype != torch.float32 or tuple(grad.shape) != tuple(shape):
+        raise ValueError(f"grad must be float32 of shape {shape}")
+    grad = grad.contiguous()
+    op = ts.request(indices, offsets, B, psw, bag_begin, bag_count)
+    _lib.check(_lib.load().pm_embbag_bwd(ctypes.byref(op), grad.data_ptr(), dst_ptrs_dev.data_ptr(),
+                                         _WDTYPE[dst_dtype], float(alpha), _stream_ptr()))
+
+
+def check_request(ts: _TableSet, indices, offsets, B, psw=None) -> None:
+    """Raise IndexError / ValueError like torch does on the CPU path for out-of-range
+    indices or non-monotone offsets (synchronises: not for timed loops)."""
+    op = ts.request(indices, offsets, B, psw, 0, None)
+    err = torch.zeros(1, dtype=torch.int32, device=ts.device)
+    _lib.check(_lib.load().pm_embbag_check(ctypes.byref(op), err.data_ptr(), _stream_ptr()))
+    n = int(err.item())
+    if n:
+        raise IndexError(f"param_amd: {n} out-of-range indices / invalid offsets in EmbeddingBag request")
+
+
+class _DenseGradFn(torch.autograd.Function):
+    """forward = batched lookup; backward = scatter-add into a dense fp32 weight.grad
+    (torch ``sparse=False`` semantics, aten::_embedding_bag_dense_backward)."""
+
+    @staticmethod
+    def forward(ctx, weight, module, indices, offsets, psw):
+        ts = module._tables()
+        B = offsets.numel()
+        ctx.module, ctx.B = module, B
+        ctx.save_for_backward(indices, offsets, psw if psw is not None else torch.empty(0))
+        ctx.has_psw = psw is not None
+        return _fwd(ts, indices, offsets, B, psw)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        indices, offsets, psw = ctx.saved_tensors
+        m = ctx.module
+        ts = m._tables()
+        dW = torch.zeros(m.weight.shape, dtype=torch.float32, device=grad_out.device)
+        d_ptr = torch.tensor([dW.data_ptr()], dtype=torch.int64, device=grad_out.device)
+        _bwd(ts, grad_out.contiguous(), indices, offsets, ctx.B, d_ptr, torch.float32, 1.0,
+             psw if ctx.has_psw else None)
+        return dW.to(m.weight.dtype), None, None, None, None
+
+
+class EmbeddingBagMI355(nn.Module):
+    """``torch.nn.EmbeddingBag(num_embeddings, embedding_dim, mode="sum")`` on MI355X HIP kernels.
+
+    Same call contract as the module the reference builds at pytorch_emb.py:179 and
+    pytorch_dist_backend.py:924: ``forward(indices[N], offsets[B]) -> float32[B, D]``,
+    ``include_last_offset=False``; ``.weight`` is an ``nn.Parameter`` (N(0,1) init like torch).
+    """
+
+    def __init__(self, num_embeddings: int, embedding_dim: int, mode: str = "sum", sparse: bool = False,
+                 dtype: torch.dtype = torch.float32, device=None, _weight: Optional[torch.Tensor] = None):
+        super().__init__()
+        if mode != "sum":
+            raise NotImplementedError('only mode="sum" is on the reference hot path (pytorch_emb.py:179)')
+        self.num_embeddings, self.embedding_dim, self.mode, self.sparse = num_embeddings, embedding_dim, mode, sparse
+        if _weight is None:
+            w = torch.empty(num_embeddings, embedding_dim, dtype=dtype, device=device)
+            if w.is_cuda:
+                fill_random_(w, "normal", 0.0, 1.0, seed=torch.initial_seed())
+            else:
+                nn.init.normal_(w)  # host staging only; forward refuses non-ROCm tensors
+        else:
+            w = _weight
+        self.weight = nn.Parameter(w)
+        self._ts: Optional[_TableSet] = None
+
+    def _tables(self) -> _TableSet:
+        w = self.weight.data
+        if self._ts is None or self._ts.ptrs[0] != w.data_ptr():
+            self._ts = _TableSet([w], "bd")
+        return self._ts
+
+    def forward(self, indices, offsets, per_sample_weights=None):
+        _require_device(self.weight, "EmbeddingBagMI355.weight")
+        if self.weight.requires_grad and torch.is_grad_enabled():
+            return _DenseGradFn.apply(self.weight, self, indices, offsets, per_sample_weights)
+        return _fwd(self._tables(), indices, offsets, offsets.numel(), per_sample_weights)
+
+    def extra_repr(self) -> str:
+        return f"{self.num_embeddings}, {self.embedding_dim}, mode=sum, dtype={self.weight.dtype}"
+
+
+class _FusedUpdateFn(torch.autograd.Function):
+    """TBE-style: backward applies ``W[idx] += -lr * grad`` in place (no weight.grad)."""
+
+    @staticmethod
+    def forward(ctx, anchor, module, indices, offsets, psw):
+        ctx.module = module
+        ctx.save_for_backward(indices, offsets, psw if psw is not None else torch.empty(0))
+        ctx.has_psw = psw is not None
+        return module.lookup(indices, offsets, psw)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        indices, offsets, psw = ctx.saved_tensors
+        ctx.module.scatter_add_(grad_out, indices, offsets, alpha=-ctx.module.learning_rate,
+                                per_sample_weights=psw if ctx.has_psw else None)
+        return None, None, None, None, None
+
+
+class BatchedEmbeddingBagMI355(nn.Module):
+    """T embedding tables in one HBM slab, looked up by ONE kernel launch.
+
+    ``forward(indices, offsets, per_sample_weights=None)`` uses the TBE request layout
+    (indices concatenated table-major, offsets ``[T*B+1]``) and returns ``[B, sum D]``
+    (``layout="bd"``) or ``[T, B, D]`` (``layout="tbd"``, dlrm.py's ``torch.stack`` shape).
+    """
+
+    def __init__(self, rows: Sequence[int], dims, dtype: torch.dtype = torch.float32, device="cuda",
+                 layout: str = "bd", init: Optional[str] = "uniform_dlrm", seed: int = 0,
+                 learning_rate: float = 0.01, fused_update: bool = True):
+        super().__init__()
+        rows = [int(r) for r in rows]
+        dims = [int(dims)] * len(rows) if isinstance(dims, int) else [int(d) for d in dims]
+        assert len(rows) == len(dims) and len(rows) >= 1
+        self.rows, self.dims, self.layout = rows, dims, layout
+        self.learning_rate, self.fused_update = learning_rate, fused_update
+        sizes = [r * d for r, d in zip(rows, dims)]
+        esize = torch.empty(0, dtype=dtype).element_size()
+        # table starts padded to 256 B so every row stays 16-byte aligned
+        starts, cur = [], 0
+        for s in sizes:
+            starts.append(cur)
+            cur += (s * esize + 255) // 256 * 256 // esize
+        self.weights = nn.Parameter(torch.empty(cur, dtype=dtype, device=device), requires_grad=False)
+        self._starts, self._sizes = starts, sizes
+        self._anchor = nn.Parameter(torch.zeros((), device=device))  # lets autograd reach backward()
+        self._ts: Optional[_TableSet] = None
+        if init is not None:
+            self.reset_parameters(init, seed)
+
+    # -- tables ------------------------------------------------------------------------------
+    def table(self, t: int) -> torch.Tensor:
+        s = self._starts[t]
+        return self.weights.data[s:s + self._sizes[t]].view(self.rows[t], self.dims[t])
+
+    def reset_parameters(self, init: str = "uniform_dlrm", seed: int = 0) -> None:
+        for t in range(len(self.rows)):
+            w = self.table(t)
+            if init == "normal":
+                fill_random_(w, "normal", 0.0, 1.0, seed=seed * 1000003 + t)
+            else:  # U(-1/sqrt(n), 1/sqrt(n)): pytorch_dist_backend.py:923-934
+                lim = math.sqrt(1.0 / self.rows[t])
+                fill_random_(w, "uniform", -lim, lim, seed=seed * 1000003 + t)
+
+    def _tables(self) -> _TableSet:
+        if self._ts is None or self._ts.ptrs[0] != self.table(0).data_ptr():
+            self._ts = _TableSet([self.table(t) for t in range(len(self.rows))], self.layout)
+        return self._ts
+
+    def _batch_of(self, offsets) -> int:
+        # TBE convention first: offsets has T*B+1 entries (split_table_batched_embeddings_ops.py:
+        # 121-128); a T*B-entry tensor is accepted too (pass batch= to disambiguate T == 1).
+        T = len(self.rows)
+        n = offsets.numel()
+        if n >= 1 and (n - 1) % T == 0:
+            return (n - 1) // T
+        if n % T == 0:
+            return n // T
+        raise ValueError(f"offsets has {n} entries: neither T*B+1 nor T*B for T={T}")
+
+    # -- ops ---------------------------------------------------------------------------------
+    def lookup(self, indices, offsets, per_sample_weights=None, out=None, bag_begin=0, bag_count=None,
+               batch: Optional[int] = None):
+        """Forward without autograd glue; ``bag_begin/bag_count`` select a batch slice."""
+        _require_device(self.weights, "BatchedEmbeddingBagMI355.weights")
+        B = self._batch_of(offsets) if batch is None else batch
+        return _fwd(self._tables(), indices, offsets, B, per_sample_weights, out, bag_begin, bag_count)
+
+    def forward(self, indices, offsets, per_sample_weights=None):
+        if self.fused_update and torch.is_grad_enabled():
+            return _FusedUpdateFn.apply(self._anchor, self, indices, offsets, per_sample_weights)
+        return self.lookup(indices, offsets, per_sample_weights)
+
+    def scatter_add_(self, grad, indices, offsets, alpha: float, per_sample_weights=None,
+                     batch: Optional[int] = None, bag_begin=0, bag_count=None):
+        """In place ``W_t[idx[j]] += alpha * psw[j] * grad(t, bag(j))`` (alpha = -lr: SGD step)."""
+        ts = self._tables()
+        B = self._batch_of(offsets) if batch is None else batch
+        _bwd(ts, grad, indices, offsets, B, ts.d_ptrs, self.weights.dtype, alpha, per_sample_weights,
+             bag_begin, bag_count)
+
+    def dense_grad(self, grad, indices, offsets, per_sample_weights=None, batch: Optional[int] = None):
+        """fp32 dense gradients (list, one per table) -- small tables / parity tests only."""
+        ts = self._tables()
+        B = self._batch_of(offsets) if batch is None else batch
+        outs = [torch.zeros(r, d, dtype=torch.float32, device=ts.device) for r, d in zip(self.rows, self.dims)]
+        d_ptrs = torch.tensor([o.data_ptr() for o in outs], dtype=torch.int64, device=ts.device)
+        _bwd(ts, grad, indices, offsets, B, d_ptrs, torch.float32, 1.0, per_sample_weights)
+        return outs
+
+    def check(self, indices, offsets, per_sample_weights=None, batch: Optional[int] = None) -> None:
+        B = self._batch_of(offsets) if batch is None else batch
+        check_request(self._tables(), indices, offsets, B, per_sample_weights)

@@ -1,0 +1,58 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol include/param_amd.h
+declares (no compute calls here: those need a GPU)."""
+import ctypes
+import os
+import re
+
+from param_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "param_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pm_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_match_binding_list():
+    assert _declared() == sorted(_lib.EXPORTED_SYMBOLS)
+
+
+def test_library_loads_and_exports_every_symbol():
+    L = _lib.load()
+    for name in _declared():
+        assert hasattr(L, name), name
+    assert L.pm_abi_version() == _lib.PM_ABI_VERSION
+    assert b"gfx950" in L.pm_build_info()
+
+
+def test_struct_layout_matches_header():
+    # 4 x int32, 4 x int64, 4 pointers, int64, 3 pointers = 16 + 32 + 32 + 8 + 24
+    assert ctypes.sizeof(_lib.pm_embbag_batch) == 112
+    assert _lib.pm_embbag_batch.tables.offset == 48
+    assert _lib.pm_embbag_batch.out_stride.offset == 80
+    assert _lib.pm_embbag_batch.per_sample_weights.offset == 104
+
+
+def test_argument_validation_without_gpu():
+    """Host-side validation paths return error codes before any HIP call."""
+    L = _lib.load()
+    op = _lib.pm_embbag_batch()
+    assert L.pm_embbag_fwd(ctypes.byref(op), None, None) == _lib.PM_ERR_INVALID
+    assert b"num_tables" in L.pm_last_error()
+    op.num_tables, op.weight_dtype, op.index_dtype, op.max_dim = 1, _lib.PM_F32, _lib.PM_I64, 6
+    op.tables = op.rows = op.dims = op.out_offsets = 8  # non-null dummies, never dereferenced on the host
+    assert L.pm_embbag_fwd(ctypes.byref(op), None, None) == _lib.PM_ERR_UNSUPPORTED
+    assert b"multiple of 4" in L.pm_last_error()
+    op.max_dim, op.index_dtype = 8, 99
+    assert L.pm_embbag_fwd(ctypes.byref(op), None, None) == _lib.PM_ERR_INVALID
+    op.index_dtype, op.batch, op.bag_begin, op.bag_count = _lib.PM_I64, 4, 2, 3
+    assert L.pm_embbag_fwd(ctypes.byref(op), None, None) == _lib.PM_ERR_INVALID
+    assert b"bag_begin" in L.pm_last_error()
+    assert L.pm_set_tuning(3, 0, -1, -1) == _lib.PM_ERR_INVALID
+    assert L.pm_set_tuning(0, 0, -1, -1) == _lib.PM_OK
+    assert L.pm_fill_random(None, -1, _lib.PM_F32, 0, 0.0, 1.0, 0, None) == _lib.PM_ERR_INVALID
+    # empty request: nothing to launch, succeeds without a device
+    op.batch = op.bag_begin = op.bag_count = 0
+    assert L.pm_embbag_fwd(ctypes.byref(op), None, None) == _lib.PM_OK

@@ -1,0 +1,118 @@
+"""Host-side mirror of the reference's train/compute/pt surface (CPU only)."""
+import contextlib
+import io
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from param_amd import indices as I
+from param_amd.compute.pt import dataset, driver, pytorch_emb
+
+
+def test_init_indices_matches_reference_goldens(golden_dir):
+    d = np.load(os.path.join(golden_dir, "init_indices.npz"))
+    seen = 0
+    for k in d.files:
+        if k.startswith("uniform_s"):
+            seed = int(k.split("_s")[1])
+            torch.manual_seed(seed)
+            np.random.seed(seed)
+            got = I.init_indices(0.0, 1000000, 512, 20)
+        elif k.startswith("zipf_"):
+            p = k.split("_")
+            alpha, f, b, n, seed = float(p[1][1:]), int(p[2][1:]), int(p[3][1:]), int(p[4][1:]), int(p[5][1:])
+            torch.manual_seed(seed)
+            np.random.seed(seed)
+            got = I.init_indices(alpha, f, b, n)
+        else:
+            continue
+        assert got.dtype == torch.int64 and np.array_equal(got.numpy(), d[k]), k
+        seen += 1
+    assert seen >= 6
+
+
+def test_init_indices_alpha_string_and_underfill():
+    torch.manual_seed(0)
+    np.random.seed(0)
+    a = I.init_indices("1.05", 5000, 4, 4)  # reference bug R2: string alpha crashes there
+    assert a.shape == (16,)
+    np.random.seed(0)
+    with pytest.raises(ValueError, match="distinct"):  # reference bug R4: broadcast error there
+        I.init_indices(3.0, 50, 8, 20)
+
+
+def test_zipf_indices_vectorised_properties():
+    g = torch.Generator().manual_seed(1)
+    z = I.zipf_indices(1.05, 200000, 512, 20, generator=g).view(512, 20)
+    assert z.dtype == torch.int64 and int(z.min()) >= 0 and int(z.max()) < 200000
+    assert all(len(set(r.tolist())) == 20 for r in z)          # per-bag sampling without replacement
+    # hot rows are the LOW row ids (unpermuted, like the reference): row 0 is in most bags
+    assert (z == 0).any(dim=1).float().mean() > 0.8
+    assert (z < 1000).float().mean() > 0.3
+    g2 = torch.Generator().manual_seed(1)
+    assert torch.equal(I.zipf_indices(1.05, 200000, 512, 20, generator=g2).view(512, 20), z)
+    u = I.zipf_indices(0.0, 1000, 64, 5)
+    assert u.shape == (320,)
+    # tiny table where every bag under-fills at first: redraw loop terminates, still distinct
+    z = I.zipf_indices(1.2, 64, 32, 16, generator=torch.Generator().manual_seed(0)).view(32, 16)
+    assert all(len(set(r.tolist())) == 16 for r in z)
+
+
+def test_tbe_request_layout():
+    idx, off = I.tbe_request([100, 200, 50], batch=4, pooling=3, alpha=0.0, seed=5)
+    assert idx.shape == (36,) and off.tolist() == list(range(0, 37, 3))
+    assert int(idx[:12].max()) < 100 and int(idx[12:24].max()) < 200 and int(idx[24:].max()) < 50
+    idx32, off32 = I.tbe_request([100], 2, 2, index_dtype=torch.int32)
+    assert idx32.dtype == off32.dtype == torch.int32
+    assert I.fixed_offsets(4, 7).tolist() == [0, 7, 14, 21]
+    assert I.fixed_offsets(2, 3, include_last=True).tolist() == [0, 3, 6]
+
+
+def test_cpu_driver_row_format_matches_reference(golden_dir):
+    gold = json.load(open(os.path.join(golden_dir, "emb_rows.json")))
+    args = types.SimpleNamespace(device="cpu", randomseed=0, warmups=1, steps=2, alpha=0.0, usexlabag=False)
+    buf = io.StringIO()
+    torch.set_num_threads(1)
+    with contextlib.redirect_stdout(buf):
+        pytorch_emb.run(args, [(r["features"], r["embdim"], r["nnz"], r["batch"]) for r in gold["rows"]])
+    lines = buf.getvalue().splitlines()
+    assert lines[:3] == gold["header"]
+    for ln, r in zip(lines[3:], gold["rows"]):
+        assert ln.startswith(r["raw_prefix"]) and len(ln) == r["len"]
+        assert [c.strip() for c in ln.split(",")][5] == r["data_mb"]
+
+
+def test_bytes_metric_and_algorithmic_bytes():
+    # PARAM metric: batch*nnz*embdim*elem (pytorch_emb.py:180); SURVEY 8d: 546.0 B/lookup at D=128 f32 L=20
+    per_lookup = pytorch_emb.algorithmic_bytes(64, 8192, 20, 128, 4) / (64 * 8192 * 20)
+    assert abs(per_lookup - 546.0) < 1e-9
+    per_lookup = pytorch_emb.algorithmic_bytes(64, 8192, 20, 128, 2) / (64 * 8192 * 20)
+    assert abs(per_lookup - 290.0) < 1e-9
+
+
+def test_cli_surface_kept():
+    a = pytorch_emb.build_parser().parse_args(
+        "--features 1000000 --embdim 32 --nnz 20 --batch 512 --steps 3 --warmups 1 --randomseed 1 "
+        "-t float32 -d cpu --usexlabag --alpha 1.05".split())
+    assert (a.features, a.embdim, a.nnz, a.batch, a.alpha, a.device) == (1000000, 32, 20, 512, 1.05, "cpu")
+    d = driver.build_parser().parse_args("--warmups 2 --steps 5 --device cpu emb -d B --randomseed 3 --alpha 1.2".split())
+    assert d.kernel == "emb" and d.dataset == "B" and d.alpha == 1.2 and d.steps == 5
+    assert dataset.emb_A[0] == (14000000, 128, 30, 512) and dataset.emb_A[-1] == (26000000, 128, 30, 65536)
+    assert len(dataset.emb_A) == 16 and dataset.emb_B[0] == (4800000, 56, 34, 2048) and len(dataset.emb_B) == 6
+
+
+def test_gpu_modules_refuse_cpu_tensors():
+    """No CPU fallback: the product modules raise on host tensors."""
+    from param_amd import BatchedEmbeddingBagMI355, EmbeddingBagMI355, fill_random_
+
+    m = EmbeddingBagMI355(10, 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.tensor([1, 2]), torch.tensor([0]))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        fill_random_(torch.empty(8))
+    with pytest.raises(RuntimeError):
+        BatchedEmbeddingBagMI355([10], 8, device="cpu", init=None).lookup(torch.tensor([1]), torch.tensor([0, 1]))

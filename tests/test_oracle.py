@@ -1,0 +1,130 @@
+"""Pin the oracle (oracle/) against the committed torch golden vectors (CPU only).
+
+The reference's own tests pin nothing at the EmbeddingBag boundary, so the
+goldens are outputs of torch.nn.EmbeddingBag -- the engine the reference calls -- generated
+by tests/golden/gen_golden.py in the build container.
+"""
+import numpy as np
+import pytest
+
+from oracle import embbag_oracle as O
+
+
+def _single(meta):
+    return [n for n, m in meta.items() if "tables" not in m]
+
+
+def _psw(data, name):
+    return data[f"{name}.psw"] if f"{name}.psw" in data.files else None
+
+
+def test_c_oracle_forward_bit_exact(cases, coracle):
+    data, meta = cases
+    for name in _single(meta):
+        out = coracle.fwd(data[f"{name}.W"], data[f"{name}.idx"], data[f"{name}.off"], _psw(data, name))
+        assert np.array_equal(out, data[f"{name}.out"]), name
+
+
+def test_numpy_oracle_forward_bit_exact(cases):
+    data, meta = cases
+    for name in _single(meta):
+        if meta[name]["n_idx"] > 4000:
+            continue  # python loop: keep the CPU suite fast
+        out = O.embbag_fwd_np(data[f"{name}.W"], data[f"{name}.idx"], data[f"{name}.off"], _psw(data, name))
+        assert np.array_equal(out, data[f"{name}.out"]), name
+
+
+def test_c_oracle_batched_bit_exact(cases, coracle):
+    data, meta = cases
+    for name, m in meta.items():
+        if "tables" not in m:
+            continue
+        tabs = [data[f"{name}.W{t}"] for t in range(m["tables"])]
+        out = coracle.fwd_batched(tabs, data[f"{name}.idx"], data[f"{name}.off"], m["bags"])
+        assert np.array_equal(out, data[f"{name}.out"]), name
+        out_np = O.embbag_fwd_batched_np(tabs, data[f"{name}.idx"], data[f"{name}.off"], m["bags"])
+        assert np.array_equal(out_np, data[f"{name}.out"]), name
+        if len({t.shape[1] for t in tabs}) == 1:  # [T,B,D] layout = same numbers, stacked
+            tbd = coracle.fwd_batched(tabs, data[f"{name}.idx"], data[f"{name}.off"], m["bags"], layout="tbd")
+            D = tabs[0].shape[1]
+            for t in range(len(tabs)):
+                assert np.array_equal(tbd[t], data[f"{name}.out"][:, t * D:(t + 1) * D])
+
+
+def _bwd_tol(data, name):
+    """1e-5 relative to the magnitude of what was accumulated into each row element:
+    sum_j |alpha*psw_j*grad[bag(j),d]| (torch's dense backward adds in a different order)."""
+    idx, off, grad = data[f"{name}.idx"], data[f"{name}.off"], data[f"{name}.grad"]
+    psw = _psw(data, name)
+    W = data[f"{name}.W"]
+    mag = np.zeros(W.shape, dtype=np.float64)
+    start, end = O.bag_bounds(off, len(off), len(idx))
+    for b in range(len(off)):
+        for j in range(start[b], end[b]):
+            mag[idx[j]] += np.abs(grad[b].astype(np.float64)) * (1.0 if psw is None else abs(float(psw[j])))
+    return 1e-5 * mag + 1e-30
+
+
+def test_c_oracle_backward_matches_torch_dense_grad(cases, coracle):
+    data, meta = cases
+    for name in _single(meta):
+        W = data[f"{name}.W"]
+        dW = coracle.bwd_f32(np.zeros_like(W), data[f"{name}.idx"], data[f"{name}.off"],
+                             data[f"{name}.grad"], _psw(data, name))
+        err = np.abs(dW.astype(np.float64) - data[f"{name}.dW"].astype(np.float64))
+        assert (err <= _bwd_tol(data, name)).all(), (name, err.max())
+        # rows never looked up stay exactly zero
+        touched = np.zeros(W.shape[0], dtype=bool)
+        touched[data[f"{name}.idx"]] = True
+        assert not dW[~touched].any()
+
+
+def test_numpy_backward_equals_c_backward(cases, coracle):
+    data, meta = cases
+    for name in ("u_d32", "ragged_d56", "psw_d64", "gather_l1"):
+        W = data[f"{name}.W"]
+        a = coracle.bwd_f32(np.zeros_like(W), data[f"{name}.idx"], data[f"{name}.off"], data[f"{name}.grad"],
+                            _psw(data, name), alpha=-0.05)
+        b = O.embbag_bwd_np(W.shape[0], data[f"{name}.idx"], data[f"{name}.off"], data[f"{name}.grad"],
+                            _psw(data, name), alpha=-0.05)
+        assert np.array_equal(a, b), name
+
+
+def test_16bit_tables_widen_then_fp32_accumulate(cases, coracle):
+    data, _ = cases
+    out = coracle.fwd(data["bf16_d128.W_bits"], data["bf16_d128.idx"], data["bf16_d128.off"], dtype=O.BF16)
+    assert np.array_equal(out, data["bf16_d128.out"])
+    assert np.array_equal(O.bf16_bits_to_f32(data["bf16_d128.W_bits"]), data["bf16_d128.W"])
+    out = coracle.fwd(data["f16_d64.W_f16"], data["f16_d64.idx"], data["f16_d64.off"])
+    assert np.array_equal(out, data["f16_d64.out"])
+
+
+def test_int32_twin_is_same_request(cases, coracle):
+    data, _ = cases
+    assert np.array_equal(data["u_d32.idx_i32"].astype(np.int64), data["u_d32.idx"])
+    out = coracle.fwd(data["u_d32.W"], data["u_d32.idx_i32"], data["u_d32.off_i32"])
+    assert np.array_equal(out, data["u_d32.out"])
+
+
+def test_bf16_backward_rounds_once(coracle):
+    rng = np.random.default_rng(3)
+    W = rng.standard_normal((50, 16)).astype(np.float32)
+    bits = O.f32_to_bf16_bits(W)
+    idx = rng.integers(0, 50, 60)
+    off = np.arange(6) * 10
+    grad = rng.standard_normal((6, 16)).astype(np.float32)
+    expect = O.f32_to_bf16_bits(O.embbag_bwd_np(50, idx, off, grad, alpha=-0.1, dst=O.bf16_bits_to_f32(bits).copy()))
+    got = coracle.bwd_bf16(bits.copy(), idx, off, grad, alpha=-0.1)
+    assert np.array_equal(got, expect)
+
+
+def test_error_behaviour(coracle):
+    W = np.zeros((4, 8), dtype=np.float32)
+    with pytest.raises(IndexError):
+        coracle.fwd(W, np.array([0, 4]), np.array([0]))
+    with pytest.raises(IndexError):
+        coracle.fwd(W, np.array([-1]), np.array([0]))
+    with pytest.raises(ValueError):
+        coracle.fwd(W, np.array([0, 1, 2]), np.array([2, 1]))
+    with pytest.raises(IndexError):
+        O.embbag_fwd_np(W, np.array([9]), np.array([0]))
