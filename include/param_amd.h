@@ -118,6 +118,32 @@ int pm_embbag_bwd(const pm_embbag_batch* op, const float* grad, void* const* dst
                   int32_t dst_dtype, float alpha, pm_stream_t stream);
 
 /*
+ * Deterministic backward without atomics (the default path of the Python modules):
+ *   pm_embbag_bwd_sorted_workspace  bytes of caller-owned device scratch for this request
+ *                                   (>= 0), or a negative PM_ERR_* code;
+ *   pm_embbag_sort_indices          builds one (table,row) key per lookup and sorts them
+ *                                   (stable radix sort); depends on indices/offsets only, so
+ *                                   it may run on a side stream under the forward pass;
+ *   pm_embbag_bwd_sorted            same arithmetic as pm_embbag_bwd, but every destination
+ *                                   row is read once, updated in fp32 registers in lookup
+ *                                   order and written once: bit-identical to a sequential
+ *                                   CPU scatter-add and run-to-run reproducible.  Requires
+ *                                   pm_embbag_sort_indices on the same workspace and request
+ *                                   (stream-ordered before it).  16-bit destinations are
+ *                                   widened, accumulated in fp32 and rounded once per row.
+ * max_rows = max_t rows[t] (host value; sizes the sort key).  The request must satisfy
+ * num_indices < 2^32 and batch < 2^32.  Replaces the sort + segmented-reduce backward of
+ * aten::_embedding_bag_dense_backward and fbgemm's TBE backward (same call sites as
+ * pm_embbag_bwd).
+ */
+int64_t pm_embbag_bwd_sorted_workspace(const pm_embbag_batch* op, int64_t max_rows);
+int pm_embbag_sort_indices(const pm_embbag_batch* op, int64_t max_rows, void* workspace,
+                           int64_t workspace_bytes, pm_stream_t stream);
+int pm_embbag_bwd_sorted(const pm_embbag_batch* op, const float* grad, void* const* dst_tables,
+                         int32_t dst_dtype, float alpha, int64_t max_rows, const void* workspace,
+                         int64_t workspace_bytes, pm_stream_t stream);
+
+/*
  * Validate a request on the device: every index in [0, rows[t]) and offsets
  * monotone within [0, num_indices].  Writes the number of violations to
  * *d_error_count (device int32, caller-zeroed is NOT required: the call zeroes

@@ -26,6 +26,9 @@ EXPORTED_SYMBOLS = (
     "pm_last_error",
     "pm_embbag_fwd",
     "pm_embbag_bwd",
+    "pm_embbag_bwd_sorted_workspace",
+    "pm_embbag_sort_indices",
+    "pm_embbag_bwd_sorted",
     "pm_embbag_check",
     "pm_fill_random",
     "pm_set_tuning",
@@ -93,6 +96,13 @@ def load() -> ctypes.CDLL:
         L.pm_embbag_fwd.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp]
         L.pm_embbag_bwd.restype = ctypes.c_int
         L.pm_embbag_bwd.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, ctypes.c_float, vp]
+        L.pm_embbag_bwd_sorted_workspace.restype = ctypes.c_int64
+        L.pm_embbag_bwd_sorted_workspace.argtypes = [ctypes.POINTER(pm_embbag_batch), i64]
+        L.pm_embbag_sort_indices.restype = ctypes.c_int
+        L.pm_embbag_sort_indices.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, vp, i64, vp]
+        L.pm_embbag_bwd_sorted.restype = ctypes.c_int
+        L.pm_embbag_bwd_sorted.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, ctypes.c_float, i64, vp,
+                                           i64, vp]
         L.pm_embbag_check.restype = ctypes.c_int
         L.pm_embbag_check.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp]
         L.pm_fill_random.restype = ctypes.c_int

@@ -153,6 +153,63 @@ int pm_embbag_bwd(const pm_embbag_batch* op, const float* grad, void* const* dst
     return PM_OK;
 }
 
+static int sorted_args_ok(const pm_embbag_batch* op, int64_t max_rows) {
+    if (max_rows < 1 || max_rows > (1LL << 31)) return fail(PM_ERR_INVALID, "max_rows must be in [1, 2^31]");
+    if (op->num_indices >= (1LL << 32) || static_cast<int64_t>(op->batch) >= (1LL << 32))
+        return fail(PM_ERR_UNSUPPORTED, "sorted backward needs num_indices and batch below 2^32");
+    return PM_OK;
+}
+
+int64_t pm_embbag_bwd_sorted_workspace(const pm_embbag_batch* op, int64_t max_rows) {
+    pm::KParams p;
+    int rc = make_params(op, op ? op->weight_dtype : -1, p);
+    if (rc != PM_OK) return rc;
+    if ((rc = sorted_args_ok(op, max_rows)) != PM_OK) return rc;
+    size_t bytes = 0;
+    hipError_t h = pm::sorted_workspace_bytes(p, max_rows, bytes);
+    if (h != hipSuccess) return hip_fail(h, "pm_embbag_bwd_sorted_workspace");
+    return static_cast<int64_t>(bytes);
+}
+
+int pm_embbag_sort_indices(const pm_embbag_batch* op, int64_t max_rows, void* workspace, int64_t workspace_bytes,
+                           pm_stream_t stream) {
+    pm::KParams p;
+    int rc = make_params(op, op ? op->weight_dtype : -1, p);
+    if (rc != PM_OK) return rc;
+    if ((rc = sorted_args_ok(op, max_rows)) != PM_OK) return rc;
+    if (p.N == 0) return PM_OK;
+    size_t need = 0;
+    hipError_t h = pm::sorted_workspace_bytes(p, max_rows, need);
+    if (h != hipSuccess) return hip_fail(h, "pm_embbag_sort_indices");
+    if (!workspace || workspace_bytes < static_cast<int64_t>(need))
+        return fail(PM_ERR_INVALID, "workspace too small: need " + std::to_string(need) + " bytes");
+    h = pm::sort_indices(p, max_rows, workspace, static_cast<hipStream_t>(stream));
+    if (h != hipSuccess) return hip_fail(h, "pm_embbag_sort_indices");
+    return PM_OK;
+}
+
+int pm_embbag_bwd_sorted(const pm_embbag_batch* op, const float* grad, void* const* dst_tables, int32_t dst_dtype,
+                         float alpha, int64_t max_rows, const void* workspace, int64_t workspace_bytes,
+                         pm_stream_t stream) {
+    pm::KParams p;
+    int rc = make_params(op, dst_dtype, p);
+    if (rc != PM_OK) return rc;
+    if ((rc = sorted_args_ok(op, max_rows)) != PM_OK) return rc;
+    if (p.N == 0 || p.bag_count == 0) return PM_OK;
+    if (!grad || !dst_tables) return fail(PM_ERR_INVALID, "grad / dst_tables is NULL");
+    size_t need = 0;
+    hipError_t h = pm::sorted_workspace_bytes(p, max_rows, need);
+    if (h != hipSuccess) return hip_fail(h, "pm_embbag_bwd_sorted");
+    if (!workspace || workspace_bytes < static_cast<int64_t>(need))
+        return fail(PM_ERR_INVALID, "workspace too small: need " + std::to_string(need) + " bytes");
+    p.io = const_cast<float*>(grad);
+    p.tables = const_cast<const void* const*>(dst_tables);
+    p.alpha = alpha;
+    h = pm::bwd_sorted_apply(p, max_rows, dst_dtype, op->max_dim, workspace, static_cast<hipStream_t>(stream));
+    if (h != hipSuccess) return hip_fail(h, "pm_embbag_bwd_sorted launch");
+    return PM_OK;
+}
+
 int pm_embbag_check(const pm_embbag_batch* op, int32_t* d_error_count, pm_stream_t stream) {
     pm::KParams p;
     int rc = make_params(op, op ? op->weight_dtype : -1, p);

@@ -114,6 +114,12 @@ hipError_t launch_embbag_check(const KParams& p, int32_t* d_err, hipStream_t str
 hipError_t launch_fill_random(void* dst, int64_t count, int dtype, int dist, float lo, float hi,
                               uint64_t seed, hipStream_t stream);
 
+// sort-based deterministic backward (embbag_bwd_sorted.hip)
+hipError_t sorted_workspace_bytes(const KParams& p, int64_t max_rows, size_t& bytes);
+hipError_t sort_indices(const KParams& p, int64_t max_rows, void* workspace, hipStream_t stream);
+hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, int max_dim, const void* workspace,
+                            hipStream_t stream);
+
 // lanes per bag for a given widest row: next power of two >= max_dim / vec, clamped to [8, 64]
 inline int group_lanes(int max_dim, int vec) {
     int need = (max_dim + vec - 1) / vec;

@@ -1,0 +1,438 @@
+// param_amd/csrc/embbag_bwd_sorted.hip -- deterministic EmbeddingBag backward (no atomics).
+//
+//     dst_t[indices[j], :] += alpha * psw[j] * grad(t, bag(j))[:]
+//
+// Why not atomics: on MI355X a device-scope float atomic is a fabric transaction per dword;
+// the atomic kernel (embbag_bwd.hip) tops out at ~77 G atomic-dwords/s = 0.6 G lookups/s at
+// D=128 (profiles/, sweep r1a), 6-8 % of the HBM roofline.  This path instead
+//   1. builds one (table,row) key and one bag value per lookup          (build_keys_kernel)
+//   2. sorts the pairs by key with a stable LSD radix sort               (rocPRIM device primitive;
+//      only bits [0, bits(T)+bits(max_rows)) are sorted)
+//   3. streams the sorted pairs: every run of equal keys is owned by ONE lane group, which
+//      reads the destination row once, adds the run's gradient rows in sorted (= original
+//      index) order in fp32 registers and writes the row back once      (bwd_sorted_kernel)
+// so each touched row costs one HBM read + one HBM write (the algorithmic 2*D*e bytes), the
+// gradient rows are re-read from L2 / Infinity Cache, and there is no atomic and no race.
+// The sort is stable, so within a row contributions are added in increasing lookup position:
+// the result is bit-identical to the sequential CPU oracle (oracle/embbag_oracle.c) and
+// run-to-run deterministic -- what torch's CUDA dense backward obtains by sort + segmented
+// reduce (aten::_embedding_bag_dense_backward) and fbgemm's TBE backward by its sorted
+// linear indices (reference call sites: pytorch_dist_backend.py:854-857,
+// split_table_batched_embeddings_ops.py:318-324).
+//
+// Step 1+2 depend only on the indices, not on the gradient: pm_embbag_sort_indices() can run
+// on a side stream under the forward pass; pm_embbag_bwd_sorted() is step 3.
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "common.h"
+
+namespace pm {
+namespace {
+
+constexpr int kSortTile = 1024;  // sorted positions per workgroup in step 3
+constexpr int kBatch = 4;        // positions whose loads are issued together per lane group
+
+struct SortedParams {
+    const void* keys;        // sorted keys (uint32 / uint64)
+    const uint32_t* vals;    // sorted values: bag within table (unweighted) or lookup position j (weighted)
+    const uint32_t* bag_of;  // weighted only: bag within table of lookup position j
+    void* const* dst;        // destination tables
+    const int32_t* dims;
+    const int64_t* out_offsets;
+    const float* grad;
+    const float* psw;
+    int64_t out_stride;
+    int64_t n;               // number of sorted pairs
+    int32_t rbits;           // key = (t << rbits) | row ; keys with bit (tbits+rbits) set are padding
+    int32_t kbits;           // tbits + rbits
+    int32_t max_dim;
+    float alpha;
+};
+
+// ---------------------------------------------------------------------------------------------
+// step 1: keys / values, same tiling and LDS offset staging as the forward
+template <typename K, bool WEIGHTED>
+__global__ void __launch_bounds__(kBlock) build_keys_kernel(const KParams p, K* keys, uint32_t* vals,
+                                                            uint32_t* bag_of, int rbits, int kbits,
+                                                            int64_t slice_begin, int64_t slice_end) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int t, tile;
+    block_to_tile(p, t, tile);
+    if (t >= p.T) return;
+    const int64_t bag0 = static_cast<int64_t>(tile) * p.bags_per_block;  // p.bag_begin == 0 here: whole batch
+    const int64_t left = p.B - bag0;
+    const int nb = left < p.bags_per_block ? static_cast<int>(left) : p.bags_per_block;
+    const int64_t g0 = static_cast<int64_t>(t) * p.B + bag0;
+    int64_t* s_off = reinterpret_cast<int64_t*>(smem);
+    for (int i = threadIdx.x; i <= nb; i += kBlock) s_off[i] = bag_start_or_end(p, g0 + i);
+    __syncthreads();
+    const int64_t base = s_off[0];
+    const int64_t end = s_off[nb];
+    const K pad = static_cast<K>(1) << kbits;
+    for (int64_t j = base + threadIdx.x; j < end; j += kBlock) {
+        // bag of lookup j: largest b with s_off[b] <= j (binary search over the LDS offsets)
+        int lo = 0, hi = nb;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_off[mid] <= j) lo = mid; else hi = mid;
+        }
+        const int64_t bag = bag0 + lo;
+        const K row = static_cast<K>(load_index(p.indices, j, p.idx64));
+        const bool in_slice = bag >= slice_begin && bag < slice_end;
+        keys[j] = in_slice ? ((static_cast<K>(t) << rbits) | row) : pad;
+        if (WEIGHTED) {
+            vals[j] = static_cast<uint32_t>(j);
+            bag_of[j] = static_cast<uint32_t>(bag);
+        } else {
+            vals[j] = static_cast<uint32_t>(bag);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// step 3 helpers: destination element types
+struct SDstF32 {
+    static constexpr int kVec = 4, kES = 4;
+    __device__ static __forceinline__ void load(const char* p, float (&a)[4]) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+        a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+    }
+    __device__ static __forceinline__ void store(char* p, const float (&a)[4]) {
+        *reinterpret_cast<f32x4*>(p) = f32x4{a[0], a[1], a[2], a[3]};
+    }
+};
+__device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+struct SDstBF16 {
+    static constexpr int kVec = 8, kES = 2;
+    __device__ static __forceinline__ void load(const char* p, float (&a)[8]) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(p);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[2 * i] = __uint_as_float(w[i] << 16); a[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    }
+    __device__ static __forceinline__ void store(char* p, const float (&a)[8]) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = f32_to_bf16_rne(a[2 * i]) | (f32_to_bf16_rne(a[2 * i + 1]) << 16);
+        *reinterpret_cast<u32x4*>(p) = u32x4{w[0], w[1], w[2], w[3]};
+    }
+};
+struct SDstF16 {
+    static constexpr int kVec = 8, kES = 2;
+    __device__ static __forceinline__ void load(const char* p, float (&a)[8]) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(p);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[2 * i] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(w[i] & 0xffffu)));
+            a[2 * i + 1] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(w[i] >> 16)));
+        }
+    }
+    __device__ static __forceinline__ void store(char* p, const float (&a)[8]) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            w[i] = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, static_cast<_Float16>(a[2 * i]))) |
+                   (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, static_cast<_Float16>(a[2 * i + 1]))) << 16);
+        *reinterpret_cast<u32x4*>(p) = u32x4{w[0], w[1], w[2], w[3]};
+    }
+};
+
+// step 3: stream the sorted pairs.  A group of G lanes owns positions [c0, c1) of the sorted
+// order and every run of equal keys that STARTS there (it follows its last run past c1 and
+// skips a leading run that started before c0).  Per batch of kBatch positions all gradient-row
+// loads and all run-head destination-row loads are issued before the first add.
+template <typename DST, typename K, int G, bool WEIGHTED>
+__global__ void __launch_bounds__(kBlock) bwd_sorted_kernel(const SortedParams p) {
+    constexpr int VEC = DST::kVec;
+    constexpr int NG = kBlock / G;
+    constexpr int C = kSortTile / NG;
+    __shared__ K s_key[kSortTile + 1];      // s_key[i + 1] = key of position base + i; s_key[0] = predecessor
+    __shared__ uint32_t s_val[kSortTile];
+
+    const K* keys = reinterpret_cast<const K*>(p.keys);
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * kSortTile;
+    const int n_tile = (p.n - base) < kSortTile ? static_cast<int>(p.n - base) : kSortTile;
+    for (int i = threadIdx.x; i < n_tile; i += kBlock) {
+        s_key[i + 1] = keys[base + i];
+        s_val[i] = p.vals[base + i];
+    }
+    if (threadIdx.x == 0) s_key[0] = base > 0 ? keys[base - 1] : static_cast<K>(0);
+    __syncthreads();
+
+    const K pad_bit = static_cast<K>(1) << p.kbits;
+    const K row_mask = (static_cast<K>(1) << p.rbits) - 1;
+    auto key_at = [&](int64_t q) -> K {  // q absolute, base - 1 <= q < n
+        const int64_t r = q - base;
+        return r < n_tile ? s_key[r + 1] : keys[q];
+    };
+    auto val_at = [&](int64_t q) -> uint32_t {
+        const int64_t r = q - base;
+        return r < n_tile ? s_val[r] : p.vals[q];
+    };
+
+    const int gid = threadIdx.x / G;
+    const int lig = threadIdx.x % G;
+    const int64_t c0 = base + static_cast<int64_t>(gid) * C;
+    const int64_t c1 = (c0 + C < base + n_tile) ? c0 + C : base + n_tile;
+    if (c0 >= c1) return;
+
+    // One pass per column chunk (one pass when G*VEC >= D, the normal case).
+    for (int c = lig * VEC; c < p.max_dim; c += G * VEC) {
+        bool open = false, done = false, any_col = false;
+        float acc[VEC];
+        char* wptr = nullptr;
+        for (int64_t pos = c0; !done && (pos < c1 || open); pos += kBatch) {
+            K kk[kBatch + 1];
+            uint32_t vv[kBatch];
+            bool valid[kBatch], head[kBatch];
+            kk[0] = pos > 0 ? key_at(pos - 1) : static_cast<K>(0);
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                valid[u] = (pos + u) < p.n;
+                kk[u + 1] = valid[u] ? key_at(pos + u) : pad_bit;
+                valid[u] = valid[u] && !(kk[u + 1] & pad_bit);  // padding keys sort last: end of data
+                vv[u] = valid[u] ? val_at(pos + u) : 0u;
+                head[u] = valid[u] && ((pos + u) == 0 || kk[u + 1] != kk[u]);
+            }
+            // issue every load of the batch
+            float gv[kBatch][VEC];
+            float wv[kBatch][VEC];
+            float sc[kBatch];
+            char* wp[kBatch];
+            bool col_ok[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                col_ok[u] = false;
+                if (valid[u]) {
+                    const int t = static_cast<int>(kk[u + 1] >> p.rbits);
+                    const int64_t row = static_cast<int64_t>(kk[u + 1] & row_mask);
+                    const int D = p.dims[t];
+                    col_ok[u] = c < D;
+                    if (col_ok[u]) {
+                        uint32_t bag = vv[u];
+                        sc[u] = p.alpha;
+                        if (WEIGHTED) {
+                            sc[u] = p.alpha * p.psw[vv[u]];
+                            bag = p.bag_of[vv[u]];
+                        }
+                        const float* g = p.grad + p.out_offsets[t] + static_cast<int64_t>(bag) * p.out_stride + c;
+#pragma unroll
+                        for (int k = 0; k < VEC; k += 4) {
+                            const f32x4 x = *reinterpret_cast<const f32x4*>(g + k);
+                            gv[u][k] = x.x; gv[u][k + 1] = x.y; gv[u][k + 2] = x.z; gv[u][k + 3] = x.w;
+                        }
+                        wp[u] = reinterpret_cast<char*>(p.dst[t]) + (row * D + c) * DST::kES;
+                        if (head[u] && (pos + u) < c1) DST::load(wp[u], wv[u]);
+                    }
+                }
+            }
+            // consume in sorted order
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                if (done) break;
+                if (!valid[u]) {  // end of data
+                    done = true;
+                    break;
+                }
+                if (head[u]) {
+                    if (open) {
+                        if (any_col) DST::store(wptr, acc);
+                        open = false;
+                    }
+                    if ((pos + u) >= c1) {  // this run belongs to the next group
+                        done = true;
+                        break;
+                    }
+                    open = true;
+                    any_col = col_ok[u];
+                    wptr = wp[u];
+                    if (any_col) {
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) acc[k] = wv[u][k];
+                    }
+                }
+                if (open && any_col) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        const float prod = sc[u] * gv[u][k];
+                        acc[k] = acc[k] + prod;
+                    }
+                }
+            }
+        }
+        if (open && any_col) DST::store(wptr, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace layout (shared by the sort and apply entry points)
+struct SortWs {
+    char* keys_a;
+    char* keys_b;
+    uint32_t* vals_a;
+    uint32_t* vals_b;
+    uint32_t* bag_of;
+    void* temp;
+    size_t temp_bytes;
+    size_t total;
+};
+
+inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+template <typename K>
+hipError_t rocprim_temp_bytes(int64_t n, int kbits_sort, size_t& bytes) {
+    bytes = 0;
+    K* kn = nullptr;
+    uint32_t* vn = nullptr;
+    return rocprim::radix_sort_pairs(nullptr, bytes, kn, kn, vn, vn, static_cast<size_t>(n), 0u,
+                                     static_cast<unsigned>(kbits_sort), hipStream_t(0));
+}
+
+hipError_t ws_layout(void* base, int64_t n, int key_bytes, int kbits_sort, bool weighted, SortWs& ws) {
+    size_t tb = 0;
+    hipError_t rc = key_bytes == 4 ? rocprim_temp_bytes<uint32_t>(n, kbits_sort, tb)
+                                   : rocprim_temp_bytes<uint64_t>(n, kbits_sort, tb);
+    if (rc != hipSuccess) return rc;
+    char* p = reinterpret_cast<char*>(base);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* q = p ? p + off : nullptr; off += align256(bytes); return q; };
+    ws.keys_a = take(static_cast<size_t>(n) * key_bytes);
+    ws.keys_b = take(static_cast<size_t>(n) * key_bytes);
+    ws.vals_a = reinterpret_cast<uint32_t*>(take(static_cast<size_t>(n) * 4));
+    ws.vals_b = reinterpret_cast<uint32_t*>(take(static_cast<size_t>(n) * 4));
+    ws.bag_of = reinterpret_cast<uint32_t*>(take(weighted ? static_cast<size_t>(n) * 4 : 0));
+    ws.temp = take(tb);
+    ws.temp_bytes = tb;
+    ws.total = off;
+    return hipSuccess;
+}
+
+inline int bits_for(int64_t n_values) {  // bits needed to represent 0 .. n_values-1
+    int b = 0;
+    while ((static_cast<int64_t>(1) << b) < n_values) ++b;
+    return b;
+}
+
+template <typename K>
+hipError_t sort_impl(const KParams& p, bool weighted, int rbits, int kbits, int64_t slice_begin, int64_t slice_end,
+                     bool sliced, SortWs& ws, hipStream_t stream) {
+    KParams q = p;
+    q.bag_begin = 0;
+    q.bag_count = p.B;
+    q.tiles_per_table = static_cast<int32_t>((p.B + p.bags_per_block - 1) / p.bags_per_block);
+    q.xcd_affine = 0;
+    const int grid = q.T * q.tiles_per_table;
+    const size_t lds = static_cast<size_t>(q.bags_per_block + 2) * sizeof(int64_t);
+    K* ka = reinterpret_cast<K*>(ws.keys_a);
+    K* kb = reinterpret_cast<K*>(ws.keys_b);
+    if (weighted)
+        hipLaunchKernelGGL((build_keys_kernel<K, true>), dim3(grid), dim3(kBlock), lds, stream, q, ka, ws.vals_a,
+                           ws.bag_of, rbits, kbits, slice_begin, slice_end);
+    else
+        hipLaunchKernelGGL((build_keys_kernel<K, false>), dim3(grid), dim3(kBlock), lds, stream, q, ka, ws.vals_a,
+                           ws.bag_of, rbits, kbits, slice_begin, slice_end);
+    hipError_t rc = hipGetLastError();
+    if (rc != hipSuccess) return rc;
+    size_t tb = ws.temp_bytes;
+    // stable LSD radix sort over the used key bits only; sorted pairs land in keys_b / vals_b
+    return rocprim::radix_sort_pairs(ws.temp, tb, ka, kb, ws.vals_a, ws.vals_b, static_cast<size_t>(p.N), 0u,
+                                     static_cast<unsigned>(kbits + (sliced ? 1 : 0)), stream);
+}
+
+template <typename DST, typename K, int G>
+hipError_t launch_apply_w(const SortedParams& sp, hipStream_t stream) {
+    const int64_t grid = (sp.n + kSortTile - 1) / kSortTile;
+    if (sp.psw)
+        hipLaunchKernelGGL((bwd_sorted_kernel<DST, K, G, true>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, sp);
+    else
+        hipLaunchKernelGGL((bwd_sorted_kernel<DST, K, G, false>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, sp);
+    return hipGetLastError();
+}
+
+template <typename DST, typename K>
+hipError_t launch_apply_g(const SortedParams& sp, int max_dim, hipStream_t stream) {
+    switch (group_lanes(max_dim, DST::kVec)) {
+        case 8: return launch_apply_w<DST, K, 8>(sp, stream);
+        case 16: return launch_apply_w<DST, K, 16>(sp, stream);
+        case 32: return launch_apply_w<DST, K, 32>(sp, stream);
+        default: return launch_apply_w<DST, K, 64>(sp, stream);
+    }
+}
+
+template <typename K>
+hipError_t launch_apply_k(const SortedParams& sp, int dst_dtype, int max_dim, hipStream_t stream) {
+    switch (dst_dtype) {
+        case PM_F32: return launch_apply_g<SDstF32, K>(sp, max_dim, stream);
+        case PM_BF16: return launch_apply_g<SDstBF16, K>(sp, max_dim, stream);
+        default: return launch_apply_g<SDstF16, K>(sp, max_dim, stream);
+    }
+}
+
+}  // namespace
+
+// ---- entry points used by capi.hip -----------------------------------------------------------
+struct SortedGeom {
+    int key_bytes, rbits, kbits;
+    bool sliced, weighted;
+};
+
+static SortedGeom sorted_geom(const KParams& p, int64_t max_rows) {
+    SortedGeom g;
+    g.rbits = bits_for(max_rows);
+    g.kbits = g.rbits + bits_for(p.T);
+    g.sliced = !(p.bag_begin == 0 && p.bag_count == p.B);
+    g.weighted = p.psw != nullptr;
+    g.key_bytes = (g.kbits + 1 <= 32) ? 4 : 8;
+    return g;
+}
+
+hipError_t sorted_workspace_bytes(const KParams& p, int64_t max_rows, size_t& bytes) {
+    const SortedGeom g = sorted_geom(p, max_rows);
+    SortWs ws;
+    hipError_t rc = ws_layout(nullptr, p.N, g.key_bytes, g.kbits + 1, g.weighted, ws);
+    bytes = ws.total;
+    return rc;
+}
+
+hipError_t sort_indices(const KParams& p, int64_t max_rows, void* workspace, hipStream_t stream) {
+    const SortedGeom g = sorted_geom(p, max_rows);
+    SortWs ws;
+    hipError_t rc = ws_layout(workspace, p.N, g.key_bytes, g.kbits + 1, g.weighted, ws);
+    if (rc != hipSuccess) return rc;
+    return g.key_bytes == 4
+               ? sort_impl<uint32_t>(p, g.weighted, g.rbits, g.kbits, p.bag_begin, p.bag_begin + p.bag_count, g.sliced, ws, stream)
+               : sort_impl<uint64_t>(p, g.weighted, g.rbits, g.kbits, p.bag_begin, p.bag_begin + p.bag_count, g.sliced, ws, stream);
+}
+
+hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, int max_dim, const void* workspace,
+                            hipStream_t stream) {
+    const SortedGeom g = sorted_geom(p, max_rows);
+    SortWs ws;
+    hipError_t rc = ws_layout(const_cast<void*>(workspace), p.N, g.key_bytes, g.kbits + 1, g.weighted, ws);
+    if (rc != hipSuccess) return rc;
+    SortedParams sp;
+    sp.keys = ws.keys_b;
+    sp.vals = ws.vals_b;
+    sp.bag_of = ws.bag_of;
+    sp.dst = const_cast<void* const*>(p.tables);
+    sp.dims = p.dims;
+    sp.out_offsets = p.out_offsets;
+    sp.grad = p.io;
+    sp.psw = p.psw;
+    sp.out_stride = p.out_stride;
+    sp.n = p.N;
+    sp.rbits = g.rbits;
+    sp.kbits = g.kbits;
+    sp.max_dim = max_dim;
+    sp.alpha = p.alpha;
+    if (sp.n == 0) return hipSuccess;
+    return g.key_bytes == 4 ? launch_apply_k<uint32_t>(sp, dst_dtype, max_dim, stream)
+                            : launch_apply_k<uint64_t>(sp, dst_dtype, max_dim, stream);
+}
+
+}  // namespace pm

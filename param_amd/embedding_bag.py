@@ -147,16 +147,49 @@ def _fwd(ts: _TableSet, indices, offsets, B, psw=None, out=None, bag_begin=0, ba
     return out
 
 
+def _workspace(ts: _TableSet, op) -> torch.Tensor:
+    """Scratch for the sort-based backward, cached on the table set (grown, never shrunk)."""
+    need = _lib.load().pm_embbag_bwd_sorted_workspace(ctypes.byref(op), max(ts.rows))
+    if need < 0:
+        _lib.check(int(need))
+    ws = getattr(ts, "_ws", None)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(int(need), dtype=torch.uint8, device=ts.device)
+        ts._ws = ws
+    return ws
+
+
+def _sort_indices(ts: _TableSet, indices, offsets, B, psw=None, bag_begin=0, bag_count=None) -> None:
+    """Step 1+2 of the deterministic backward (keys + stable radix sort): needs only the request,
+    so it can be issued early / on another stream; ``_bwd(..., presorted=True)`` consumes it."""
+    op = ts.request(indices, offsets, B, psw, bag_begin, bag_count)
+    ws = _workspace(ts, op)
+    _lib.check(_lib.load().pm_embbag_sort_indices(ctypes.byref(op), max(ts.rows), ws.data_ptr(), ws.numel(),
+                                                  _stream_ptr()))
+
+
 def _bwd(ts: _TableSet, grad, indices, offsets, B, dst_ptrs_dev, dst_dtype, alpha, psw=None,
-         bag_begin=0, bag_count=None):
+         bag_begin=0, bag_count=None, method: str = "sorted", presorted: bool = False):
+    """``method="sorted"`` (default): deterministic, bit-identical to a sequential scatter-add;
+    ``method="atomic"``: hardware float atomics (order not fixed)."""
     _require_device(grad, "grad")
     _, _, shape = ts.out_desc(B)
     if grad.dtype != torch.float32 or tuple(grad.shape) != tuple(shape):
         raise ValueError(f"grad must be float32 of shape {shape}")
     grad = grad.contiguous()
     op = ts.request(indices, offsets, B, psw, bag_begin, bag_count)
-    _lib.check(_lib.load().pm_embbag_bwd(ctypes.byref(op), grad.data_ptr(), dst_ptrs_dev.data_ptr(),
-                                         _WDTYPE[dst_dtype], float(alpha), _stream_ptr()))
+    L = _lib.load()
+    if method == "atomic":
+        _lib.check(L.pm_embbag_bwd(ctypes.byref(op), grad.data_ptr(), dst_ptrs_dev.data_ptr(),
+                                   _WDTYPE[dst_dtype], float(alpha), _stream_ptr()))
+        return
+    if method != "sorted":
+        raise ValueError('method must be "sorted" or "atomic"')
+    ws = _workspace(ts, op)
+    if not presorted:
+        _lib.check(L.pm_embbag_sort_indices(ctypes.byref(op), max(ts.rows), ws.data_ptr(), ws.numel(), _stream_ptr()))
+    _lib.check(L.pm_embbag_bwd_sorted(ctypes.byref(op), grad.data_ptr(), dst_ptrs_dev.data_ptr(), _WDTYPE[dst_dtype],
+                                      float(alpha), max(ts.rows), ws.data_ptr(), ws.numel(), _stream_ptr()))
 
 
 def check_request(ts: _TableSet, indices, offsets, B, psw=None) -> None:
@@ -328,21 +361,28 @@ class BatchedEmbeddingBagMI355(nn.Module):
             return _FusedUpdateFn.apply(self._anchor, self, indices, offsets, per_sample_weights)
         return self.lookup(indices, offsets, per_sample_weights)
 
+    def sort_indices(self, indices, offsets, per_sample_weights=None, batch: Optional[int] = None) -> None:
+        """Pre-sort the request for the deterministic backward (can overlap the forward)."""
+        B = self._batch_of(offsets) if batch is None else batch
+        _sort_indices(self._tables(), indices, offsets, B, per_sample_weights)
+
     def scatter_add_(self, grad, indices, offsets, alpha: float, per_sample_weights=None,
-                     batch: Optional[int] = None, bag_begin=0, bag_count=None):
+                     batch: Optional[int] = None, bag_begin=0, bag_count=None, method: str = "sorted",
+                     presorted: bool = False):
         """In place ``W_t[idx[j]] += alpha * psw[j] * grad(t, bag(j))`` (alpha = -lr: SGD step)."""
         ts = self._tables()
         B = self._batch_of(offsets) if batch is None else batch
         _bwd(ts, grad, indices, offsets, B, ts.d_ptrs, self.weights.dtype, alpha, per_sample_weights,
-             bag_begin, bag_count)
+             bag_begin, bag_count, method, presorted)
 
-    def dense_grad(self, grad, indices, offsets, per_sample_weights=None, batch: Optional[int] = None):
+    def dense_grad(self, grad, indices, offsets, per_sample_weights=None, batch: Optional[int] = None,
+                   method: str = "sorted"):
         """fp32 dense gradients (list, one per table) -- small tables / parity tests only."""
         ts = self._tables()
         B = self._batch_of(offsets) if batch is None else batch
         outs = [torch.zeros(r, d, dtype=torch.float32, device=ts.device) for r, d in zip(self.rows, self.dims)]
         d_ptrs = torch.tensor([o.data_ptr() for o in outs], dtype=torch.int64, device=ts.device)
-        _bwd(ts, grad, indices, offsets, B, d_ptrs, torch.float32, 1.0, per_sample_weights)
+        _bwd(ts, grad, indices, offsets, B, d_ptrs, torch.float32, 1.0, per_sample_weights, method=method)
         return outs
 
     def check(self, indices, offsets, per_sample_weights=None, batch: Optional[int] = None) -> None:

@@ -175,9 +175,16 @@ def test_backward_dense_grad_goldens(cases, coracle):
         tol = 1e-5 * _mag(W.shape, idx, off, grad, psw) + 1e-30
         assert (np.abs(dW - data[f"{name}.dW"]) <= tol).all(), name          # vs torch dense grad
         ref = coracle.bwd_f32(np.zeros_like(W), idx, off, grad, psw)
-        assert (np.abs(dW - ref) <= tol).all(), name                          # vs the oracle
-        if meta[name]["n_idx"] == meta[name]["bags"]:                         # L=1: one add per row at most...
-            pass
+        # default (sorted, no atomics) path: same order of adds as the sequential oracle -> bit-exact
+        assert np.array_equal(m.weight.grad.cpu().numpy(), ref), name
+        # atomic path (order not fixed): 1e-5 relative
+        from param_amd.embedding_bag import _bwd
+        ts = m._tables()
+        dA = torch.zeros(W.shape, dtype=torch.float32, device=DEV)
+        ptr = torch.tensor([dA.data_ptr()], dtype=torch.int64, device=DEV)
+        _bwd(ts, _t(grad), _t(idx), _t(off), len(off), ptr, torch.float32, 1.0, None if psw is None else _t(psw),
+             method="atomic")
+        assert (np.abs(dA.cpu().numpy().astype(np.float64) - ref) <= tol).all(), name
     # pure scatter (distinct rows, one contribution each) is exact
     W = data["gather_l1.W"]
     idx = np.arange(16, dtype=np.int64) * 3
@@ -203,17 +210,32 @@ def test_fused_inplace_update_fp32_and_bf16(cases, coracle):
     lr = 0.05
     # fp32 tables: W += -lr * grad, in place, all tables in one launch
     m = _batched_from_numpy(tabs)
-    m.scatter_add_(_t(grad), _t(idx), _t(off), alpha=-lr)
+    m.scatter_add_(_t(grad), _t(idx), _t(off), alpha=-lr)                      # sorted: bit-exact
+    ma = _batched_from_numpy(tabs)
+    ma.scatter_add_(_t(grad), _t(idx), _t(off), alpha=-lr, method="atomic")   # atomics: 1e-5
     for t, W in enumerate(tabs):
         s, e = off[t * B], off[(t + 1) * B]
         loc = off[t * B:(t + 1) * B] - s
         g = np.ascontiguousarray(grad[:, t * D:(t + 1) * D])
         exp = coracle.bwd_f32(W.copy(), idx[s:e], loc, g, alpha=-lr)
+        assert np.array_equal(m.table(t).cpu().numpy(), exp), t
         tol = 1e-5 * (_mag(W.shape, idx[s:e], loc, g, None, lr) + np.abs(W)) + 1e-30
-        assert (np.abs(m.table(t).cpu().numpy().astype(np.float64) - exp) <= tol).all(), t
-    # bf16 tables: packed bf16 atomics round once per add -> <= 1 bf16 ulp of the running value per add
+        assert (np.abs(ma.table(t).cpu().numpy().astype(np.float64) - exp) <= tol).all(), t
+    # bf16 tables, sorted path: widen, accumulate the row's whole update in fp32, round once
+    # == oracle_embbag_bwd_bf16, bit for bit
+    ms = _batched_from_numpy(tabs, dtype=torch.bfloat16)
+    ms.scatter_add_(_t(grad), _t(idx), _t(off), alpha=-lr)
+    for t, W in enumerate(tabs):
+        s, e = off[t * B], off[(t + 1) * B]
+        loc = off[t * B:(t + 1) * B] - s
+        g = np.ascontiguousarray(grad[:, t * D:(t + 1) * D])
+        exp_bits = coracle.bwd_bf16(O.f32_to_bf16_bits(W), idx[s:e], loc, g, alpha=-lr)
+        got_bits = ms.table(t).view(torch.int16).cpu().numpy().view(np.uint16)
+        assert np.array_equal(got_bits, exp_bits), t
+    # bf16 tables, atomic path: packed bf16 atomics round once per add -> <= 1 bf16 ulp of the
+    # running value per add
     mb = _batched_from_numpy(tabs, dtype=torch.bfloat16)
-    mb.scatter_add_(_t(grad), _t(idx), _t(off), alpha=-lr)
+    mb.scatter_add_(_t(grad), _t(idx), _t(off), alpha=-lr, method="atomic")
     for t, W in enumerate(tabs):
         s, e = off[t * B], off[(t + 1) * B]
         loc = off[t * B:(t + 1) * B] - s
@@ -247,6 +269,92 @@ def test_autograd_fused_update_path(cases):
         exp = W.astype(np.float64).copy()
         np.add.at(exp, idx[off[t * B]:off[(t + 1) * B]], -0.1)
         assert np.allclose(m.table(t).cpu().numpy(), exp, rtol=1e-5, atol=1e-6), t
+
+
+def test_sorted_backward_mid_size_bit_exact_and_deterministic(coracle):
+    """Heavy duplicates (Zipf head + one row hit by every lookup of a bag range), ragged bags,
+    per-sample weights, several dims, int32/int64 indices: sorted path == sequential oracle."""
+    from param_amd.embedding_bag import _bwd, _sort_indices
+    from param_amd.indices import zipf_indices
+
+    rng = np.random.default_rng(21)
+    for D, weighted, it in [(128, False, torch.int64), (64, True, torch.int64), (56, False, torch.int32),
+                            (256, False, torch.int64), (512, True, torch.int32), (8, False, torch.int64)]:
+        R, B = 20000, 700
+        lens = rng.integers(0, 60, B)
+        lens[3] = 5000
+        off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+        n = int(lens.sum())
+        idx = zipf_indices(1.2, R, n, 1, dedupe=False, generator=torch.Generator().manual_seed(D)).numpy()
+        idx[off[3]:off[3] + 5000] = 17                     # one very long run
+        grad = rng.standard_normal((B, D)).astype(np.float32)
+        psw = rng.standard_normal(n).astype(np.float32) if weighted else None
+        W = rng.standard_normal((R, D)).astype(np.float32)
+        exp = coracle.bwd_f32(W.copy(), idx, off, grad, psw, alpha=-0.03)
+        m = _module(W)
+        ts = m._tables()
+        tabs_ptr = ts.d_ptrs
+        args = (_t(grad), _t(idx, it), _t(off, it), B, tabs_ptr, torch.float32, -0.03, None if psw is None else _t(psw))
+        _bwd(ts, *args)
+        got = m.weight.data.cpu().numpy()
+        assert np.array_equal(got, exp), (D, weighted)
+        # pre-sorted on the request alone, then applied: same bits; and again from scratch: same bits
+        m2 = _module(W)
+        ts2 = m2._tables()
+        _sort_indices(ts2, args[1], args[2], B, args[7])
+        _bwd(ts2, args[0], args[1], args[2], B, ts2.d_ptrs, torch.float32, -0.03, args[7], presorted=True)
+        assert np.array_equal(m2.weight.data.cpu().numpy(), exp), (D, weighted)
+
+
+def test_sorted_backward_batch_slice_and_multi_table(cases, coracle):
+    data, meta = cases
+    name = "tbe_same"
+    tabs = [data[f"{name}.W{t}"] for t in range(meta[name]["tables"])]
+    idx, off, B = data[f"{name}.idx"], data[f"{name}.off"], meta[name]["bags"]
+    D = tabs[0].shape[1]
+    grad = np.random.default_rng(4).standard_normal((B, D * len(tabs))).astype(np.float32)
+    m = _batched_from_numpy(tabs)
+    # two disjoint batch slices compose to the full update
+    m.scatter_add_(_t(grad), _t(idx), _t(off), alpha=0.5, bag_begin=0, bag_count=6)
+    m.scatter_add_(_t(grad), _t(idx), _t(off), alpha=0.5, bag_begin=6, bag_count=B - 6)
+    for t, W in enumerate(tabs):
+        s = off[t * B]
+        loc = off[t * B:(t + 1) * B + 1] - s
+        g = np.ascontiguousarray(grad[:, t * D:(t + 1) * D])
+        exp = coracle.bwd_f32(W.copy(), idx[s:s + loc[6]], loc[:6], g[:6], alpha=0.5)
+        exp = coracle.bwd_f32(exp, idx[s + loc[6]:s + loc[B]], loc[6:B] - loc[6], g[6:], alpha=0.5)
+        assert np.array_equal(m.table(t).cpu().numpy(), exp), t
+
+
+def test_sorted_backward_wide_keys():
+    """rows close to 2^30 with several tables -> 64-bit sort keys; checked on the touched rows
+    against the independent atomic kernel (1e-5) and for exact determinism."""
+    from param_amd import BatchedEmbeddingBagMI355
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < (60 << 30):
+        pytest.skip("needs ~40 GiB")
+    rows = [1 << 30, 1000, 5000, 77, 300]          # bits(2^30)=30 + bits(5)=3 -> 33-bit keys
+    m = BatchedEmbeddingBagMI355(rows, 4, device=DEV, init=None, fused_update=False)
+    m.weights.data.zero_()
+    B, L = 64, 6
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    idx = torch.cat([torch.randint(0, r, (B * L,), device=DEV, generator=gen) for r in rows])
+    idx[:40] = (1 << 30) - 1                       # last row of the big table, many duplicates
+    off = torch.arange(len(rows) * B + 1, device=DEV) * L
+    grad = torch.randn(B, 4 * len(rows), device=DEV, generator=gen)
+    m.scatter_add_(grad, idx, off, alpha=1.0)
+    touched = [m.table(t)[idx[t * B * L:(t + 1) * B * L]].clone() for t in range(len(rows))]
+    m.weights.data.zero_()
+    m.scatter_add_(grad, idx, off, alpha=1.0)
+    for t in range(len(rows)):
+        assert torch.equal(m.table(t)[idx[t * B * L:(t + 1) * B * L]], touched[t])
+    m.weights.data.zero_()
+    m.scatter_add_(grad, idx, off, alpha=1.0, method="atomic")
+    for t in range(len(rows)):
+        ref = m.table(t)[idx[t * B * L:(t + 1) * B * L]]
+        assert torch.allclose(ref, touched[t], rtol=1e-5, atol=1e-5), t
+    assert float(m.table(0)[(1 << 30) - 1].abs().sum()) > 0
 
 
 # ----------------------------------------------------------------------------- utilities
