@@ -126,8 +126,11 @@ int pm_embbag_bwd(const pm_embbag_batch* op, const float* grad, void* const* dst
  *                                   it may run on a side stream under the forward pass;
  *   pm_embbag_bwd_sorted            same arithmetic as pm_embbag_bwd, but every destination
  *                                   row is read once, updated in fp32 registers in lookup
- *                                   order and written once: bit-identical to a sequential
- *                                   CPU scatter-add and run-to-run reproducible.  Requires
+ *                                   order and written once: run-to-run reproducible, and
+ *                                   bit-identical to a sequential CPU scatter-add for every
+ *                                   row looked up at most 256 times in the call (hotter rows
+ *                                   are summed as ordered per-chunk partial sums: same value
+ *                                   up to fp32 rounding of the association).  Requires
  *                                   pm_embbag_sort_indices on the same workspace and request
  *                                   (stream-ordered before it).  16-bit destinations are
  *                                   widened, accumulated in fp32 and rounded once per row.

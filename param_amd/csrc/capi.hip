@@ -166,7 +166,7 @@ int64_t pm_embbag_bwd_sorted_workspace(const pm_embbag_batch* op, int64_t max_ro
     if (rc != PM_OK) return rc;
     if ((rc = sorted_args_ok(op, max_rows)) != PM_OK) return rc;
     size_t bytes = 0;
-    hipError_t h = pm::sorted_workspace_bytes(p, max_rows, bytes);
+    hipError_t h = pm::sorted_workspace_bytes(p, max_rows, op->max_dim, bytes);
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_bwd_sorted_workspace");
     return static_cast<int64_t>(bytes);
 }
@@ -179,11 +179,11 @@ int pm_embbag_sort_indices(const pm_embbag_batch* op, int64_t max_rows, void* wo
     if ((rc = sorted_args_ok(op, max_rows)) != PM_OK) return rc;
     if (p.N == 0) return PM_OK;
     size_t need = 0;
-    hipError_t h = pm::sorted_workspace_bytes(p, max_rows, need);
+    hipError_t h = pm::sorted_workspace_bytes(p, max_rows, op->max_dim, need);
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_sort_indices");
     if (!workspace || workspace_bytes < static_cast<int64_t>(need))
         return fail(PM_ERR_INVALID, "workspace too small: need " + std::to_string(need) + " bytes");
-    h = pm::sort_indices(p, max_rows, workspace, static_cast<hipStream_t>(stream));
+    h = pm::sort_indices(p, max_rows, op->max_dim, workspace, static_cast<hipStream_t>(stream));
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_sort_indices");
     return PM_OK;
 }
@@ -198,7 +198,7 @@ int pm_embbag_bwd_sorted(const pm_embbag_batch* op, const float* grad, void* con
     if (p.N == 0 || p.bag_count == 0) return PM_OK;
     if (!grad || !dst_tables) return fail(PM_ERR_INVALID, "grad / dst_tables is NULL");
     size_t need = 0;
-    hipError_t h = pm::sorted_workspace_bytes(p, max_rows, need);
+    hipError_t h = pm::sorted_workspace_bytes(p, max_rows, op->max_dim, need);
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_bwd_sorted");
     if (!workspace || workspace_bytes < static_cast<int64_t>(need))
         return fail(PM_ERR_INVALID, "workspace too small: need " + std::to_string(need) + " bytes");

@@ -115,8 +115,8 @@ hipError_t launch_fill_random(void* dst, int64_t count, int dtype, int dist, flo
                               uint64_t seed, hipStream_t stream);
 
 // sort-based deterministic backward (embbag_bwd_sorted.hip)
-hipError_t sorted_workspace_bytes(const KParams& p, int64_t max_rows, size_t& bytes);
-hipError_t sort_indices(const KParams& p, int64_t max_rows, void* workspace, hipStream_t stream);
+hipError_t sorted_workspace_bytes(const KParams& p, int64_t max_rows, int max_dim, size_t& bytes);
+hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, void* workspace, hipStream_t stream);
 hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, int max_dim, const void* workspace,
                             hipStream_t stream);
 

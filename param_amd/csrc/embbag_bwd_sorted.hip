@@ -32,7 +32,12 @@ namespace {
 constexpr int kSortTile = 1024;  // sorted positions per workgroup in step 3
 constexpr int kBatch = 4;        // positions whose loads are issued together per lane group
 
+struct ChunkRec;
+
 struct SortedParams {
+    ChunkRec* recs;          // per-chunk piece lengths of boundary-crossing runs (main -> fix-up)
+    float* partials;         // per chunk: lead / trail fp32 partial sums, 2 * max_dim floats
+    int32_t T;
     const void* keys;        // sorted keys (uint32 / uint64)
     const uint32_t* vals;    // sorted values: bag within table (unweighted) or lookup position j (weighted)
     const uint32_t* bag_of;  // weighted only: bag within table of lookup position j
@@ -142,132 +147,7 @@ struct SDstF16 {
     }
 };
 
-// step 3: stream the sorted pairs.  A group of G lanes owns positions [c0, c1) of the sorted
-// order and every run of equal keys that STARTS there (it follows its last run past c1 and
-// skips a leading run that started before c0).  Per batch of kBatch positions all gradient-row
-// loads and all run-head destination-row loads are issued before the first add.
-template <typename DST, typename K, int G, bool WEIGHTED>
-__global__ void __launch_bounds__(kBlock) bwd_sorted_kernel(const SortedParams p) {
-    constexpr int VEC = DST::kVec;
-    constexpr int NG = kBlock / G;
-    constexpr int C = kSortTile / NG;
-    __shared__ K s_key[kSortTile + 1];      // s_key[i + 1] = key of position base + i; s_key[0] = predecessor
-    __shared__ uint32_t s_val[kSortTile];
-
-    const K* keys = reinterpret_cast<const K*>(p.keys);
-    const int64_t base = static_cast<int64_t>(blockIdx.x) * kSortTile;
-    const int n_tile = (p.n - base) < kSortTile ? static_cast<int>(p.n - base) : kSortTile;
-    for (int i = threadIdx.x; i < n_tile; i += kBlock) {
-        s_key[i + 1] = keys[base + i];
-        s_val[i] = p.vals[base + i];
-    }
-    if (threadIdx.x == 0) s_key[0] = base > 0 ? keys[base - 1] : static_cast<K>(0);
-    __syncthreads();
-
-    const K pad_bit = static_cast<K>(1) << p.kbits;
-    const K row_mask = (static_cast<K>(1) << p.rbits) - 1;
-    auto key_at = [&](int64_t q) -> K {  // q absolute, base - 1 <= q < n
-        const int64_t r = q - base;
-        return r < n_tile ? s_key[r + 1] : keys[q];
-    };
-    auto val_at = [&](int64_t q) -> uint32_t {
-        const int64_t r = q - base;
-        return r < n_tile ? s_val[r] : p.vals[q];
-    };
-
-    const int gid = threadIdx.x / G;
-    const int lig = threadIdx.x % G;
-    const int64_t c0 = base + static_cast<int64_t>(gid) * C;
-    const int64_t c1 = (c0 + C < base + n_tile) ? c0 + C : base + n_tile;
-    if (c0 >= c1) return;
-
-    // One pass per column chunk (one pass when G*VEC >= D, the normal case).
-    for (int c = lig * VEC; c < p.max_dim; c += G * VEC) {
-        bool open = false, done = false, any_col = false;
-        float acc[VEC];
-        char* wptr = nullptr;
-        for (int64_t pos = c0; !done && (pos < c1 || open); pos += kBatch) {
-            K kk[kBatch + 1];
-            uint32_t vv[kBatch];
-            bool valid[kBatch], head[kBatch];
-            kk[0] = pos > 0 ? key_at(pos - 1) : static_cast<K>(0);
-#pragma unroll
-            for (int u = 0; u < kBatch; ++u) {
-                valid[u] = (pos + u) < p.n;
-                kk[u + 1] = valid[u] ? key_at(pos + u) : pad_bit;
-                valid[u] = valid[u] && !(kk[u + 1] & pad_bit);  // padding keys sort last: end of data
-                vv[u] = valid[u] ? val_at(pos + u) : 0u;
-                head[u] = valid[u] && ((pos + u) == 0 || kk[u + 1] != kk[u]);
-            }
-            // issue every load of the batch
-            float gv[kBatch][VEC];
-            float wv[kBatch][VEC];
-            float sc[kBatch];
-            char* wp[kBatch];
-            bool col_ok[kBatch];
-#pragma unroll
-            for (int u = 0; u < kBatch; ++u) {
-                col_ok[u] = false;
-                if (valid[u]) {
-                    const int t = static_cast<int>(kk[u + 1] >> p.rbits);
-                    const int64_t row = static_cast<int64_t>(kk[u + 1] & row_mask);
-                    const int D = p.dims[t];
-                    col_ok[u] = c < D;
-                    if (col_ok[u]) {
-                        uint32_t bag = vv[u];
-                        sc[u] = p.alpha;
-                        if (WEIGHTED) {
-                            sc[u] = p.alpha * p.psw[vv[u]];
-                            bag = p.bag_of[vv[u]];
-                        }
-                        const float* g = p.grad + p.out_offsets[t] + static_cast<int64_t>(bag) * p.out_stride + c;
-#pragma unroll
-                        for (int k = 0; k < VEC; k += 4) {
-                            const f32x4 x = *reinterpret_cast<const f32x4*>(g + k);
-                            gv[u][k] = x.x; gv[u][k + 1] = x.y; gv[u][k + 2] = x.z; gv[u][k + 3] = x.w;
-                        }
-                        wp[u] = reinterpret_cast<char*>(p.dst[t]) + (row * D + c) * DST::kES;
-                        if (head[u] && (pos + u) < c1) DST::load(wp[u], wv[u]);
-                    }
-                }
-            }
-            // consume in sorted order
-#pragma unroll
-            for (int u = 0; u < kBatch; ++u) {
-                if (done) break;
-                if (!valid[u]) {  // end of data
-                    done = true;
-                    break;
-                }
-                if (head[u]) {
-                    if (open) {
-                        if (any_col) DST::store(wptr, acc);
-                        open = false;
-                    }
-                    if ((pos + u) >= c1) {  // this run belongs to the next group
-                        done = true;
-                        break;
-                    }
-                    open = true;
-                    any_col = col_ok[u];
-                    wptr = wp[u];
-                    if (any_col) {
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) acc[k] = wv[u][k];
-                    }
-                }
-                if (open && any_col) {
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) {
-                        const float prod = sc[u] * gv[u][k];
-                        acc[k] = acc[k] + prod;
-                    }
-                }
-            }
-        }
-        if (open && any_col) DST::store(wptr, acc);
-    }
-}
+#include "embbag_bwd_sorted_kernels.inc"
 
 // ---------------------------------------------------------------------------------------------
 // workspace layout (shared by the sort and apply entry points)
@@ -277,10 +157,20 @@ struct SortWs {
     uint32_t* vals_a;
     uint32_t* vals_b;
     uint32_t* bag_of;
+    ChunkRec* recs;
+    float* partials;
     void* temp;
     size_t temp_bytes;
     size_t total;
 };
+
+// chunks of the apply kernels: kSortTile / (kBlock / G) positions each; sized for the smallest
+// chunk any destination dtype can select for this max_dim (16-bit destinations: 8 elements/lane)
+inline int64_t max_chunks(int64_t n, int max_dim) {
+    const int g = group_lanes(max_dim, 8);
+    const int c = kSortTile / (kBlock / g);
+    return (n + c - 1) / c + 1;
+}
 
 inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
@@ -293,7 +183,7 @@ hipError_t rocprim_temp_bytes(int64_t n, int kbits_sort, size_t& bytes) {
                                      static_cast<unsigned>(kbits_sort), hipStream_t(0));
 }
 
-hipError_t ws_layout(void* base, int64_t n, int key_bytes, int kbits_sort, bool weighted, SortWs& ws) {
+hipError_t ws_layout(void* base, int64_t n, int key_bytes, int kbits_sort, bool weighted, int max_dim, SortWs& ws) {
     size_t tb = 0;
     hipError_t rc = key_bytes == 4 ? rocprim_temp_bytes<uint32_t>(n, kbits_sort, tb)
                                    : rocprim_temp_bytes<uint64_t>(n, kbits_sort, tb);
@@ -306,6 +196,9 @@ hipError_t ws_layout(void* base, int64_t n, int key_bytes, int kbits_sort, bool 
     ws.vals_a = reinterpret_cast<uint32_t*>(take(static_cast<size_t>(n) * 4));
     ws.vals_b = reinterpret_cast<uint32_t*>(take(static_cast<size_t>(n) * 4));
     ws.bag_of = reinterpret_cast<uint32_t*>(take(weighted ? static_cast<size_t>(n) * 4 : 0));
+    const size_t nch = static_cast<size_t>(max_chunks(n, max_dim));
+    ws.recs = reinterpret_cast<ChunkRec*>(take(nch * sizeof(ChunkRec)));
+    ws.partials = reinterpret_cast<float*>(take(nch * 2 * static_cast<size_t>(max_dim) * sizeof(float)));
     ws.temp = take(tb);
     ws.temp_bytes = tb;
     ws.total = off;
@@ -346,11 +239,18 @@ hipError_t sort_impl(const KParams& p, bool weighted, int rbits, int kbits, int6
 
 template <typename DST, typename K, int G>
 hipError_t launch_apply_w(const SortedParams& sp, hipStream_t stream) {
+    constexpr int NG = kBlock / G;
+    constexpr int C = kSortTile / NG;
     const int64_t grid = (sp.n + kSortTile - 1) / kSortTile;
-    if (sp.psw)
-        hipLaunchKernelGGL((bwd_sorted_kernel<DST, K, G, true>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, sp);
-    else
-        hipLaunchKernelGGL((bwd_sorted_kernel<DST, K, G, false>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, sp);
+    const int64_t n_chunks = (sp.n + C - 1) / C;       // every chunk below this index wrote its record
+    const int64_t fgrid = (n_chunks + NG - 1) / NG;
+    if (sp.psw) {
+        hipLaunchKernelGGL((bwd_sorted_main_kernel<DST, K, G, true>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, sp);
+        hipLaunchKernelGGL((bwd_sorted_fixup_kernel<DST, K, G, true>), dim3(static_cast<unsigned>(fgrid)), dim3(kBlock), 0, stream, sp, n_chunks);
+    } else {
+        hipLaunchKernelGGL((bwd_sorted_main_kernel<DST, K, G, false>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, sp);
+        hipLaunchKernelGGL((bwd_sorted_fixup_kernel<DST, K, G, false>), dim3(static_cast<unsigned>(fgrid)), dim3(kBlock), 0, stream, sp, n_chunks);
+    }
     return hipGetLastError();
 }
 
@@ -391,18 +291,18 @@ static SortedGeom sorted_geom(const KParams& p, int64_t max_rows) {
     return g;
 }
 
-hipError_t sorted_workspace_bytes(const KParams& p, int64_t max_rows, size_t& bytes) {
+hipError_t sorted_workspace_bytes(const KParams& p, int64_t max_rows, int max_dim, size_t& bytes) {
     const SortedGeom g = sorted_geom(p, max_rows);
     SortWs ws;
-    hipError_t rc = ws_layout(nullptr, p.N, g.key_bytes, g.kbits + 1, g.weighted, ws);
+    hipError_t rc = ws_layout(nullptr, p.N, g.key_bytes, g.kbits + 1, g.weighted, max_dim, ws);
     bytes = ws.total;
     return rc;
 }
 
-hipError_t sort_indices(const KParams& p, int64_t max_rows, void* workspace, hipStream_t stream) {
+hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, void* workspace, hipStream_t stream) {
     const SortedGeom g = sorted_geom(p, max_rows);
     SortWs ws;
-    hipError_t rc = ws_layout(workspace, p.N, g.key_bytes, g.kbits + 1, g.weighted, ws);
+    hipError_t rc = ws_layout(workspace, p.N, g.key_bytes, g.kbits + 1, g.weighted, max_dim, ws);
     if (rc != hipSuccess) return rc;
     return g.key_bytes == 4
                ? sort_impl<uint32_t>(p, g.weighted, g.rbits, g.kbits, p.bag_begin, p.bag_begin + p.bag_count, g.sliced, ws, stream)
@@ -413,9 +313,13 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
                             hipStream_t stream) {
     const SortedGeom g = sorted_geom(p, max_rows);
     SortWs ws;
-    hipError_t rc = ws_layout(const_cast<void*>(workspace), p.N, g.key_bytes, g.kbits + 1, g.weighted, ws);
+    hipError_t rc = ws_layout(const_cast<void*>(workspace), p.N, g.key_bytes, g.kbits + 1, g.weighted, max_dim, ws);
     if (rc != hipSuccess) return rc;
+    if (p.T > kMaxTablesLds) return hipErrorInvalidValue;
     SortedParams sp;
+    sp.recs = ws.recs;
+    sp.partials = ws.partials;
+    sp.T = p.T;
     sp.keys = ws.keys_b;
     sp.vals = ws.vals_b;
     sp.bag_of = ws.bag_of;

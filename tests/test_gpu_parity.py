@@ -12,6 +12,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
+EXACT_RUN = 256  # kExactRun in param_amd/csrc/embbag_bwd_sorted_kernels.inc
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -176,7 +177,11 @@ def test_backward_dense_grad_goldens(cases, coracle):
         assert (np.abs(dW - data[f"{name}.dW"]) <= tol).all(), name          # vs torch dense grad
         ref = coracle.bwd_f32(np.zeros_like(W), idx, off, grad, psw)
         # default (sorted, no atomics) path: same order of adds as the sequential oracle -> bit-exact
-        assert np.array_equal(m.weight.grad.cpu().numpy(), ref), name
+        # for every row looked up at most EXACT_RUN times; hotter rows: ordered chunk partials, 1e-5
+        got = m.weight.grad.cpu().numpy()
+        cold = np.bincount(idx, minlength=W.shape[0]) <= EXACT_RUN
+        assert np.array_equal(got[cold], ref[cold]), name
+        assert (np.abs(got.astype(np.float64) - ref) <= tol).all(), name
         # atomic path (order not fixed): 1e-5 relative
         from param_amd.embedding_bag import _bwd
         ts = m._tables()
@@ -297,13 +302,17 @@ def test_sorted_backward_mid_size_bit_exact_and_deterministic(coracle):
         args = (_t(grad), _t(idx, it), _t(off, it), B, tabs_ptr, torch.float32, -0.03, None if psw is None else _t(psw))
         _bwd(ts, *args)
         got = m.weight.data.cpu().numpy()
-        assert np.array_equal(got, exp), (D, weighted)
-        # pre-sorted on the request alone, then applied: same bits; and again from scratch: same bits
+        cold = np.bincount(idx, minlength=R) <= EXACT_RUN
+        assert cold.sum() > 0.9 * R and (~cold).sum() >= 3          # both regimes are exercised
+        assert np.array_equal(got[cold], exp[cold]), (D, weighted)   # bit-exact: sequential order
+        tol = 1e-5 * (_mag(W.shape, idx, off, grad, psw, 0.03) + np.abs(W)) + 1e-30
+        assert (np.abs(got.astype(np.float64) - exp) <= tol).all(), (D, weighted)
+        # pre-sorted on the request alone, then applied: SAME BITS as the one-call form (deterministic)
         m2 = _module(W)
         ts2 = m2._tables()
         _sort_indices(ts2, args[1], args[2], B, args[7])
         _bwd(ts2, args[0], args[1], args[2], B, ts2.d_ptrs, torch.float32, -0.03, args[7], presorted=True)
-        assert np.array_equal(m2.weight.data.cpu().numpy(), exp), (D, weighted)
+        assert np.array_equal(m2.weight.data.cpu().numpy(), got), (D, weighted)
 
 
 def test_sorted_backward_batch_slice_and_multi_table(cases, coracle):
