@@ -196,33 +196,24 @@ def main():
         def step(i=idx, o=off):
             model.lookup(i, o, out=out, batch=B_glob)
     else:
+        from param_amd.comms.pt.pipeline import LookupAllToAll, split_request_by_group
         from param_amd.embedding_bag import _TableSet, _fwd
 
         tsets = [_TableSet([model.table(g * Tg + t) for t in range(Tg)], "bd") for g in range(groups)]
-        send = [torch.empty((B_glob, Tg * D), dtype=torch.float32, device=dev) for _ in range(groups)]
-        recv = [torch.empty((world * B_local, Tg * D), dtype=torch.float32, device=dev) for _ in range(groups)]
+
+        def hip_lookup(g, ig, og, out_g):  # the HIP batched forward of table group g
+            _fwd(tsets[g], ig, og, B_glob, out=out_g)
+
+        # lookup(g) -> RCCL all_to_all(g) on the process group's own stream, under lookup(g+1)
+        pipe = LookupAllToAll(hip_lookup, world, B_local, [Tg * D] * groups, dev)
 
         def split_request(i, o):
-            reqs = []
-            for g in range(groups):
-                lo, hi = g * Tg * B_glob, (g + 1) * Tg * B_glob
-                og = (o[lo:hi + 1] - o[lo]).contiguous()
-                ig = i[int(o[lo]):int(o[hi])].contiguous()
-                reqs.append((ig, og))
-            return reqs
+            return split_request_by_group(i, o, T_loc, groups, B_glob)
 
         reqs = split_request(idx, off)
 
         def step(rq=None):
-            rq = reqs if rq is None else rq
-            works = []
-            for g in range(groups):
-                _fwd(tsets[g], rq[g][0], rq[g][1], B_glob, out=send[g])
-                # RCCL all-to-all on the process group's own stream: it waits for the lookup
-                # above and then runs under the NEXT group's lookup (compute stream keeps going)
-                works.append(dist.all_to_all_single(recv[g], send[g], async_op=True))
-            for w in works:
-                w.wait()
+            pipe.step(reqs if rq is None else rq)
 
     wall, dev_s = time_steps(step, a.steps, a.warmup, barrier)
     if dist is not None:
@@ -257,10 +248,7 @@ def main():
     if world == 1:
         kern_s = dev_s
     else:  # time the lookups alone (no a2a) for the kernel roofline
-        def lookups_only():
-            for g in range(groups):
-                _fwd(tsets[g], reqs[g][0], reqs[g][1], B_glob, out=send[g])
-        _, kern_s = time_steps(lookups_only, max(5, a.steps // 2), 2, barrier)
+        _, kern_s = time_steps(lambda: pipe.lookups_only(reqs), max(5, a.steps // 2), 2, barrier)
         if dist is not None:
             t = torch.tensor([kern_s], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -284,11 +272,7 @@ def main():
 
     if world > 1:
         a2a_bytes = world * B_local * T_loc * D * 4  # output tensor bytes per rank (reference memSize)
-        def a2a_only():
-            ws = [dist.all_to_all_single(recv[g], send[g], async_op=True) for g in range(groups)]
-            for w in ws:
-                w.wait()
-        _, a2a_s = time_steps(a2a_only, max(5, a.steps // 2), 2, barrier)
+        _, a2a_s = time_steps(pipe.all_to_all_only, max(5, a.steps // 2), 2, barrier)
         t = torch.tensor([a2a_s], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         a2a_s = t.item()
@@ -306,10 +290,7 @@ def main():
             _, us = time_steps(lambda: step(ui, uo), max(5, a.steps // 2), 2, barrier)
         else:
             ur = split_request(ui, uo)
-            def lookups_uniform():
-                for g in range(groups):
-                    _fwd(tsets[g], ur[g][0], ur[g][1], B_glob, out=send[g])
-            _, us = time_steps(lookups_uniform, max(5, a.steps // 2), 2, barrier)
+            _, us = time_steps(lambda: pipe.lookups_only(ur), max(5, a.steps // 2), 2, barrier)
         if dist is not None:
             t = torch.tensor([us], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -1,0 +1,149 @@
+"""Worker bodies for the world_size-2 gloo/CPU tests (spawned by tests/test_dist_gloo.py).
+
+The collectives run for real over loopback; the embedding lookup is a TEST STUB
+(torch.nn.functional.embedding_bag) injected into the pipeline -- the product lookup is the HIP
+kernel and never runs on CPU."""
+import os
+import socket
+import types
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _env(rank, world, port):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank),
+                       "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank), "LOCAL_SIZE": str(world)})
+    torch.set_num_threads(1)
+
+
+def _backend(rank, world, port):
+    from param_amd.comms.pt import comms_utils
+    from param_amd.comms.pt.mi355_backend import MI355XBackend
+
+    env = comms_utils.read_comms_env_vars()
+    assert env == {"world_size": world, "local_size": world, "global_rank": rank, "local_rank": rank}
+    info = comms_utils.bootstrap_info_holder("127.0.0.1", str(port), 0, env)
+    params = types.SimpleNamespace(device="cpu", backend="gloo")
+    bf = MI355XBackend(info, params)
+    bf.initialize_backend("127.0.0.1", str(port), backend="gloo")
+    return bf
+
+
+def backend_collectives(rank, world, port):
+    from param_amd.comms.pt.pytorch_backend_utils import collectiveArgsHolder
+
+    _env(rank, world, port)
+    bf = _backend(rank, world, port)
+    try:
+        ca = collectiveArgsHolder()
+        ca.world_size, ca.global_rank, ca.group, ca.device = world, rank, bf.get_default_group(), bf.get_device()
+        assert bf.get_world_size() == world and bf.get_global_rank() == rank and bf.get_device().type == "cpu"
+        # all_to_allv with uneven splits: rank r sends (r+1) elements to rank 0 and 2 to rank 1
+        send_counts = [[1, 2], [2, 2]][rank]
+        recv_counts = [[1, 2], [2, 2]]
+        recv_counts = [recv_counts[src][rank] for src in range(world)]
+        ca.ipTensor = torch.arange(sum(send_counts), dtype=torch.float32) + 100 * rank
+        ca.opTensor = torch.full((sum(recv_counts),), -1.0)
+        ca.ipTensor_split, ca.opTensor_split, ca.asyncOp = send_counts, recv_counts, True
+        w = bf.all_to_allv(ca, retFlag=True)
+        assert w is not None and ca.waitObj == [w]          # async: queued AND returned
+        bf.complete_accel_ops(ca)
+        assert ca.waitObj == []
+        expect = {0: [0.0, 100.0, 101.0], 1: [1.0, 2.0, 102.0, 103.0]}[rank]
+        assert ca.opTensor.tolist() == expect, (rank, ca.opTensor.tolist())
+        assert bf.get_mem_size(ca) == 4 * len(expect)
+        # list-form all_to_all (gloo has none: the backend flattens it)
+        ca.asyncOp = False
+        ca.ipTensor = [torch.full((3,), float(10 * rank + j)) for j in range(world)]
+        ca.opTensor = [torch.empty(3) for _ in range(world)]
+        assert bf.all_to_all(ca, retFlag=True) is None and ca.waitObj == []
+        for src in range(world):
+            assert ca.opTensor[src].tolist() == [float(10 * src + rank)] * 3
+        # equal-split single form, all_reduce, barrier
+        ca.ipTensor, ca.opTensor = torch.arange(4.0) + 10 * rank, torch.empty(4)
+        ca.ipTensor_split = ca.opTensor_split = [2, 2]
+        bf.all_to_all_single(ca)
+        assert ca.opTensor.tolist() == [[0.0, 1.0, 10.0, 11.0], [2.0, 3.0, 12.0, 13.0]][rank]
+        ca.ipTensor = torch.ones(5) * (rank + 1)
+        ca.op = bf.get_reduce_op("sum")
+        bf.all_reduce(ca)
+        assert ca.ipTensor.tolist() == [3.0] * 5
+        bf.sync_barrier(ca)
+        assert bf.getBusBW("all_to_allv", 10.0, ca) == 5.0 and bf.getBusBW("all_reduce", 10.0, ca) == 10.0
+    finally:
+        bf.shutdown()
+
+
+def comms_sweep(rank, world, port, outdir):
+    import contextlib
+    import io
+    import json
+
+    from param_amd.comms.pt import comms
+
+    _env(rank, world, port)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        res = comms.main(["--master-ip", "127.0.0.1", "--master-port", str(port), "--b", "64", "--e", "1024", "--f", "4",
+                          "--n", "3", "--w", "1", "--z", "1", "--c", "1", "--collective",
+                          "all_to_allv,all_to_all,all_reduce", "--backend", "gloo", "--device", "cpu"])
+    with open(os.path.join(outdir, f"rank{rank}.json"), "w") as f:
+        json.dump({"results": res, "stdout": buf.getvalue()}, f)
+
+
+def pipeline_layout(rank, world, port):
+    from param_amd.comms.pt.pipeline import LookupAllToAll, split_request_by_group
+
+    _env(rank, world, port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        T_loc, groups, D, B_local, L, R = 4, 2, 8, 3, 5, 50
+        Tg, B_glob = T_loc // groups, world * B_local
+        g = torch.Generator().manual_seed(100 + rank)
+        tables = [torch.randn(R, D, generator=g) for _ in range(T_loc)]          # this rank's tables
+        # every rank must look up the SAME global batch: generate it from a shared seed per owner rank
+        def request_for(owner):
+            gg = torch.Generator().manual_seed(7 + owner)
+            idx = torch.randint(0, R, (T_loc * B_glob * L,), generator=gg)
+            off = torch.arange(T_loc * B_glob + 1) * L
+            return idx, off
+        idx, off = request_for(rank)
+        reqs = split_request_by_group(idx, off, T_loc, groups, B_glob)
+        assert [r[1].numel() for r in reqs] == [Tg * B_glob + 1] * groups and int(reqs[1][1][0]) == 0
+
+        def stub_lookup(gi, ig, og, out):  # TEST STUB for the HIP kernel: [B_glob, Tg*D]
+            for t in range(Tg):
+                s, e = int(og[t * B_glob]), int(og[(t + 1) * B_glob])
+                out[:, t * D:(t + 1) * D] = torch.nn.functional.embedding_bag(
+                    ig[s:e], tables[gi * Tg + t], og[t * B_glob:(t + 1) * B_glob] - s, mode="sum")
+
+        pipe = LookupAllToAll(stub_lookup, world, B_local, [Tg * D] * groups, torch.device("cpu"))
+        recv = pipe.step(reqs)
+        assert pipe.bytes_per_rank() == world * B_local * T_loc * D * 4
+        # check: recv[g][src, b, t*D:(t+1)*D] == pooled embedding of MY local sample b for src's table g*Tg+t
+        for src in range(world):
+            gs = torch.Generator().manual_seed(100 + src)
+            src_tables = [torch.randn(R, D, generator=gs) for _ in range(T_loc)]
+            s_idx, s_off = request_for(src)
+            for gi in range(groups):
+                for t in range(Tg):
+                    tt = gi * Tg + t
+                    for b in range(B_local):
+                        bag = tt * B_glob + rank * B_local + b      # my rows of the global batch
+                        rows = s_idx[int(s_off[bag]):int(s_off[bag + 1])]
+                        exp = src_tables[tt][rows].sum(0)
+                        assert torch.allclose(recv[gi][src, b, t * D:(t + 1) * D], exp, atol=1e-5), (src, gi, t, b)
+        pipe.lookups_only(reqs)
+        pipe.all_to_all_only()
+    finally:
+        dist.destroy_process_group()
