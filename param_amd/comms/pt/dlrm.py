@@ -1,0 +1,412 @@
+"""dlrm.py -- DLRM sparse-feature communication benchmark on the MI355X path.
+
+Own restatement of the hot path of reference ``train/comms/pt/dlrm.py`` (per-iteration flow
+``benchTime`` ``:1200-1323``):
+
+  SparseFeatures            offsets -> lengths on the host, H2D            (:226-277)
+  SparseDataDist            all_to_all(lengths) -> all_to_all(indices)     (:744-855)
+  splitPerTable             regroup [rank][table][batch] -> per table      (:430-504)
+  apply_emb                 local tables x GLOBAL batch                     (:363-388)
+  alltoallv (fwd / bwd)     pooled embeddings <-> batch-parallel layout     (:86-218, :858-878)
+  MLP all_reduces           weight-shaped random tensors                    (:1266-1282, :1303-1317)
+
+What is different, on purpose (MI355X-first):
+  * apply_emb is ONE batched HIP launch over all local tables that writes the all-to-all send
+    layout ``[N_global, sum E_local]`` directly (the reference loops over tables in Python,
+    ``torch.stack``s and then ``torch.cat``s again, ``:371-387,97``);
+  * the regroup after the index exchange is a single device-side gather built from block prefix
+    sums (the reference does O(world x tables) Python slicing/``cat`` with ``.item()``/``.numpy()``
+    host syncs per batch, ``:448-504,801-811``); only the split sizes an all_to_all needs on the
+    host are read back;
+  * backward applies the fused in-place update through the sorted (deterministic) scatter-add
+    instead of building a sparse COO gradient that nothing consumes (``:1296``);
+  * the CLI registers ``--use-device-time`` (reference bug R1 crashes without it).
+The timed regions keep the reference's names (``initTimers`` ``:961-1009``); ``--print-comms``
+writes the same per-rank JSON records (``:1393-1402``).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import logging
+import os
+import time
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import comms_utils
+from .mi355_backend import BACKEND_NAME, MI355XBackend
+from .pytorch_backend_utils import collectiveArgsHolder
+
+logger = logging.getLogger(__name__)
+
+
+# ------------------------------------------------------------------------------------------------
+# pure helpers (pinned by tests/golden/comms_pure.json against the reference)
+def get_split_lengths_by_len(n: int, global_rank: int, world_size: int) -> Tuple[int, List[int]]:
+    """contiguous table partition: first ``n mod W`` ranks get one more (dlrm.py:390-398)"""
+    k, m = divmod(n, world_size)
+    splits = [k + 1 if i < m else k for i in range(world_size)]
+    return (k if m == 0 else splits[global_rank]), splits
+
+
+def get_slice_sparse(global_rank: int, num_emb_per_rank: Sequence[int], world_size: int) -> slice:
+    start = sum(num_emb_per_rank[:global_rank])
+    return slice(start, start + num_emb_per_rank[global_rank], 1)
+
+
+def lengthsToOffsets(lengths: torch.Tensor, curDevice=None) -> torch.Tensor:
+    """exclusive prefix sum, one entry per bag (no trailing end; dlrm.py:245-251)"""
+    out = torch.zeros_like(lengths)
+    if lengths.numel() > 1:
+        out[1:] = torch.cumsum(lengths[:-1], dim=0)
+    return out
+
+
+def calculateLengths(feature_count: int, offsets: Sequence[torch.Tensor], indices: Sequence[torch.Tensor]):
+    """per-feature offsets -> lengths, features concatenated (dlrm.py:226-242)"""
+    lens = []
+    for f in range(feature_count):
+        o, n = offsets[f], len(indices[f])
+        if len(o) > 0:
+            ln = torch.empty_like(o)
+            ln[:-1] = o[1:] - o[:-1]
+            ln[-1] = n - o[-1]
+        else:
+            ln = o
+        lens.append(ln)
+    return torch.cat(lens), torch.cat(list(indices))
+
+
+def regroup_per_table(lengths: torch.Tensor, indices: torch.Tensor, batch_size: int, num_my_features: int,
+                      world_size: int):
+    """Received layout: lengths ``[rank][table][batch]``, indices concatenated block by block in the
+    same (rank, table) order.  Returns the TBE request for the batched kernel:
+    ``indices_tbe`` (table-major, within a table rank-major = global sample order) and
+    ``offsets_tbe`` ``[F * world * batch + 1]``.  One gather, no per-block Python loop, no host sync.
+    Same regrouping as the reference's splitPerTable (dlrm.py:430-504)."""
+    W, F, B = world_size, num_my_features, batch_size
+    dev = lengths.device
+    l3 = lengths.view(W, F, B).to(torch.int64)
+    block = l3.sum(dim=2)                                  # [W, F] indices per (rank, table) block
+    src_start = torch.cumsum(block.reshape(-1), 0) - block.reshape(-1)       # received order (r, f)
+    blk_t = block.t().contiguous().reshape(-1)             # destination order (f, r)
+    src_start_t = src_start.view(W, F).t().contiguous().reshape(-1)
+    dst_start_t = torch.cumsum(blk_t, 0) - blk_t
+    n = indices.numel()
+    shift = torch.repeat_interleave(src_start_t - dst_start_t, blk_t, output_size=n)
+    gather = torch.arange(n, device=dev) + shift
+    indices_tbe = indices[gather]
+    lens_tbe = l3.permute(1, 0, 2).reshape(-1)             # [F, W, B] flattened
+    offsets_tbe = torch.zeros(F * W * B + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(lens_tbe, 0, out=offsets_tbe[1:])
+    return indices_tbe, offsets_tbe
+
+
+def splitPerTable(lengths, indices, batch_size, num_my_features, world_size, global_rank=0, curDevice=None):
+    """Reference-shaped result (list of per-table offsets without the trailing end, list of per-table
+    index tensors) derived from :func:`regroup_per_table`."""
+    idx, off = regroup_per_table(lengths, indices, batch_size, num_my_features, world_size)
+    n = world_size * batch_size
+    offsets, inds = [], []
+    for f in range(num_my_features):
+        s, e = int(off[f * n]), int(off[(f + 1) * n])
+        offsets.append(off[f * n:(f + 1) * n] - s)
+        inds.append(idx[s:e])
+    return offsets, inds
+
+
+def generate_sparse_batch(rows: Sequence[int], n: int, num_indices_per_lookup: int, fixed: bool, device,
+                          generator: Optional[torch.Generator] = None):
+    """Synthetic sparse input of one rank, all tables, feature-major: ``lengths [T*n]`` and the
+    concatenated indices.  Same distribution as the reference's generate_uniform_input_batch
+    (dlrm_data.py:151-194: bag size fixed, or round(max(1, r * min(size, L))); indices
+    round(r * (size-1)), sorted and de-duplicated per bag) but vectorised."""
+    lens_all, idx_all = [], []
+    L = num_indices_per_lookup
+    for size in rows:
+        if fixed:
+            want = torch.full((n,), L, dtype=torch.int64, device=device)
+        else:
+            r = torch.rand(n, device=device, generator=generator, dtype=torch.float64)
+            want = torch.clamp(torch.round(r * min(size, L)), min=1).to(torch.int64)
+        cand = torch.round(torch.rand((n, L), device=device, generator=generator, dtype=torch.float64) * (size - 1)).to(torch.int64)
+        live = torch.arange(L, device=device).unsqueeze(0) < want.unsqueeze(1)
+        cand = torch.where(live, cand, torch.full_like(cand, size))      # dead slots sort last
+        cand, _ = torch.sort(cand, dim=1)
+        keep = cand < size
+        keep[:, 1:] &= cand[:, 1:] != cand[:, :-1]                         # np.unique: sorted, duplicates dropped
+        lens_all.append(keep.sum(dim=1))
+        idx_all.append(cand[keep])
+    return torch.cat(lens_all), torch.cat(idx_all)
+
+
+# ------------------------------------------------------------------------------------------------
+class DLRMSparsePath:
+    """One rank's sparse-feature path: redistribute inputs, look up, exchange pooled embeddings,
+    exchange gradients back, update.  ``lookup(indices, offsets, out)`` and
+    ``update(grad, indices, offsets)`` are injected: the product passes the HIP kernels."""
+
+    def __init__(self, backend, collectiveArgs, n_emb_per_rank: Sequence[int], emb_dim: int, local_batch: int,
+                 lookup: Callable, update: Optional[Callable] = None):
+        self.bf, self.ca = backend, collectiveArgs
+        self.world, self.rank = collectiveArgs.world_size, collectiveArgs.global_rank
+        self.n_emb_per_rank = list(n_emb_per_rank)
+        self.my_features = self.n_emb_per_rank[self.rank]
+        self.D, self.B = emb_dim, local_batch
+        self.N = self.world * local_batch
+        self.lookup, self.update = lookup, update
+        self.commDetails: List[dict] = []
+        self.dims_sum_per_rank = [k * emb_dim for k in self.n_emb_per_rank]
+        self.timers = collectiveArgs.timers
+
+    def _a2a(self, out, inp, out_split, in_split, async_op=False):
+        ca = self.ca
+        ca.opTensor, ca.ipTensor, ca.opTensor_split, ca.ipTensor_split, ca.asyncOp = out, inp, out_split, in_split, async_op
+        return self.bf.all_to_allv(ca, retFlag=True)
+
+    def sparse_data_dist(self, lengths: torch.Tensor, indices: torch.Tensor):
+        """lengths ``[T_total * B]`` feature-major (this rank's local batch, ALL tables) ->
+        TBE request of this rank's tables for the GLOBAL batch (dlrm.py:744-855)."""
+        W, B, dev = self.world, self.B, lengths.device
+        T_total = sum(self.n_emb_per_rank)
+        out_lengths = torch.empty(self.my_features * B * W, dtype=lengths.dtype, device=dev)
+        out_splits = [self.my_features * B] * W
+        in_splits = [k * B for k in self.n_emb_per_rank]
+        self.bf.sync_barrier(self.ca)
+        self.timers["offset_xchg_start"] = time.monotonic()
+        self._a2a(out_lengths, lengths, out_splits, in_splits)
+        self.bf.complete_accel_ops(self.ca)
+        self.timers["offset_xchg_end"] = time.monotonic()
+        self.commDetails.append({"comms": "all_to_all", "msg_size": out_lengths.numel() * out_lengths.element_size(),
+                                 "in_split": in_splits, "out_split": out_splits, "dtype": str(lengths.dtype)})
+        # the index exchange needs its split sizes on the host: ONE small D2H of 2*W numbers
+        per_feature = lengths.view(T_total, B).sum(dim=1)
+        bounds = np.cumsum([0] + self.n_emb_per_rank)
+        send_per_rank = torch.stack([per_feature[bounds[j]:bounds[j + 1]].sum() for j in range(W)])
+        recv_per_rank = out_lengths.view(W, -1).sum(dim=1)
+        sizes = torch.stack([send_per_rank, recv_per_rank]).cpu().numpy()
+        in_idx_splits, out_idx_splits = sizes[0].tolist(), sizes[1].tolist()
+        out_indices = torch.empty(int(sum(out_idx_splits)), dtype=torch.int64, device=dev)
+        self.bf.sync_barrier(self.ca)
+        self.timers["idx_xchg_start"] = time.monotonic()
+        self._a2a(out_indices, indices, out_idx_splits, in_idx_splits)
+        self.bf.complete_accel_ops(self.ca)
+        self.timers["idx_xchg_end"] = time.monotonic()
+        self.commDetails.append({"comms": "all_to_all", "msg_size": out_indices.numel() * out_indices.element_size(),
+                                 "in_split": [int(x) for x in in_idx_splits], "out_split": [int(x) for x in out_idx_splits],
+                                 "dtype": str(indices.dtype)})
+        return regroup_per_table(out_lengths, out_indices, B, self.my_features, W)
+
+    def apply_emb(self, indices_tbe, offsets_tbe, out=None):
+        """ONE batched launch -> ``[N_global, my_features * D]`` (the all-to-all send layout)."""
+        if out is None:
+            out = torch.empty((self.N, self.my_features * self.D), dtype=torch.float32, device=indices_tbe.device)
+        self.lookup(indices_tbe, offsets_tbe, out)
+        return out
+
+    def alltoallv_fwd(self, ly: torch.Tensor):
+        """pooled embeddings -> batch-parallel: returns ``[B, sum_j E_j]`` assembled from the per-source
+        ``[B, E_j]`` blocks (what All2Allv_Wait.forward + torch.cat(dim=1) produce, dlrm.py:173-175,1253)."""
+        E_loc = self.my_features * self.D
+        in_split = [self.B * E_loc] * self.world
+        out_split = [self.B * e for e in self.dims_sum_per_rank]
+        recv = torch.empty(sum(out_split), dtype=ly.dtype, device=ly.device)
+        self.bf.sync_barrier(self.ca)
+        self.timers["fwd_a2a_start"] = time.monotonic()
+        req = self._a2a(recv, ly.view(-1), out_split, in_split, async_op=True)
+        if req is not None:
+            req.wait()
+        self.bf.complete_accel_ops(self.ca)
+        self.timers["fwd_a2a_end"] = time.monotonic()
+        self.commDetails.append({"comms": "all_to_all", "msg_size": ly.numel() * ly.element_size(),
+                                 "in_split": in_split, "out_split": out_split, "dtype": str(ly.dtype)})
+        blocks = [b.view(self.B, -1) for b in recv.split(out_split)]
+        return torch.cat(blocks, dim=1), out_split, in_split
+
+    def alltoallv_bwd(self, grad_full: torch.Tensor, out_split, in_split):
+        """gradient of the concatenated pooled embeddings ``[B, sum_j E_j]`` -> ``[N_global, E_local]``"""
+        gblocks = [g.contiguous().view(-1) for g in grad_full.split(self.dims_sum_per_rank, dim=1)]
+        send = torch.cat(gblocks)
+        recv = torch.empty(self.N * self.my_features * self.D, dtype=grad_full.dtype, device=grad_full.device)
+        self.bf.sync_barrier(self.ca)
+        self.timers["bwd_a2a_start"] = time.monotonic()
+        req = self._a2a(recv, send, in_split, out_split, async_op=True)
+        if req is not None:
+            req.wait()
+        self.bf.complete_accel_ops(self.ca)
+        self.timers["bwd_a2a_end"] = time.monotonic()
+        self.commDetails.append({"comms": "all_to_all", "msg_size": recv.numel() * recv.element_size(),
+                                 "in_split": out_split, "out_split": in_split, "dtype": str(grad_full.dtype)})
+        return recv.view(self.N, self.my_features * self.D)
+
+
+# ------------------------------------------------------------------------------------------------
+REGIONS = [  # (name, start timer, end timer): reference initTimers, dlrm.py:961-1009
+    ("intermed_calc_length", "iter_start", "length_calc_end"), ("mem_push_idx", "length_calc_end", "mem_push_idx_end"),
+    ("intermed_bef_offset_xchg", "mem_push_idx_end", "offset_xchg_start"), ("offset_xchg", "offset_xchg_start", "offset_xchg_end"),
+    ("intermed_btw_offset_idx_xchg", "offset_xchg_end", "idx_xchg_start"), ("idx_xchg", "idx_xchg_start", "idx_xchg_end"),
+    ("intermed_post_idx_xchg_sparse_dist", "idx_xchg_end", "bef_emb_lookup"),
+    ("intermed_emb_lookup_to_a2a_start", "bef_emb_lookup", "fwd_a2a_start"), ("fwd_a2a", "fwd_a2a_start", "fwd_a2a_end"),
+    ("intermed_fwd_a2a_grad_push", "fwd_a2a_end", "grad_push_start"), ("mem_push_gradients", "grad_push_start", "bwd_top_ar_start"),
+    ("bwd_top_ar", "bwd_top_ar_start", "bwd_top_ar_end"), ("intermed_top_ar_end_to_bwd_a2a_start", "bwd_top_ar_end", "bwd_a2a_start"),
+    ("bwd_a2a", "bwd_a2a_start", "bwd_a2a_end"), ("intermed_bwd_a2a_bot_ar", "bwd_a2a_end", "bwd_bot_ar_start"),
+    ("bwd_bot_ar", "bwd_bot_ar_start", "bwd_bot_ar_end"), ("iter_time", "iter_start", "bwd_bot_ar_end"),
+    ("iter_data_prep", "iter_start", "bef_emb_lookup"), ("iter_fwd_a2a", "iter_start", "grad_push_start"),
+    ("iter_bwd_top_ar", "iter_start", "bwd_top_ar_end"), ("iter_bwd_a2a", "iter_start", "bwd_bot_ar_start"),
+]
+
+
+class commsDLRMBench:
+    def __init__(self):
+        self.collectiveArgs = collectiveArgsHolder()
+        self.measured = {name: [] for name, _, _ in REGIONS}
+
+    def readArgs(self, parser, argv=None):
+        parser.add_argument("--master-ip", type=str, default="127.0.0.1")
+        parser.add_argument("--master-port", type=str, default="29500")
+        parser.add_argument("--backend", type=str, default=BACKEND_NAME)
+        parser.add_argument("--device", type=str, default="rocm", choices=["cuda", "rocm", "cpu"])
+        parser.add_argument("--arch-sparse-feature-size", type=int, default=4)
+        parser.add_argument("--arch-embedding-size", type=str, default="4-3-2")
+        parser.add_argument("--arch-mlp-bot", type=str, default="4-3-2")
+        parser.add_argument("--arch-mlp-top", type=str, default="4-2-1")
+        parser.add_argument("--mini-batch-size", type=int, default=1)
+        parser.add_argument("--num-batches", type=int, default=10)
+        parser.add_argument("--warmup-batches", type=int, default=2)
+        parser.add_argument("--num-indices-per-lookup", type=int, default=10)
+        parser.add_argument("--num-indices-per-lookup-fixed", action="store_true", default=False)
+        parser.add_argument("--numpy-rand-seed", type=int, default=123)
+        parser.add_argument("--embed-data-type", type=str, default="float32", choices=["float32", "bfloat16", "float16"])
+        parser.add_argument("--learning-rate", type=float, default=0.01)
+        parser.add_argument("--print-comms", action="store_true")
+        parser.add_argument("--use-device-time", action="store_true", default=False)  # reference bug R1: never registered there
+        parser.add_argument("--log", type=str, default="ERROR")
+        return parser.parse_args(argv)
+
+    def run(self, args, lookup_factory=None):
+        """``lookup_factory(rows, dim, device, dtype) -> (lookup, update)`` overrides the HIP kernels
+        (tests only; the product path builds BatchedEmbeddingBagMI355)."""
+        env = comms_utils.read_comms_env_vars()
+        if env["world_size"] < 1:
+            env = {"world_size": 1, "local_size": 1, "global_rank": 0, "local_rank": 0}
+        info = comms_utils.bootstrap_info_holder(args.master_ip, args.master_port, 0, env)
+        device = "cuda" if args.device == "rocm" else args.device
+        bf = MI355XBackend(info, {"device": device, "backend": args.backend})
+        bf.initialize_backend(args.master_ip, args.master_port,
+                              backend="gloo" if device == "cpu" else ("nccl" if args.backend == BACKEND_NAME else args.backend))
+        ca = self.collectiveArgs
+        ca.device, ca.world_size, ca.global_rank, ca.group = bf.get_device(), bf.get_world_size(), bf.get_global_rank(), bf.get_default_group()
+        W, rank, dev = ca.world_size, ca.global_rank, ca.device
+        ln_emb = [int(x) for x in args.arch_embedding_size.split("-")]
+        if len(ln_emb) < W:
+            raise ValueError("Embedding size should match process count, please fix '--arch-embedding-size' and try again")
+        _, n_emb_per_rank = get_split_lengths_by_len(len(ln_emb), rank, W)
+        my_rows = ln_emb[get_slice_sparse(rank, n_emb_per_rank, W)]
+        D, B = args.arch_sparse_feature_size, args.mini_batch_size
+        dtype = {"float32": torch.float32, "bfloat16": torch.bfloat16, "float16": torch.float16}[args.embed_data_type]
+        if lookup_factory is None:
+            from ... import BatchedEmbeddingBagMI355  # HIP kernels: raises if libparam_amd.so is missing
+
+            np.random.seed(args.numpy_rand_seed + rank)
+            emb = BatchedEmbeddingBagMI355(my_rows, D, dtype=dtype, device=dev, init="uniform_dlrm",
+                                           seed=args.numpy_rand_seed + rank, learning_rate=args.learning_rate)
+            n_glob = W * B
+            lookup = lambda i, o, out: emb.lookup(i, o, out=out, batch=n_glob)                    # noqa: E731
+            update = lambda g, i, o: emb.scatter_add_(g, i, o, alpha=-args.learning_rate, batch=n_glob)  # noqa: E731
+        else:
+            lookup, update = lookup_factory(my_rows, D, dev, dtype)
+        path = DLRMSparsePath(bf, ca, n_emb_per_rank, D, B, lookup, update)
+        # MLP "gradients": weight-shaped random tensors (dlrm.py:307-361)
+        def layers(spec):
+            dims = [int(x) for x in spec.split("-")]
+            return [torch.rand(dims[i + 1], dims[i], device=dev) for i in range(len(dims) - 1)]
+        # top MLP input = dot-interaction of (tables + 1) features, unique pairs, + bottom output
+        # (dlrm.py:575-603, --arch-interaction-op dot, not itself): num_int = f(f-1)/2 + m_den_out
+        num_fea = len(ln_emb) + 1
+        m_den_out = int(args.arch_mlp_bot.split("-")[-1])
+        num_int = (num_fea * (num_fea - 1)) // 2 + m_den_out
+        top, bot = layers(f"{num_int}-{args.arch_mlp_top}"), layers(args.arch_mlp_bot)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(args.numpy_rand_seed + rank)
+        timers = ca.timers
+        for batch in range(args.num_batches):
+            timers["iter_start"] = time.monotonic()
+            lengths, indices = generate_sparse_batch(ln_emb, B, args.num_indices_per_lookup,
+                                                     args.num_indices_per_lookup_fixed, dev, gen)
+            timers["length_calc_end"] = timers["mem_push_idx_end"] = time.monotonic()   # generated on the device
+            idx_tbe, off_tbe = path.sparse_data_dist(lengths, indices)
+            bf.sync_barrier(ca)
+            timers["bef_emb_lookup"] = time.monotonic()
+            ly = path.apply_emb(idx_tbe, off_tbe)
+            pooled, out_split, in_split = path.alltoallv_fwd(ly)
+            timers["grad_push_start"] = time.monotonic()
+            bf.sync_barrier(ca)
+            timers["bwd_top_ar_start"] = time.monotonic()
+            self._all_reduce_layers(bf, ca, top, path)
+            timers["bwd_top_ar_end"] = time.monotonic()
+            grad_ly = path.alltoallv_bwd(pooled, out_split, in_split)       # C = tempB (dlrm.py:1255)
+            if path.update is not None:
+                path.update(grad_ly, idx_tbe, off_tbe)
+            timers["bwd_bot_ar_start"] = time.monotonic()
+            self._all_reduce_layers(bf, ca, bot, path)
+            timers["bwd_bot_ar_end"] = time.monotonic()
+            if batch >= args.warmup_batches:
+                for name, s, e in REGIONS:
+                    self.measured[name].append((timers.get(e, 0.0) - timers.get(s, 0.0)) * 1e6)
+        report = self.report(bf, ca, path, args)
+        if args.print_comms:
+            folder = os.path.join(os.getcwd(), f"dlrm_np{W}")
+            os.makedirs(folder, exist_ok=True)
+            per_iter = len(path.commDetails) // max(1, args.num_batches)
+            with open(os.path.join(folder, f"rank{rank}.json"), "w") as f:
+                json.dump(path.commDetails[:per_iter], f, indent=2)
+        bf.shutdown()
+        return report
+
+    @staticmethod
+    def _all_reduce_layers(bf, ca, layers, path):
+        for t in layers:
+            ca.ipTensor, ca.asyncOp, ca.op = t, True, bf.get_reduce_op("sum")
+            bf.all_reduce(ca)
+            path.commDetails.append({"comms": "all_reduce", "msg_size": t.nelement() * t.element_size(), "dtype": str(t.dtype)})
+        bf.sync_barrier(ca)
+
+    def report(self, bf, ca, path, args):
+        """min / p50 / p75 / p95 over iterations of the per-rank MAX... the reference gathers every rank's
+        samples (dlrm.py:1011-1198); here: all_gather of the per-region medians, rank 0 prints."""
+        names = [n for n, _, _ in REGIONS]
+        mine = torch.tensor([float(np.median(self.measured[n])) if self.measured[n] else 0.0 for n in names],
+                            dtype=torch.float64, device=ca.device)
+        allr = [torch.zeros_like(mine) for _ in range(ca.world_size)]
+        dist.all_gather(allr, mine, group=bf.get_default_group())
+        table = torch.stack(allr).cpu().numpy()        # [world, regions]
+        out = {}
+        if ca.global_rank == 0:
+            print("\n\t{:>40}{:>14}{:>14}{:>14}{:>14}".format("region (us, median per rank)", "min", "p50", "p95", "max"))
+        for k, n in enumerate(names):
+            col = table[:, k]
+            out[n] = {"min": float(col.min()), "p50": float(np.percentile(col, 50)), "p95": float(np.percentile(col, 95)),
+                      "max": float(col.max())}
+            if ca.global_rank == 0:
+                print("\t{:>40}{:>14.1f}{:>14.1f}{:>14.1f}{:>14.1f}".format(n, out[n]["min"], out[n]["p50"], out[n]["p95"], out[n]["max"]))
+        a2a_bytes = path.B * sum(path.dims_sum_per_rank) * 4
+        if out["fwd_a2a"]["p50"] > 0:
+            alg = a2a_bytes / (out["fwd_a2a"]["p50"] * 1e3)
+            out["fwd_a2a_bw"] = {"bytes_per_rank": a2a_bytes, "algBW_GBps": alg,
+                                 "busBW_GBps": bf.getBusBW("all_to_allv", alg, ca)}
+        return out
+
+
+def main(argv=None):
+    bench = commsDLRMBench()
+    args = bench.readArgs(argparse.ArgumentParser(description="DLRM sparse-feature comms benchmark (MI355X build)"), argv)
+    logging.basicConfig(level=getattr(logging, args.log.upper(), logging.ERROR))
+    return bench.run(args)
+
+
+if __name__ == "__main__":
+    main()  # pragma: no cover

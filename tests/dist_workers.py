@@ -101,6 +101,99 @@ def comms_sweep(rank, world, port, outdir):
         json.dump({"results": res, "stdout": buf.getvalue()}, f)
 
 
+def _stub_tables(rows, D):
+    """deterministic per-GLOBAL-table weights so every rank can compute any table's expected output"""
+    return [torch.randn(r, D, generator=torch.Generator().manual_seed(1000 + r)) for r in rows]
+
+
+def dlrm_sparse_path(rank, world, port):
+    """DLRMSparsePath over gloo with a torch STUB lookup: after lengths/indices exchange, lookup and the
+    pooled all-to-all, every rank holds [B, sum_t D] pooled embeddings of ITS samples for ALL tables."""
+    from param_amd.comms.pt import dlrm as D_
+    from param_amd.comms.pt.pytorch_backend_utils import collectiveArgsHolder
+
+    _env(rank, world, port)
+    bf = _backend(rank, world, port)
+    try:
+        ln_emb, D, B, L = [40, 50, 60], 4, 5, 3          # 3 tables over 2 ranks -> [2, 1]
+        _, per_rank = D_.get_split_lengths_by_len(len(ln_emb), rank, world)
+        assert per_rank == [2, 1]
+        ca = collectiveArgsHolder()
+        ca.world_size, ca.global_rank, ca.group, ca.device = world, rank, bf.get_default_group(), bf.get_device()
+        all_tables = _stub_tables(ln_emb, D)
+        mine = all_tables[D_.get_slice_sparse(rank, per_rank, world)]
+        n_glob = world * B
+
+        def lookup(idx, off, out):
+            for t, Wt in enumerate(mine):
+                s, e = int(off[t * n_glob]), int(off[(t + 1) * n_glob])
+                out[:, t * D:(t + 1) * D] = torch.nn.functional.embedding_bag(
+                    idx[s:e], Wt, off[t * n_glob:(t + 1) * n_glob] - s, mode="sum")
+
+        path = D_.DLRMSparsePath(bf, ca, per_rank, D, B, lookup, None)
+        gen = torch.Generator().manual_seed(50 + rank)
+        lengths, indices = D_.generate_sparse_batch(ln_emb, B, L, False, torch.device("cpu"), gen)
+        assert lengths.shape == (len(ln_emb) * B,) and int(lengths.sum()) == indices.numel() and int(lengths.min()) >= 1
+        idx_tbe, off_tbe = path.sparse_data_dist(lengths, indices)
+        assert off_tbe.numel() == per_rank[rank] * n_glob + 1 and int(off_tbe[-1]) == idx_tbe.numel()
+        ly = path.apply_emb(idx_tbe, off_tbe)
+        pooled, out_split, in_split = path.alltoallv_fwd(ly)
+        assert pooled.shape == (B, len(ln_emb) * D)
+        # expected: my sample b, global table t -> sum of that table's rows at MY indices
+        offs = torch.cumsum(lengths, 0) - lengths
+        for t in range(len(ln_emb)):
+            for b in range(B):
+                s = int(offs[t * B + b])
+                rows = indices[s:s + int(lengths[t * B + b])]
+                assert torch.allclose(pooled[b, t * D:(t + 1) * D], all_tables[t][rows].sum(0), atol=1e-5), (rank, t, b)
+        # backward exchange: gradient of pooled goes back to the table owners in [N_global, E_local] layout
+        grad = torch.arange(pooled.numel(), dtype=torch.float32).view_as(pooled) + 1000 * rank
+        g_loc = path.alltoallv_bwd(grad, out_split, in_split)
+        assert g_loc.shape == (n_glob, per_rank[rank] * D)
+        col0 = sum(per_rank[:rank]) * D
+        for src in range(world):
+            exp = (torch.arange(B * len(ln_emb) * D, dtype=torch.float32).view(B, -1) + 1000 * src)[:, col0:col0 + per_rank[rank] * D]
+            assert torch.equal(g_loc[src * B:(src + 1) * B], exp), (rank, src)
+        kinds = [c["comms"] for c in path.commDetails]
+        assert kinds == ["all_to_all"] * 4 and path.commDetails[2]["out_split"] == [B * 2 * D, B * 1 * D]
+    finally:
+        bf.shutdown()
+
+
+def dlrm_driver(rank, world, port, outdir):
+    import contextlib
+    import io
+    import json
+
+    from param_amd.comms.pt import dlrm as D_
+
+    _env(rank, world, port)
+    os.chdir(outdir)
+
+    def factory(rows, D, dev, dtype):
+        tabs = _stub_tables(rows, D)
+
+        def lookup(idx, off, out):
+            n = out.shape[0]
+            for t, Wt in enumerate(tabs):
+                s, e = int(off[t * n]), int(off[(t + 1) * n])
+                out[:, t * D:(t + 1) * D] = torch.nn.functional.embedding_bag(idx[s:e], Wt, off[t * n:(t + 1) * n] - s, mode="sum")
+        return lookup, None
+
+    bench = D_.commsDLRMBench()
+    import argparse
+    args = bench.readArgs(argparse.ArgumentParser(), [
+        "--master-ip", "127.0.0.1", "--master-port", str(port), "--backend", "gloo", "--device", "cpu",
+        "--mini-batch-size", "8", "--num-batches", "4", "--warmup-batches", "1", "--arch-mlp-bot", "16-8",
+        "--arch-mlp-top", "8-1", "--arch-sparse-feature-size", "8", "--arch-embedding-size", "100-200-300-400",
+        "--num-indices-per-lookup", "5", "--print-comms"])
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        rep = bench.run(args, lookup_factory=factory)
+    with open(os.path.join(outdir, f"report{rank}.json"), "w") as f:
+        json.dump({"report": rep, "stdout": buf.getvalue()}, f)
+
+
 def pipeline_layout(rank, world, port):
     from param_amd.comms.pt.pipeline import LookupAllToAll, split_request_by_group
 

@@ -51,6 +51,60 @@ def test_comms_sweep_driver_over_gloo(tmp_path, golden_dir):
     assert shape(rows0[1]).startswith("\tCOMMS-RES-all_to_allv-float#")
 
 
+def test_dlrm_sparse_path_over_gloo():
+    _spawn(W.dlrm_sparse_path)
+
+
+def test_dlrm_driver_over_gloo_print_comms(tmp_path):
+    """Same flags as the survey's reference run: the per-rank --print-comms JSON has
+    the reference's record order and fixed-size entries (dlrm_np2/rank0.json there:
+    lengths a2a 256 B [16,16]/[16,16] int64, indices a2a, pooled a2a 1024 B [128,128]/[128,128] float32, ...)."""
+    _spawn(W.dlrm_driver, str(tmp_path))
+    rec = json.load(open(tmp_path / "dlrm_np2" / "rank0.json"))
+    assert [r["comms"] for r in rec] == ["all_to_all", "all_to_all", "all_to_all", "all_reduce", "all_reduce",
+                                         "all_to_all", "all_reduce"]
+    assert rec[0] == {"comms": "all_to_all", "msg_size": 256, "in_split": [16, 16], "out_split": [16, 16], "dtype": "torch.int64"}
+    assert rec[1]["dtype"] == "torch.int64" and sum(rec[1]["out_split"]) * 8 == rec[1]["msg_size"]
+    assert rec[2] == {"comms": "all_to_all", "msg_size": 1024, "in_split": [128, 128], "out_split": [128, 128], "dtype": "torch.float32"}
+    # top MLP "18-8-1": 5 features -> 10 unique pairs + 8 = 18 inputs; 18x8 fp32 = 576 B (the reference's value)
+    assert rec[3] == {"comms": "all_reduce", "msg_size": 576, "dtype": "torch.float32"}
+    assert rec[4] == {"comms": "all_reduce", "msg_size": 32, "dtype": "torch.float32"}
+    assert rec[5]["in_split"] == [128, 128] and rec[5]["msg_size"] == 1024                      # bwd a2a, splits swapped
+    assert rec[6] == {"comms": "all_reduce", "msg_size": 512, "dtype": "torch.float32"}       # bot MLP 16-8
+    rep = json.load(open(tmp_path / "report0.json"))
+    assert set(n for n in rep["report"] if not n.endswith("_bw")) == {
+        "intermed_calc_length", "mem_push_idx", "intermed_bef_offset_xchg", "offset_xchg", "intermed_btw_offset_idx_xchg",
+        "idx_xchg", "intermed_post_idx_xchg_sparse_dist", "intermed_emb_lookup_to_a2a_start", "fwd_a2a",
+        "intermed_fwd_a2a_grad_push", "mem_push_gradients", "bwd_top_ar", "intermed_top_ar_end_to_bwd_a2a_start", "bwd_a2a",
+        "intermed_bwd_a2a_bot_ar", "bwd_bot_ar", "iter_time", "iter_data_prep", "iter_fwd_a2a", "iter_bwd_top_ar", "iter_bwd_a2a"}
+    assert rep["report"]["fwd_a2a"]["p50"] > 0 and "fwd_a2a" in rep["stdout"]
+    assert rep["report"]["fwd_a2a_bw"]["busBW_GBps"] == pytest.approx(rep["report"]["fwd_a2a_bw"]["algBW_GBps"] / 2)
+
+
+def test_dlrm_helpers_match_reference_goldens(golden_dir):
+    import torch
+
+    from param_amd.comms.pt import dlrm as D_
+
+    g = json.load(open(os.path.join(golden_dir, "comms_pure.json")))
+    for (n, r, w), v in g["get_split_lengths_by_len"]:
+        my, splits = D_.get_split_lengths_by_len(n, r, w)
+        assert [my, splits] == v
+    for (r, per, w), v in g["get_slice_sparse"]:
+        s = D_.get_slice_sparse(r, per, w)
+        assert [s.start, s.stop, s.step] == v
+    for lens, v in g["lengthsToOffsets"]:
+        assert D_.lengthsToOffsets(torch.tensor(lens)).tolist() == v
+    c = g["calculateLengths"]
+    offs = [torch.tensor(o) for o in c["offsets"]]
+    idxs = [torch.arange(7), torch.arange(10, 16)]
+    ln, ix = D_.calculateLengths(2, offs, idxs)
+    assert ln.tolist() == c["lengths"] and ix.tolist() == c["indices"]
+    s = g["splitPerTable"]
+    o, i = D_.splitPerTable(torch.tensor(s["lengths"]), torch.tensor(s["indices"]), s["batch"], s["features"], s["world"])
+    assert [x.tolist() for x in o] == s["offsets_out"] and [x.tolist() for x in i] == s["indices_out"]
+
+
 def test_harness_arithmetic_matches_reference_goldens(golden_dir):
     """pure functions vs tests/golden/comms_pure.json (generated by importing the reference)"""
     import types

@@ -1,0 +1,177 @@
+"""GPU tests of the driver / plug-in layers on ONE MI355X (world size 1): the compute/pt driver rows,
+the compute/python operator, the comms backend's embedding functions and the DLRM driver end to end."""
+import contextlib
+import io
+import json
+import os
+import socket
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_compute_pt_driver_gpu_rows():
+    from param_amd.compute.pt import pytorch_emb
+
+    args = types.SimpleNamespace(device="gpu", randomseed=0, warmups=2, steps=5, alpha=0.0, usexlabag=False,
+                                 dtype="float32", tables=1, json=True)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        pytorch_emb.run(args, [(1000000, 32, 20, 512), (200000, 128, 30, 2048)])
+        args.tables, args.alpha, args.dtype = 8, 1.05, "bfloat16"
+        pytorch_emb.run(args, [(100000, 128, 20, 1024)])
+    lines = buf.getvalue().splitlines()
+    assert lines[1] == pytorch_emb.HEADER
+    rows = [json.loads(ln) for ln in lines if ln.startswith("{")]
+    assert len(rows) == 3 and all(r["lookups_per_s"] > 1e8 for r in rows)
+    assert rows[0]["param_GBps"] == pytest.approx(512 * 20 * 32 * 4 / rows[0]["s_per_step"] / 1e9)
+    assert rows[2]["tables"] == 8 and rows[2]["dtype"] == "bfloat16"
+
+
+def test_compute_python_operator_forward_backward(coracle):
+    from param_amd.compute.python import op_map
+    from param_amd.compute.python.split_table_batched_embeddings_ops import generate_batched_request
+
+    op = op_map["SplitTableBatchedEmbeddingBagsCodegen"]
+    op.device = "cuda"
+    op.cleanup()
+    op.build(3, [300, 500, 700], 64, 0, True, "fp32", "sgd", lr=0.1)
+    torch.manual_seed(1)
+    idx, off, w = generate_batched_request(3, [300, 500, 700], 16, [4, 6, 2], alpha=1.0, weighted=True, device=DEV)
+    out = op.forward(idx, off, w)
+    tabs = [op.op.table(t).cpu().numpy().copy() for t in range(3)]
+    ref = coracle.fwd_batched(tabs, idx.cpu().numpy(), off.cpu().numpy(), 16, psw=w.cpu().numpy())
+    assert np.array_equal(out.cpu().numpy(), ref)
+    op.create_grad()
+    op.backward()
+    B = 16
+    idx_h, off_h, w_h = idx.cpu().numpy(), off.cpu().numpy(), w.cpu().numpy()
+    for t in range(3):
+        s, e = off_h[t * B], off_h[(t + 1) * B]
+        exp = coracle.bwd_f32(tabs[t].copy(), idx_h[s:e], off_h[t * B:(t + 1) * B] - s, np.ones((B, 64), np.float32),
+                              w_h[s:e], alpha=-0.1)
+        assert np.array_equal(op.op.table(t).cpu().numpy(), exp), t
+    op.cleanup()
+
+
+def test_backend_embedding_functions_single_rank(coracle):
+    """MI355XBackend.alloc_embedding_tables / emb_lookup / lookup_all_to_all on a 1-rank RCCL group."""
+    import torch.distributed as dist
+
+    from param_amd.comms.pt import comms_utils
+    from param_amd.comms.pt.mi355_backend import MI355XBackend, register
+    from param_amd.comms.pt.pytorch_backend_utils import collectiveArgsHolder, customized_backend
+
+    register()
+    assert customized_backend["rccl_xgmi"] is MI355XBackend
+    env = {"world_size": 1, "local_size": 1, "global_rank": 0, "local_rank": 0}
+    port = _port()
+    bf = MI355XBackend(comms_utils.bootstrap_info_holder("127.0.0.1", str(port), 0, env), {"device": "cuda", "backend": "nccl"})
+    bf.initialize_backend("127.0.0.1", str(port), backend="rccl_xgmi")
+    try:
+        E = bf.alloc_embedding_tables(1000, 32, DEV, torch.float32)
+        lim = np.sqrt(1 / 1000)
+        assert float(E.weight.data.abs().max()) <= lim and float(E.weight.data.std()) > lim / 3
+        idx = torch.randint(0, 1000, (200,), device=DEV)
+        off = torch.arange(20, device=DEV) * 10
+        with torch.no_grad():
+            o = E(idx, off)
+        assert np.array_equal(o.cpu().numpy(), coracle.fwd(E.weight.data.cpu().numpy(), idx.cpu().numpy(), off.cpu().numpy()))
+        ca = collectiveArgsHolder()
+        ca.world_size, ca.global_rank, ca.group, ca.device = 1, 0, bf.get_default_group(), bf.get_device()
+        ca.emb = [bf.alloc_batched_embedding_tables([500, 600], 64, DEV, torch.float32) for _ in range(2)]
+        from param_amd.indices import tbe_request
+        ca.embRequests = [tbe_request([500, 600], 8, 5, device=DEV, seed=s) + (None,) for s in (1, 2)]
+        ca.num_emb_ops, ca.num_emb_tables_batched, ca.asyncOp, ca.direction = 2, 2, False, "forward"
+        bf.emb_lookup(ca)
+        assert ca.LookupOut.shape == (8, 128)
+        bf.all_to_all(ca)                     # fused lookup -> all_to_all per op (1 rank: identity exchange)
+        bf.complete_accel_ops(ca)
+        for i in range(2):
+            assert torch.equal(ca.a2a_recv[i], ca.emb[i].lookup(*ca.embRequests[i][:2]))
+        before = ca.emb[0].table(0).clone()
+        ca.direction, ca.grad_output = "backward", torch.ones(8, 128, device=DEV)
+        bf.emb_lookup(ca)
+        assert not torch.equal(before, ca.emb[0].table(0))
+        t = torch.ones(16, device=DEV)
+        ca.ipTensor, ca.asyncOp = t, True
+        bf.all_reduce(ca)
+        bf.sync_barrier(ca)
+        assert ca.waitObj == [] and float(t.sum()) == 16.0
+    finally:
+        bf.shutdown()
+
+
+def test_dlrm_driver_single_gpu(tmp_path):
+    from param_amd.comms.pt import dlrm
+
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_SIZE"):
+        os.environ.pop(k, None)
+    buf = io.StringIO()
+    try:
+        with contextlib.redirect_stdout(buf):
+            rep = dlrm.main(["--master-ip", "127.0.0.1", "--master-port", str(_port()), "--device", "rocm",
+                             "--mini-batch-size", "256", "--num-batches", "6", "--warmup-batches", "2",
+                             "--arch-mlp-bot", "64-32", "--arch-mlp-top", "32-1", "--arch-sparse-feature-size", "128",
+                             "--arch-embedding-size", "20000-30000-40000-50000", "--num-indices-per-lookup", "20",
+                             "--num-indices-per-lookup-fixed", "--print-comms"])
+    finally:
+        os.chdir(cwd)
+    assert rep["iter_time"]["p50"] > 0 and rep["fwd_a2a_bw"]["bytes_per_rank"] == 256 * 4 * 128 * 4
+    rec = json.load(open(tmp_path / "dlrm_np1" / "rank0.json"))
+    assert [r["comms"] for r in rec][:3] == ["all_to_all"] * 3 and rec[2]["msg_size"] == 256 * 4 * 128 * 4
+
+
+def test_dlrm_sparse_path_hip_vs_oracle(coracle):
+    """DLRMSparsePath with the HIP lookup/update at world size 1: pooled == oracle, update == oracle."""
+    import torch.distributed as dist
+
+    from param_amd import BatchedEmbeddingBagMI355
+    from param_amd.comms.pt import comms_utils, dlrm as D_
+    from param_amd.comms.pt.mi355_backend import MI355XBackend
+    from param_amd.comms.pt.pytorch_backend_utils import collectiveArgsHolder
+
+    env = {"world_size": 1, "local_size": 1, "global_rank": 0, "local_rank": 0}
+    port = _port()
+    bf = MI355XBackend(comms_utils.bootstrap_info_holder("127.0.0.1", str(port), 0, env), {"device": "cuda", "backend": "nccl"})
+    bf.initialize_backend("127.0.0.1", str(port), backend="nccl")
+    try:
+        rows, D, B, L = [3000, 5000, 800], 64, 128, 12
+        emb = BatchedEmbeddingBagMI355(rows, D, device=DEV, init="uniform_dlrm", seed=3)
+        tabs = [emb.table(t).cpu().numpy().copy() for t in range(3)]
+        ca = collectiveArgsHolder()
+        ca.world_size, ca.global_rank, ca.group, ca.device = 1, 0, bf.get_default_group(), bf.get_device()
+        path = D_.DLRMSparsePath(bf, ca, [3], D, B, lambda i, o, out: emb.lookup(i, o, out=out, batch=B),
+                                 lambda g, i, o: emb.scatter_add_(g, i, o, alpha=-0.05, batch=B))
+        gen = torch.Generator(device=DEV).manual_seed(9)
+        lengths, indices = D_.generate_sparse_batch(rows, B, L, False, torch.device(DEV), gen)
+        idx_tbe, off_tbe = path.sparse_data_dist(lengths, indices)
+        assert torch.equal(idx_tbe, indices)                       # one rank: regrouping is the identity
+        pooled, osp, isp = path.alltoallv_fwd(path.apply_emb(idx_tbe, off_tbe))
+        ref = coracle.fwd_batched(tabs, idx_tbe.cpu().numpy(), off_tbe.cpu().numpy(), B)
+        assert np.array_equal(pooled.cpu().numpy(), ref)
+        g = path.alltoallv_bwd(pooled, osp, isp)
+        path.update(g, idx_tbe, off_tbe)
+        ih, oh = idx_tbe.cpu().numpy(), off_tbe.cpu().numpy()
+        for t in range(3):
+            s, e = oh[t * B], oh[(t + 1) * B]
+            exp = coracle.bwd_f32(tabs[t].copy(), ih[s:e], oh[t * B:(t + 1) * B] - s,
+                                  np.ascontiguousarray(ref[:, t * D:(t + 1) * D]), alpha=-0.05)
+            assert np.array_equal(emb.table(t).cpu().numpy(), exp), t
+    finally:
+        bf.shutdown()

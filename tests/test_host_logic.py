@@ -116,3 +116,41 @@ def test_gpu_modules_refuse_cpu_tensors():
         fill_random_(torch.empty(8))
     with pytest.raises(RuntimeError):
         BatchedEmbeddingBagMI355([10], 8, device="cpu", init=None).lookup(torch.tensor([1]), torch.tensor([0, 1]))
+
+
+def test_operator_registry_contract():
+    """register_operator semantics of the reference (lib/operator.py:48-54; test_register.py:22-60 there)"""
+    from param_amd.compute.python import OperatorInterface, op_map, register_operator
+    from param_amd.compute.python.split_table_batched_embeddings_ops import SplitTableBatchedEmbeddingBagsCodegenOp
+
+    assert isinstance(op_map["SplitTableBatchedEmbeddingBagsCodegen"], SplitTableBatchedEmbeddingBagsCodegenOp)
+    with pytest.raises(ValueError, match="Duplicate operator registration name"):
+        register_operator("SplitTableBatchedEmbeddingBagsCodegen", SplitTableBatchedEmbeddingBagsCodegenOp())
+    with pytest.raises(TypeError):
+        OperatorInterface()  # forward is abstract
+    op = SplitTableBatchedEmbeddingBagsCodegenOp()
+    op.device = "cpu"
+    with pytest.raises(ValueError, match="Unknown compute device"):
+        op.build(2, 100, 8, 0, False, "fp32", "sgd")
+    op.device = "cuda"
+    with pytest.raises(ValueError, match="SUM"):
+        op.build(2, 100, 8, 1, False, "fp32", "sgd")
+    with pytest.raises(ValueError, match="SGD"):
+        op.build(2, 100, 8, 0, False, "fp32", "exact_row_wise_adagrad")
+
+
+def test_generate_requests_layout():
+    from param_amd.compute.python.split_table_batched_embeddings_ops import generate_batched_request, generate_requests
+
+    i, o, w = generate_requests(4, 3, 10, 0, alpha=0)           # arange % L
+    assert i.tolist() == [0, 1, 2] * 4 and o.tolist() == [0, 3, 6, 9, 12] and w is None
+    i, o, w = generate_requests(4, 3, 5, 12, alpha=0.5, weighted=True)   # arange % E, continued offsets (no leading 0)
+    assert i.tolist() == [x % 5 for x in range(12)] and o.tolist() == [15, 18, 21, 24] and w.shape == (12,)
+    torch.manual_seed(0)
+    i, _, _ = generate_requests(64, 5, 7, 0, alpha=1.0)
+    assert int(i.min()) >= 0 and int(i.max()) < 7
+    np.random.seed(0)
+    i, _, _ = generate_requests(64, 5, 1000, 0, alpha=1.15)
+    assert int(i.max()) < 1000 and (i < 10).float().mean() > 0.3            # zipf % E: mass on small ids
+    idx, off, wts = generate_batched_request(3, [10, 20, 30], 4, [2, 3, 1], alpha=1.0, device="cpu")
+    assert off.tolist() == [0, 2, 4, 6, 8, 11, 14, 17, 20, 21, 22, 23, 24] and idx.numel() == 24 and wts is None
