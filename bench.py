@@ -57,6 +57,7 @@ def parse():
     p.add_argument("--dtype", choices=sorted(_DT), default="fp32")
     p.add_argument("--a2a-groups", type=int, default=4, help="N>1: table groups pipelined against the all-to-all")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--dist-debug", action="store_true", help="run the N>1 (pipeline + RCCL) code path even at world size 1")
     p.add_argument("--no-uniform", action="store_true", help="skip the extra uniform-index (pure HBM) measurement")
     p.add_argument("--bwd", action="store_true", help="also time the scatter-add backward (extra field)")
     p.add_argument("--unroll", type=int, default=0)
@@ -145,11 +146,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    multi = world > 1 or a.dist_debug  # --dist-debug: exercise the N>1 code path on one GPU (1-rank RCCL group)
+    if multi:
         import torch.distributed as dist_mod
 
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" IS RCCL on ROCm
 
     def barrier():
         if dist is not None:
@@ -177,7 +182,7 @@ def main():
 
     model = param_amd.BatchedEmbeddingBagMI355([R] * T_loc, D, dtype=dtype, device=dev, init="normal",
                                                seed=1000 + rank, fused_update=False)
-    groups = 1 if world == 1 else max(1, min(a.a2a_groups, T_loc))
+    groups = 1 if not multi else max(1, min(a.a2a_groups, T_loc))
     while T_loc % groups:
         groups -= 1
     Tg = T_loc // groups
@@ -190,7 +195,7 @@ def main():
     alg_bytes = algorithmic_bytes(T_loc, B_glob, L, D, esize)
 
     # ---- the step ---------------------------------------------------------------------------
-    if world == 1:
+    if not multi:
         out = torch.empty((B_glob, T_loc * D), dtype=torch.float32, device=dev)
 
         def step(i=idx, o=off):
@@ -245,7 +250,7 @@ def main():
     }
 
     # roofline of the dominant kernel (forward lookup): algorithmic bytes / avg launch duration
-    if world == 1:
+    if not multi:
         kern_s = dev_s
     else:  # time the lookups alone (no a2a) for the kernel roofline
         _, kern_s = time_steps(lambda: pipe.lookups_only(reqs), max(5, a.steps // 2), 2, barrier)
@@ -270,7 +275,7 @@ def main():
         "lookups_per_s_kernel": lookups_step_rank / kern_s,
     }
 
-    if world > 1:
+    if multi:
         a2a_bytes = world * B_local * T_loc * D * 4  # output tensor bytes per rank (reference memSize)
         _, a2a_s = time_steps(pipe.all_to_all_only, max(5, a.steps // 2), 2, barrier)
         t = torch.tensor([a2a_s], dtype=torch.float64, device=dev)
@@ -286,7 +291,7 @@ def main():
     # extra: uniform indices = no cache help, the pure-HBM run (SURVEY.md 8d "roofline-defining run")
     if not a.no_uniform and a.alpha != 0.0:
         ui, uo = make_request(0.0, 2)
-        if world == 1:
+        if not multi:
             _, us = time_steps(lambda: step(ui, uo), max(5, a.steps // 2), 2, barrier)
         else:
             ur = split_request(ui, uo)

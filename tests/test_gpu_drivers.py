@@ -175,3 +175,27 @@ def test_dlrm_sparse_path_hip_vs_oracle(coracle):
             assert np.array_equal(emb.table(t).cpu().numpy(), exp), t
     finally:
         bf.shutdown()
+
+
+def test_comms_compute_overlap_bench_single_gpu():
+    """comm (all_to_allv on the PG stream) || emb_lookup on the compute stream, per-stream device timers"""
+    from param_amd.comms.pt import commsComputeBench
+
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_SIZE"):
+        os.environ.pop(k, None)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        res = commsComputeBench.main(["--master-ip", "127.0.0.1", "--master-port", str(_port()), "--b", "1M", "--e", "4M",
+                                      "--f", "4", "--n", "4", "--w", "2", "--collective", "all_to_allv", "--device", "rocm",
+                                      "--kernel", "emb_lookup", "--num-compute", "3", "--ntables", "8", "--num-embs", "200000",
+                                      "--emb-dim", "128", "--batch-size", "2048", "--bag-size", "20"])
+    assert [r["size"] for r in res] == [1 << 20, 4 << 20]
+    for r in res:
+        assert r["compute_dev_us"] > 0 and r["comm_dev_us"] >= 0 and r["lookups_per_iter"] == 8 * 2048 * 20 * 3
+        assert r["lookups_per_s_compute_stream"] > 1e9
+    assert "COMMS-COMPUTE-RES-all_to_allv-emb_lookup" in buf.getvalue()
+    res = commsComputeBench.main(["--master-ip", "127.0.0.1", "--master-port", str(_port()), "--b", "1M", "--e", "1M",
+                                  "--n", "2", "--w", "1", "--collective", "all_to_allv", "--device", "rocm", "--mode", "compute",
+                                  "--direction", "backward", "--num-compute", "2", "--ntables", "4", "--num-emb-tables-batched", "2",
+                                  "--num-embs", "50000", "--batch-size", "512"])
+    assert res[0]["memSize"] == 0 and res[0]["compute_dev_us"] > 0

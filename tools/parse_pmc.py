@@ -45,8 +45,14 @@ def label_rows(rows):
                     out["fwd_uniform"].append(val)
             elif n_fwd > reps + 2:
                 out["fwd_zipf"].append(val)
-        elif "embbag_bwd_kernel" in name or "bwd_sorted_kernel" in name:
-            out["bwd_uniform"].append(val)
+        elif "embbag_bwd_kernel" in name:
+            out["bwd_atomic_uniform"].append(val)
+        elif "bwd_sorted_main_kernel" in name:
+            out["bwd_uniform"].append(val)          # the dominant backward kernel (apply)
+        elif "bwd_sorted_fixup_kernel" in name:
+            out["bwd_fixup_uniform"].append(val)
+        elif "radix_sort" in name and "onesweep" in name:
+            out["bwd_sort_pass_uniform"].append(val)
     if out["_fill_all"]:
         out["calib_write"] = out["_fill_all"][-reps:]
     if out["_reduce_all"]:
