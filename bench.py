@@ -138,6 +138,12 @@ def cpu_baseline(table0: torch.Tensor, idx0: torch.Tensor, B: int, L: int, budge
 
 def main():
     a = parse()
+    # stdout must carry exactly ONE JSON line: RCCL prints a version banner to the C-level stdout and
+    # torch may warn there too, so fd 1 is pointed at stderr for the whole run and the JSON line goes
+    # to a private duplicate of the original stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -333,11 +339,13 @@ def main():
         result["cpu_baseline"] = None if a.no_cpu_baseline else {
             "value": None, "unit": "lookups/s", "cores": None, "kind": "port", "sample": "timed at N=1 only"}
 
-    if rank == 0:
-        print(json.dumps(result))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0:
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":

@@ -49,7 +49,14 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p) {
     const int G = pm::group_lanes(op->max_dim, vec);
     const int NG = pm::kBlock / G;
     int bpb = g_bags_per_block.load();
-    if (bpb <= 0) bpb = 4 * NG;
+    if (bpb <= 0) {
+        // 4 bags per lane group amortise the LDS staging; small requests shrink the tile until the
+        // grid fills the chip (256 CUs x 8 resident workgroups) -- a 16 K-bag single-table lookup
+        // ran 2 workgroups per CU at 49 % of the roofline with the fixed tile (gpurun r1e)
+        bpb = 4 * NG;
+        const int64_t want_blocks = 256 * 8;
+        while (bpb > NG && static_cast<int64_t>(op->num_tables) * ((op->bag_count + bpb - 1) / bpb) < want_blocks) bpb /= 2;
+    }
     if (bpb < NG) bpb = NG;
     if (bpb > 1024) bpb = 1024;
 
