@@ -51,6 +51,7 @@ struct SortedParams {
     int32_t rbits;           // key = (t << rbits) | row ; keys with bit (tbits+rbits) set are padding
     int32_t kbits;           // tbits + rbits
     int32_t max_dim;
+    int32_t nt_rows;         // 1: streaming (non-temporal) destination-row loads/stores
     float alpha;
 };
 
@@ -96,14 +97,25 @@ __global__ void __launch_bounds__(kBlock) build_keys_kernel(const KParams p, K* 
 
 // ---------------------------------------------------------------------------------------------
 // step 3 helpers: destination element types
+// 16-byte destination-row accesses; nt = streaming hint (every touched row is read once and written
+// once per call, so it should not displace the gradient rows that ARE re-read from L2)
+__device__ __forceinline__ u32x4 raw16_load(const char* p, bool nt) {
+    const u32x4* q = reinterpret_cast<const u32x4*>(p);
+    return nt ? __builtin_nontemporal_load(q) : *q;
+}
+__device__ __forceinline__ void raw16_store(char* p, const u32x4 v, bool nt) {
+    u32x4* q = reinterpret_cast<u32x4*>(p);
+    if (nt) __builtin_nontemporal_store(v, q); else *q = v;
+}
+
 struct SDstF32 {
     static constexpr int kVec = 4, kES = 4;
-    __device__ static __forceinline__ void load(const char* p, float (&a)[4]) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
-        a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+    __device__ static __forceinline__ void load(const char* p, float (&a)[4], bool nt = false) {
+        const u32x4 v = raw16_load(p, nt);
+        a[0] = __uint_as_float(v.x); a[1] = __uint_as_float(v.y); a[2] = __uint_as_float(v.z); a[3] = __uint_as_float(v.w);
     }
-    __device__ static __forceinline__ void store(char* p, const float (&a)[4]) {
-        *reinterpret_cast<f32x4*>(p) = f32x4{a[0], a[1], a[2], a[3]};
+    __device__ static __forceinline__ void store(char* p, const float (&a)[4], bool nt = false) {
+        raw16_store(p, u32x4{__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3])}, nt);
     }
 };
 __device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
@@ -113,23 +125,23 @@ __device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
 }
 struct SDstBF16 {
     static constexpr int kVec = 8, kES = 2;
-    __device__ static __forceinline__ void load(const char* p, float (&a)[8]) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(p);
+    __device__ static __forceinline__ void load(const char* p, float (&a)[8], bool nt = false) {
+        const u32x4 v = raw16_load(p, nt);
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) { a[2 * i] = __uint_as_float(w[i] << 16); a[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
     }
-    __device__ static __forceinline__ void store(char* p, const float (&a)[8]) {
+    __device__ static __forceinline__ void store(char* p, const float (&a)[8], bool nt = false) {
         uint32_t w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[i] = f32_to_bf16_rne(a[2 * i]) | (f32_to_bf16_rne(a[2 * i + 1]) << 16);
-        *reinterpret_cast<u32x4*>(p) = u32x4{w[0], w[1], w[2], w[3]};
+        raw16_store(p, u32x4{w[0], w[1], w[2], w[3]}, nt);
     }
 };
 struct SDstF16 {
     static constexpr int kVec = 8, kES = 2;
-    __device__ static __forceinline__ void load(const char* p, float (&a)[8]) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(p);
+    __device__ static __forceinline__ void load(const char* p, float (&a)[8], bool nt = false) {
+        const u32x4 v = raw16_load(p, nt);
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -137,13 +149,13 @@ struct SDstF16 {
             a[2 * i + 1] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(w[i] >> 16)));
         }
     }
-    __device__ static __forceinline__ void store(char* p, const float (&a)[8]) {
+    __device__ static __forceinline__ void store(char* p, const float (&a)[8], bool nt = false) {
         uint32_t w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             w[i] = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, static_cast<_Float16>(a[2 * i]))) |
                    (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, static_cast<_Float16>(a[2 * i + 1]))) << 16);
-        *reinterpret_cast<u32x4*>(p) = u32x4{w[0], w[1], w[2], w[3]};
+        raw16_store(p, u32x4{w[0], w[1], w[2], w[3]}, nt);
     }
 };
 
@@ -333,6 +345,7 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
     sp.rbits = g.rbits;
     sp.kbits = g.kbits;
     sp.max_dim = max_dim;
+    sp.nt_rows = p.nt_loads;
     sp.alpha = p.alpha;
     if (sp.n == 0) return hipSuccess;
     return g.key_bytes == 4 ? launch_apply_k<uint32_t>(sp, dst_dtype, max_dim, stream)
