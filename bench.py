@@ -48,6 +48,8 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--workload", choices=["uniform-tables", "criteo"], default="uniform-tables",
+                   help="criteo: the 26 MLPerf DLRM-v2 tables with per-table multi-hot pooling (BASELINE.json configs[4]), N=1 only")
     p.add_argument("--tables", type=int, default=64, help="logical table count of the workload")
     p.add_argument("--rows", type=int, default=10_000_000)
     p.add_argument("--dim", type=int, default=128)
@@ -185,8 +187,15 @@ def main():
         T_loc = a.tables // world
     assert T_loc >= 1, "not enough HBM for one table"
     B_glob = B_local * world  # table-wise sharding: every rank serves the global batch for its tables
+    rows_list, pool_list = [R] * T_loc, [L] * T_loc
+    if a.workload == "criteo":
+        from param_amd.compute.pt import dataset as ds
 
-    model = param_amd.BatchedEmbeddingBagMI355([R] * T_loc, D, dtype=dtype, device=dev, init="normal",
+        assert not multi, "--workload criteo is a single-GPU configuration of bench.py"
+        rows_list, pool_list, D = list(ds.criteo_v2_rows), list(ds.criteo_v2_multi_hot), ds.criteo_v2_dim
+        T_loc, a.tables = len(rows_list), len(rows_list)
+
+    model = param_amd.BatchedEmbeddingBagMI355(rows_list, D, dtype=dtype, device=dev, init="normal",
                                                seed=1000 + rank, fused_update=False)
     groups = 1 if not multi else max(1, min(a.a2a_groups, T_loc))
     while T_loc % groups:
@@ -194,11 +203,13 @@ def main():
     Tg = T_loc // groups
 
     def make_request(alpha, seed):
-        return tbe_request([R] * T_loc, B_glob, L, alpha=alpha, device=dev, seed=seed + 17 * rank)
+        return tbe_request(rows_list, B_glob, pool_list if a.workload == "criteo" else L, alpha=alpha, device=dev,
+                           seed=seed + 17 * rank)
 
     idx, off = make_request(a.alpha, 1)
-    lookups_step_rank = T_loc * B_glob * L
-    alg_bytes = algorithmic_bytes(T_loc, B_glob, L, D, esize)
+    lookups_step_rank = B_glob * sum(pool_list)
+    # SURVEY 8d per-unit figures summed over tables: per lookup D*e + 8 read, per bag 8 read + D*4 written
+    alg_bytes = sum(algorithmic_bytes(1, B_glob, Lt, D, esize) for Lt in pool_list)
 
     # ---- the step ---------------------------------------------------------------------------
     if not multi:
@@ -242,13 +253,17 @@ def main():
         "dtype": {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}[a.dtype],
         "data": "synthetic",
         "config": {
-            "workload": (f"batched EmbeddingBag(sum) fwd, {a.tables} tables x {R} rows x {D} dim {a.dtype}, "
-                         f"batch {B_local}/rank, pool {L}, Zipf alpha={a.alpha} (reference pmf, per-bag dedupe)"
+            "workload": ((f"batched EmbeddingBag(sum) fwd, {a.tables} tables x {R} rows x {D} dim {a.dtype}, "
+                          f"batch {B_local}/rank, pool {L}, " if a.workload != "criteo" else
+                          f"batched EmbeddingBag(sum) fwd, MLPerf DLRM-v2 Criteo tables (26 tables, {sum(rows_list)} rows, "
+                          f"dim {D}, {a.dtype}), batch {B_local}, multi-hot pooling {sum(pool_list)} lookups/sample, ")
+                         + f"Zipf alpha={a.alpha} (reference pmf, per-bag dedupe)"
                          + (f"; 1 GPU holds {T_loc} of {a.tables} tables ({T_loc * table_bytes / 1e9:.1f} GB): "
                             f"{a.tables} x {table_bytes / 1e9:.2f} GB exceeds 288 GB HBM" if world == 1 and T_loc < a.tables else "")
                          + (f"; table-wise sharded {T_loc}/GPU, global batch {B_glob}, pooled all-to-all in "
                             f"{groups} table groups overlapped with lookup" if world > 1 else "")),
-            "tables_total": a.tables if world > 1 else T_loc, "tables_per_gpu": T_loc, "rows": R, "dim": D,
+            "tables_total": a.tables if world > 1 else T_loc, "tables_per_gpu": T_loc,
+            "rows": R if a.workload != "criteo" else "criteo_v2 (3 .. 40M rows, 204.2 M total)", "dim": D,
             "batch_per_rank": B_local, "global_batch": B_glob, "pooling": L, "alpha": a.alpha,
             "index_dtype": "int64", "parallelism": "1gpu" if world == 1 else f"table-wise x{world} + all-to-all",
             "lookups_per_step": lookups_step_rank * world,
@@ -270,7 +285,7 @@ def main():
     if world == 1 and os.path.exists(pmc_path):
         try:
             pm = json.load(open(pmc_path))
-            key = f"T{T_loc}_R{R}_D{D}_B{B_local}_L{L}_a{a.alpha}_{a.dtype}"
+            key = f"T{T_loc}_R{R}_D{D}_B{B_local}_L{L}_a{a.alpha}_{a.dtype}" if a.workload != "criteo" else "criteo"
             traffic = pm.get(key, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -312,7 +327,7 @@ def main():
 
     if a.bwd and world == 1:
         grad = torch.randn((B_glob, T_loc * D), dtype=torch.float32, device=dev)
-        bwd_bytes = T_loc * B_glob * L * (2 * D * esize + 8) + T_loc * B_glob * (D * 4 + 8)
+        bwd_bytes = lookups_step_rank * (2 * D * esize + 8) + T_loc * B_glob * (D * 4 + 8)
         n_b = max(5, a.steps // 2)
         _, bs = time_steps(lambda: model.scatter_add_(grad, idx, off, alpha=-1e-6, batch=B_glob), n_b, 2, barrier)
         model.sort_indices(idx, off, batch=B_glob)
@@ -331,7 +346,8 @@ def main():
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
-            result["cpu_baseline"] = cpu_baseline(model.table(0), idx[: B_glob * L], B_glob, L)
+            L0 = pool_list[0]  # table 0 of the workload: same rows / dim / indices as on the GPU
+            result["cpu_baseline"] = cpu_baseline(model.table(0), idx[: B_glob * L0], B_glob, L0)
         except Exception as exc:
             result["cpu_baseline"] = {"value": None, "unit": "lookups/s", "cores": torch.get_num_threads(),
                                       "kind": "port", "sample": f"failed: {exc}"}

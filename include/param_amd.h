@@ -147,6 +147,21 @@ int pm_embbag_bwd_sorted(const pm_embbag_batch* op, const float* grad, void* con
                          int64_t workspace_bytes, pm_stream_t stream);
 
 /*
+ * Fused backward + exact row-wise Adagrad (the optimizer the reference configures for its TBE ops,
+ * train/comms/pt/comms_utils.py:2014 and split_table_batched_embeddings_ops.py:289; algorithm as
+ * published by fbgemm_gpu): per touched row r of table t,
+ *     G      = sum over the row's lookups of psw[j] * grad(t, bag(j))[:]      (fp32)
+ *     m[r]  += (sum_d G[d]^2) / D_t
+ *     W[r]  -= lr / (sqrt(m[r]) + eps) * G
+ * `momentum` is a device array [T] of fp32 state pointers, one value per row.  Same sort /
+ * workspace / determinism contract as pm_embbag_bwd_sorted; max_dim <= 256 (fp32) / 512 (16-bit).
+ */
+int pm_embbag_bwd_sorted_adagrad(const pm_embbag_batch* op, const float* grad, void* const* tables,
+                                 int32_t table_dtype, float* const* momentum, float lr, float eps,
+                                 int64_t max_rows, const void* workspace, int64_t workspace_bytes,
+                                 pm_stream_t stream);
+
+/*
  * Validate a request on the device: every index in [0, rows[t]) and offsets
  * monotone within [0, num_indices].  Writes the number of violations to
  * *d_error_count (device int32, caller-zeroed is NOT required: the call zeroes

@@ -207,6 +207,44 @@ int oracle_embbag_bwd_bf16(uint16_t* dst, float* scratch, int64_t rows, int32_t 
     return ORACLE_OK;
 }
 
+/*
+ * Fused backward + exact row-wise Adagrad on an fp32 table (the optimizer the reference configures
+ * for its TBE ops: train/comms/pt/comms_utils.py:2014, split_table_batched_embeddings_ops.py:289
+ * "EXACT_ROWWISE_ADAGRAD").  The arithmetic lives in fbgemm_gpu, which is ABSENT from the survey
+ * container and unpinned in the reference's requirements.txt: restated from fbgemm's published
+ * algorithm; PARITY UNPINNED for this routine (no reference output could be generated).
+ *   per touched row r (each row once per call, duplicates aggregated first = "exact"):
+ *     G     = sum over the row's lookups, in lookup order, of psw[j] * grad[bag(j), :]     (fp32)
+ *     m[r] += (sum_d G[d]^2) / dim
+ *     W[r] -= lr / (sqrtf(m[r]) + eps) * G
+ * scratch: rows*dim floats (aggregated gradient), touched: rows bytes.
+ */
+int oracle_embbag_bwd_rowwise_adagrad_f32(float* W, float* mom, float* scratch, uint8_t* touched, int64_t rows,
+                                          int32_t dim, const int64_t* idx, int64_t N, const int64_t* off, int64_t B,
+                                          const float* psw, const float* grad, int64_t grad_stride, float lr,
+                                          float eps) {
+    memset(scratch, 0, (size_t)rows * dim * sizeof(float));
+    memset(touched, 0, (size_t)rows);
+    int rc = oracle_embbag_bwd_f32(scratch, rows, dim, idx, N, off, B, psw, grad, grad_stride, 1.0f);
+    if (rc != ORACLE_OK) return rc;
+    for (int64_t j = 0; j < N; ++j) touched[idx[j]] = 1;
+    for (int64_t r = 0; r < rows; ++r) {
+        if (!touched[r]) continue;
+        const float* G = scratch + r * (int64_t)dim;
+        double ss = 0.0;  /* fp64 sum of squares: the GPU reduces it in a tree; compared at 1e-6 relative */
+        for (int32_t d = 0; d < dim; ++d) ss += (double)G[d] * (double)G[d];
+        const float m = mom[r] + (float)(ss / (double)dim);
+        mom[r] = m;
+        const float mult = lr / (sqrtf(m) + eps);
+        float* w = W + r * (int64_t)dim;
+        for (int32_t d = 0; d < dim; ++d) {
+            volatile float step = mult * G[d];
+            w[d] = w[d] - step;
+        }
+    }
+    return ORACLE_OK;
+}
+
 /* widen helpers exported for the tests */
 void oracle_bf16_to_f32(const uint16_t* src, float* dst, int64_t n) {
     for (int64_t i = 0; i < n; ++i) dst[i] = bf16_to_f32(src[i]);

@@ -154,6 +154,10 @@ class COracle:
         L.oracle_embbag_bwd_bf16.restype = ctypes.c_int
         L.oracle_embbag_bwd_bf16.argtypes = [ctypes.POINTER(ctypes.c_uint16), f32p, i64, i32, i64p, i64,
                                              i64p, i64, f32p, f32p, i64, ctypes.c_float]
+        L.oracle_embbag_bwd_rowwise_adagrad_f32.restype = ctypes.c_int
+        L.oracle_embbag_bwd_rowwise_adagrad_f32.argtypes = [f32p, f32p, f32p, ctypes.POINTER(ctypes.c_uint8), i64, i32,
+                                                            i64p, i64, i64p, i64, f32p, f32p, i64, ctypes.c_float,
+                                                            ctypes.c_float]
         self.L = L
 
     @staticmethod
@@ -230,6 +234,24 @@ class COracle:
                                           grad.shape[1], float(alpha))
         self._check(rc)
         return dst
+
+    def bwd_rowwise_adagrad(self, W: np.ndarray, mom: np.ndarray, idx, off, grad: np.ndarray, psw=None, lr=0.01,
+                            eps=1e-8):
+        """in place on W (fp32 [R,D]) and mom (fp32 [R]); PARITY UNPINNED (fbgemm absent), see the C header."""
+        assert W.dtype == np.float32 and W.flags.c_contiguous and mom.dtype == np.float32 and mom.shape == (W.shape[0],)
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        off = np.ascontiguousarray(off, dtype=np.int64)
+        grad = np.ascontiguousarray(grad, dtype=np.float32)
+        psw = None if psw is None else np.ascontiguousarray(psw, dtype=np.float32)
+        scratch = np.empty_like(W)
+        touched = np.empty(W.shape[0], dtype=np.uint8)
+        rc = self.L.oracle_embbag_bwd_rowwise_adagrad_f32(
+            _ptr(W, ctypes.c_float), _ptr(mom, ctypes.c_float), _ptr(scratch, ctypes.c_float),
+            _ptr(touched, ctypes.c_uint8), W.shape[0], W.shape[1], _ptr(idx, ctypes.c_int64), len(idx),
+            _ptr(off, ctypes.c_int64), len(off), _ptr(psw, ctypes.c_float), _ptr(grad, ctypes.c_float), grad.shape[1],
+            float(lr), float(eps))
+        self._check(rc)
+        return W, mom
 
     def bwd_bf16(self, dst_bits: np.ndarray, idx, off, grad: np.ndarray, psw=None, alpha=1.0):
         """in-place on a uint16 (bf16 bit pattern) table."""

@@ -11,8 +11,9 @@ on across tables, ``T*B+1`` entries) and the generator's alpha switch (0: ``aran
 <= 1: uniform, > 1: ``np.random.zipf(alpha) % E``).
 
 Stated differences: pooling must be SUM (PoolingMode 0, the only mode on the reference hot path); the
-optimizer applied by ``backward`` is the plain in-place SGD scatter-add (``"sgd"``/``"exact_sgd"``; row-wise
-Adagrad is listed under "next" in DESIGN.md) -- other optimizer names raise; ``device`` must be a ROCm device.
+optimizer fused into ``backward`` is plain SGD (``"sgd"``/``"exact_sgd"``) or exact row-wise Adagrad
+(``"exact_row_wise_adagrad"``, the reference's choice at comms_utils.py:2014) -- other optimizer names raise;
+weight decay and stochastic rounding are not implemented; ``device`` must be a ROCm device.
 """
 from __future__ import annotations
 
@@ -78,14 +79,20 @@ class SplitTableBatchedEmbeddingBagsCodegenOp(OperatorInterface):
         dims_list = dims if isinstance(dims, list) else [dims] * num_tables
         if int(pooling) != 0:
             raise ValueError("only PoolingMode.SUM (0) is implemented on the MI355X path")
-        if str(optimizer).lower() not in ("sgd", "exact_sgd"):
-            raise ValueError(f"optimizer {optimizer!r}: only plain SGD is fused into the MI355X backward so far")
+        opt = str(optimizer).lower()
+        if opt in ("sgd", "exact_sgd"):
+            opt = "sgd"
+        elif opt in ("exact_row_wise_adagrad", "exact_rowwise_adagrad", "rowwise_adagrad", "row_wise_adagrad"):
+            opt = "rowwise_adagrad"   # fbgemm OptimType.EXACT_ROWWISE_ADAGRAD ("exact_row_wise_adagrad")
+        else:
+            raise ValueError(f"optimizer {optimizer!r}: the MI355X backward fuses plain SGD and exact row-wise Adagrad only")
         if not str(self.device).startswith(("cuda", "rocm")):
             raise ValueError(f"Unknown compute device {self.device} (the MI355X operator needs a ROCm device)")
         dev = "cuda" + str(self.device)[4:] if str(self.device).startswith("rocm") else str(self.device)
         self.weighted = weighted
         self.op = BatchedEmbeddingBagMI355(rows_list, dims_list, dtype=_PRECISION[str(weights_precision).lower()],
-                                           device=dev, init="uniform_dlrm", learning_rate=lr, fused_update=True)
+                                           device=dev, init="uniform_dlrm", learning_rate=lr, fused_update=True,
+                                           optimizer=opt, eps=eps)
 
     def cleanup(self):
         self.op = None
@@ -109,7 +116,7 @@ class SplitTableBatchedEmbeddingBagsCodegenOp(OperatorInterface):
                 self.create_grad()
             grad = self.grad_in
         indices, offsets, psw = self._request
-        self.op.scatter_add_(grad, indices, offsets, alpha=-self.op.learning_rate, per_sample_weights=psw)
+        self.op.optimizer_step_(grad, indices, offsets, per_sample_weights=psw)
 
 
 register_operator("SplitTableBatchedEmbeddingBagsCodegen", SplitTableBatchedEmbeddingBagsCodegenOp())

@@ -67,7 +67,9 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p) {
     const int64_t avg_l = total_bags > 0 ? (op->num_indices + total_bags - 1) / total_bags : 0;
     int64_t cap = 2 * bpb * avg_l;
     cap = (cap + 255) / 256 * 256;
-    if (cap < 1024) cap = 1024;
+    // tables of one request can have very different bag sizes (Criteo multi-hot 1 .. 100 at an average of 8):
+    // size the tile for 4x the average, at least 2048 entries (4096 unweighted: 16 KiB of LDS per workgroup)
+    if (cap < (op->per_sample_weights ? 2048 : 4096)) cap = op->per_sample_weights ? 2048 : 4096;
     if (cap > 4096) cap = 4096;
 
     p.tables = op->tables;
@@ -212,8 +214,35 @@ int pm_embbag_bwd_sorted(const pm_embbag_batch* op, const float* grad, void* con
     p.io = const_cast<float*>(grad);
     p.tables = const_cast<const void* const*>(dst_tables);
     p.alpha = alpha;
-    h = pm::bwd_sorted_apply(p, max_rows, dst_dtype, op->max_dim, workspace, static_cast<hipStream_t>(stream));
+    h = pm::bwd_sorted_apply(p, max_rows, dst_dtype, op->max_dim, workspace, nullptr, 0.0f, 0.0f,
+                             static_cast<hipStream_t>(stream));
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_bwd_sorted launch");
+    return PM_OK;
+}
+
+int pm_embbag_bwd_sorted_adagrad(const pm_embbag_batch* op, const float* grad, void* const* tables, int32_t table_dtype,
+                                 float* const* momentum, float lr, float eps, int64_t max_rows, const void* workspace,
+                                 int64_t workspace_bytes, pm_stream_t stream) {
+    pm::KParams p;
+    int rc = make_params(op, table_dtype, p);
+    if (rc != PM_OK) return rc;
+    if ((rc = sorted_args_ok(op, max_rows)) != PM_OK) return rc;
+    if (p.N == 0 || p.bag_count == 0) return PM_OK;
+    if (!grad || !tables || !momentum) return fail(PM_ERR_INVALID, "grad / tables / momentum is NULL");
+    const int vec = (table_dtype == PM_F32) ? 4 : 8;
+    if (op->max_dim > 64 * vec)
+        return fail(PM_ERR_UNSUPPORTED, "row-wise Adagrad needs max_dim <= " + std::to_string(64 * vec) + " for this table dtype");
+    size_t need = 0;
+    hipError_t h = pm::sorted_workspace_bytes(p, max_rows, op->max_dim, need);
+    if (h != hipSuccess) return hip_fail(h, "pm_embbag_bwd_sorted_adagrad");
+    if (!workspace || workspace_bytes < static_cast<int64_t>(need))
+        return fail(PM_ERR_INVALID, "workspace too small: need " + std::to_string(need) + " bytes");
+    p.io = const_cast<float*>(grad);
+    p.tables = const_cast<const void* const*>(tables);
+    p.alpha = 1.0f;
+    h = pm::bwd_sorted_apply(p, max_rows, table_dtype, op->max_dim, workspace, momentum, lr, eps,
+                             static_cast<hipStream_t>(stream));
+    if (h != hipSuccess) return hip_fail(h, "pm_embbag_bwd_sorted_adagrad launch");
     return PM_OK;
 }
 

@@ -118,7 +118,7 @@ hipError_t launch_fill_random(void* dst, int64_t count, int dtype, int dist, flo
 hipError_t sorted_workspace_bytes(const KParams& p, int64_t max_rows, int max_dim, size_t& bytes);
 hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, void* workspace, hipStream_t stream);
 hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, int max_dim, const void* workspace,
-                            hipStream_t stream);
+                            float* const* momentum, float lr, float eps, hipStream_t stream);
 
 // lanes per bag for a given widest row: next power of two >= max_dim / vec, clamped to [8, 64]
 inline int group_lanes(int max_dim, int vec) {

@@ -53,6 +53,9 @@ struct SortedParams {
     int32_t max_dim;
     int32_t nt_rows;         // 1: streaming (non-temporal) destination-row loads/stores
     float alpha;
+    float* const* mom;       // row-wise Adagrad: device array [T] of per-row fp32 state (else NULL)
+    float lr;
+    float eps;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -256,13 +259,19 @@ hipError_t launch_apply_w(const SortedParams& sp, hipStream_t stream) {
     const int64_t grid = (sp.n + kSortTile - 1) / kSortTile;
     const int64_t n_chunks = (sp.n + C - 1) / C;       // every chunk below this index wrote its record
     const int64_t fgrid = (n_chunks + NG - 1) / NG;
-    if (sp.psw) {
-        hipLaunchKernelGGL((bwd_sorted_main_kernel<DST, K, G, true>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, sp);
-        hipLaunchKernelGGL((bwd_sorted_fixup_kernel<DST, K, G, true>), dim3(static_cast<unsigned>(fgrid)), dim3(kBlock), 0, stream, sp, n_chunks);
+    const dim3 g1(static_cast<unsigned>(grid)), g2(static_cast<unsigned>(fgrid)), blk(kBlock);
+#define PM_LAUNCH_SORTED(W_, OPT_)                                                                             \
+    do {                                                                                                       \
+        hipLaunchKernelGGL((bwd_sorted_main_kernel<DST, K, G, W_, OPT_>), g1, blk, 0, stream, sp);             \
+        hipLaunchKernelGGL((bwd_sorted_fixup_kernel<DST, K, G, W_, OPT_>), g2, blk, 0, stream, sp, n_chunks); \
+    } while (0)
+    if (sp.mom) {  // row-wise Adagrad: one column pass with all G lanes (cross-lane reduction)
+        if (sp.max_dim > G * DST::kVec) return hipErrorInvalidValue;
+        if (sp.psw) PM_LAUNCH_SORTED(true, 1); else PM_LAUNCH_SORTED(false, 1);
     } else {
-        hipLaunchKernelGGL((bwd_sorted_main_kernel<DST, K, G, false>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, stream, sp);
-        hipLaunchKernelGGL((bwd_sorted_fixup_kernel<DST, K, G, false>), dim3(static_cast<unsigned>(fgrid)), dim3(kBlock), 0, stream, sp, n_chunks);
+        if (sp.psw) PM_LAUNCH_SORTED(true, 0); else PM_LAUNCH_SORTED(false, 0);
     }
+#undef PM_LAUNCH_SORTED
     return hipGetLastError();
 }
 
@@ -322,7 +331,7 @@ hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, void* w
 }
 
 hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, int max_dim, const void* workspace,
-                            hipStream_t stream) {
+                            float* const* momentum, float lr, float eps, hipStream_t stream) {
     const SortedGeom g = sorted_geom(p, max_rows);
     SortWs ws;
     hipError_t rc = ws_layout(const_cast<void*>(workspace), p.N, g.key_bytes, g.kbits + 1, g.weighted, max_dim, ws);
@@ -347,6 +356,9 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
     sp.max_dim = max_dim;
     sp.nt_rows = p.nt_loads;
     sp.alpha = p.alpha;
+    sp.mom = momentum;
+    sp.lr = lr;
+    sp.eps = eps;
     if (sp.n == 0) return hipSuccess;
     return g.key_bytes == 4 ? launch_apply_k<uint32_t>(sp, dst_dtype, max_dim, stream)
                             : launch_apply_k<uint64_t>(sp, dst_dtype, max_dim, stream);

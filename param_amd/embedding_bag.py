@@ -203,6 +203,24 @@ def check_request(ts: _TableSet, indices, offsets, B, psw=None) -> None:
         raise IndexError(f"param_amd: {n} out-of-range indices / invalid offsets in EmbeddingBag request")
 
 
+def _adagrad(ts: _TableSet, grad, indices, offsets, B, mom_ptrs_dev, lr: float, eps: float, psw=None,
+             presorted: bool = False):
+    """Fused backward + exact row-wise Adagrad on the tables of ``ts`` (``pm_embbag_bwd_sorted_adagrad``)."""
+    _require_device(grad, "grad")
+    _, _, shape = ts.out_desc(B)
+    if grad.dtype != torch.float32 or tuple(grad.shape) != tuple(shape):
+        raise ValueError(f"grad must be float32 of shape {shape}")
+    grad = grad.contiguous()
+    op = ts.request(indices, offsets, B, psw, 0, None)
+    L = _lib.load()
+    ws = _workspace(ts, op)
+    if not presorted:
+        _lib.check(L.pm_embbag_sort_indices(ctypes.byref(op), max(ts.rows), ws.data_ptr(), ws.numel(), _stream_ptr()))
+    _lib.check(L.pm_embbag_bwd_sorted_adagrad(ctypes.byref(op), grad.data_ptr(), ts.d_ptrs.data_ptr(), _WDTYPE[ts.dtype],
+                                              mom_ptrs_dev.data_ptr(), float(lr), float(eps), max(ts.rows),
+                                              ws.data_ptr(), ws.numel(), _stream_ptr()))
+
+
 class _DenseGradFn(torch.autograd.Function):
     """forward = batched lookup; backward = scatter-add into a dense fp32 weight.grad
     (torch ``sparse=False`` semantics, aten::_embedding_bag_dense_backward)."""
@@ -282,8 +300,7 @@ class _FusedUpdateFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         indices, offsets, psw = ctx.saved_tensors
-        ctx.module.scatter_add_(grad_out, indices, offsets, alpha=-ctx.module.learning_rate,
-                                per_sample_weights=psw if ctx.has_psw else None)
+        ctx.module.optimizer_step_(grad_out, indices, offsets, per_sample_weights=psw if ctx.has_psw else None)
         return None, None, None, None, None
 
 
@@ -297,13 +314,18 @@ class BatchedEmbeddingBagMI355(nn.Module):
 
     def __init__(self, rows: Sequence[int], dims, dtype: torch.dtype = torch.float32, device="cuda",
                  layout: str = "bd", init: Optional[str] = "uniform_dlrm", seed: int = 0,
-                 learning_rate: float = 0.01, fused_update: bool = True):
+                 learning_rate: float = 0.01, fused_update: bool = True, optimizer: str = "sgd", eps: float = 1.0e-8):
         super().__init__()
         rows = [int(r) for r in rows]
         dims = [int(dims)] * len(rows) if isinstance(dims, int) else [int(d) for d in dims]
         assert len(rows) == len(dims) and len(rows) >= 1
         self.rows, self.dims, self.layout = rows, dims, layout
         self.learning_rate, self.fused_update = learning_rate, fused_update
+        if optimizer not in ("sgd", "rowwise_adagrad"):
+            raise ValueError('optimizer must be "sgd" or "rowwise_adagrad"')
+        self.optimizer, self.eps = optimizer, eps
+        self.momentum: Optional[torch.Tensor] = None      # row-wise Adagrad state: one fp32 per row
+        self._mom_ptrs: Optional[torch.Tensor] = None
         sizes = [r * d for r, d in zip(rows, dims)]
         esize = torch.empty(0, dtype=dtype).element_size()
         # table starts padded to 256 B so every row stays 16-byte aligned
@@ -374,6 +396,37 @@ class BatchedEmbeddingBagMI355(nn.Module):
         B = self._batch_of(offsets) if batch is None else batch
         _bwd(ts, grad, indices, offsets, B, ts.d_ptrs, self.weights.dtype, alpha, per_sample_weights,
              bag_begin, bag_count, method, presorted)
+
+    def momentum_table(self, t: int) -> torch.Tensor:
+        """row-wise Adagrad state of table t (allocated zero on first use)"""
+        if self.momentum is None:
+            self.momentum = torch.zeros(sum(self.rows), dtype=torch.float32, device=self.weights.device)
+            starts = [0]
+            for r in self.rows[:-1]:
+                starts.append(starts[-1] + r)
+            self._mom_starts = starts
+            self._mom_ptrs = torch.tensor([self.momentum.data_ptr() + 4 * s for s in starts], dtype=torch.int64,
+                                          device=self.weights.device)
+        s = self._mom_starts[t]
+        return self.momentum[s:s + self.rows[t]]
+
+    def adagrad_step_(self, grad, indices, offsets, per_sample_weights=None, batch: Optional[int] = None,
+                      presorted: bool = False):
+        """Fused backward + exact row-wise Adagrad (TBE ``EXACT_ROWWISE_ADAGRAD``, the optimizer the reference
+        configures at comms_utils.py:2014): ``m[r] += mean_d(G[r,d]^2); W[r] -= lr / (sqrt(m[r]) + eps) * G[r]``."""
+        self.momentum_table(0)
+        B = self._batch_of(offsets) if batch is None else batch
+        _adagrad(self._tables(), grad, indices, offsets, B, self._mom_ptrs, self.learning_rate, self.eps,
+                 per_sample_weights, presorted)
+
+    def optimizer_step_(self, grad, indices, offsets, per_sample_weights=None, batch: Optional[int] = None,
+                        presorted: bool = False):
+        """what ``.backward()`` applies when ``fused_update`` is on"""
+        if self.optimizer == "rowwise_adagrad":
+            self.adagrad_step_(grad, indices, offsets, per_sample_weights, batch, presorted)
+        else:
+            self.scatter_add_(grad, indices, offsets, alpha=-self.learning_rate, per_sample_weights=per_sample_weights,
+                              batch=batch, presorted=presorted)
 
     def dense_grad(self, grad, indices, offsets, per_sample_weights=None, batch: Optional[int] = None,
                    method: str = "sorted"):

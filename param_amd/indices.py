@@ -111,21 +111,31 @@ def zipf_indices(alpha: float, features: int, batch: int, nnz: int, device=None,
     return out.reshape(-1)
 
 
-def tbe_request(rows: Sequence[int], batch: int, pooling: int, alpha: float = 0.0, device=None,
+def tbe_request(rows: Sequence[int], batch: int, pooling, alpha: float = 0.0, device=None,
                 seed: int = 0, index_dtype=torch.int64):
     """A batched request in the TBE layout the reference's data generator emits
     (split_table_batched_embeddings_ops.py:191-208): indices = per-table lists concatenated
     table-major, offsets = ``[0, L, 2L, ...]`` running on across tables, length ``T*B+1``.
     alpha == 0 -> uniform ``randint``; alpha > 0 -> :func:`zipf_indices` (pmf of
-    pytorch_emb.py:143, the benchmark's skew model)."""
+    pytorch_emb.py:143, the benchmark's skew model).  ``pooling`` is one bag size for every table or a
+    per-table list (multi-hot sizes of a Criteo-style model); a table with fewer rows than its
+    pooling factor is sampled with replacement."""
     gen = torch.Generator(device=device if device is not None else "cpu")
     gen.manual_seed(seed)
+    pools = [int(pooling)] * len(rows) if isinstance(pooling, int) else [int(x) for x in pooling]
+    assert len(pools) == len(rows)
     parts = []
-    for r in rows:
-        if alpha == 0.0:
-            parts.append(torch.randint(0, int(r), (batch * pooling,), device=device, generator=gen))
+    for r, L in zip(rows, pools):
+        if alpha == 0.0 or int(r) < 4 * L:
+            parts.append(torch.randint(0, int(r), (batch * L,), device=device, generator=gen))
         else:
-            parts.append(zipf_indices(alpha, int(r), batch, pooling, device=device, generator=gen))
+            parts.append(zipf_indices(alpha, int(r), batch, L, device=device, generator=gen))
     indices = torch.cat(parts).to(index_dtype)
-    offsets = torch.arange(len(rows) * batch + 1, dtype=index_dtype, device=device) * pooling
+    if len(set(pools)) == 1:
+        offsets = torch.arange(len(rows) * batch + 1, dtype=index_dtype, device=device) * pools[0]
+    else:
+        lens = torch.cat([torch.full((batch,), L, dtype=torch.int64, device=device) for L in pools])
+        offsets = torch.zeros(len(rows) * batch + 1, dtype=torch.int64, device=device)
+        torch.cumsum(lens, 0, out=offsets[1:])
+        offsets = offsets.to(index_dtype)
     return indices, offsets

@@ -377,6 +377,42 @@ def test_sorted_backward_wide_keys():
     assert float(m.table(0)[(1 << 30) - 1].abs().sum()) > 0
 
 
+def test_criteo_shaped_tables_multi_hot(coracle):
+    """BASELINE configs[4] geometry scaled down: 26 tables of very different sizes (3 rows .. 50 K), per-table
+    multi-hot pooling 1 .. 100 in one batched request: forward bit-exact, in-place update exact on cold rows."""
+    from oracle.embbag_oracle import bag_bounds
+    from param_amd import BatchedEmbeddingBagMI355
+    from param_amd.compute.pt import dataset as ds
+    from param_amd.indices import tbe_request
+
+    rows = [min(r, 50000) for r in ds.criteo_v2_rows]
+    pools, D, B = ds.criteo_v2_multi_hot, 128, 256
+    m = BatchedEmbeddingBagMI355(rows, D, device=DEV, init="normal", seed=5, fused_update=False)
+    idx, off = tbe_request(rows, B, pools, alpha=1.05, device=DEV, seed=9)
+    assert off.numel() == 26 * B + 1 and int(off[-1]) == B * sum(pools) == idx.numel()
+    m.check(idx, off)
+    tabs = [m.table(t).cpu().numpy().copy() for t in range(26)]
+    out = m.lookup(idx, off)
+    ih, oh = idx.cpu().numpy(), off.cpu().numpy()
+    assert np.array_equal(out.cpu().numpy(), coracle.fwd_batched(tabs, ih, oh, B))
+    grad = torch.randn(B, 26 * D, device=DEV)
+    m.scatter_add_(grad, idx, off, alpha=-0.01)
+    gh = grad.cpu().numpy()
+    for t in range(26):
+        s, e = oh[t * B], oh[(t + 1) * B]
+        loc = oh[t * B:(t + 1) * B] - s
+        g = np.ascontiguousarray(gh[:, t * D:(t + 1) * D])
+        exp = coracle.bwd_f32(tabs[t].copy(), ih[s:e], loc, g, alpha=-0.01)
+        got = m.table(t).cpu().numpy()
+        cold = np.bincount(ih[s:e], minlength=rows[t]) <= EXACT_RUN
+        assert np.array_equal(got[cold], exp[cold]), t
+        start, end = bag_bounds(loc, B, e - s)
+        truth = tabs[t].astype(np.float64)
+        np.add.at(truth, ih[s:e], -0.01 * g.astype(np.float64)[np.repeat(np.arange(B), end - start)])
+        tol = 1e-5 * (_mag(tabs[t].shape, ih[s:e], loc, g, None, 0.01) + np.abs(tabs[t])) + 1e-30
+        assert (np.abs(got - truth) <= tol).all(), t
+
+
 # ----------------------------------------------------------------------------- utilities
 def test_check_request_raises_like_torch(cases):
     from param_amd import check_request
@@ -465,3 +501,58 @@ def test_full_size_properties_and_live_torch_oracle():
     hit[idx[:B * L]] = True
     untouched = (~hit[:1000]).nonzero().squeeze(1)
     assert torch.equal(t0[untouched], probe[untouched])
+
+
+def test_fused_rowwise_adagrad_vs_oracle(coracle):
+    """pm_embbag_bwd_sorted_adagrad vs the CPU restatement of fbgemm's exact row-wise Adagrad (parity UNPINNED:
+    fbgemm is absent; the oracle itself is checked against an fp64 numpy form here).  Two steps, Zipf duplicates
+    incl. a hot row (chunk-partial path), per-sample weights, dims whose lane group has idle lanes (D=56)."""
+    from param_amd import BatchedEmbeddingBagMI355
+    from param_amd.indices import zipf_indices
+
+    rng = np.random.default_rng(8)
+    for D, weighted in [(128, False), (56, True), (64, False), (256, True)]:
+        rows, B, L = [4000, 700], 300, 10
+        m = BatchedEmbeddingBagMI355(rows, D, device=DEV, init="normal", seed=D, learning_rate=0.05,
+                                     optimizer="rowwise_adagrad", eps=1e-6)
+        W = [m.table(t).cpu().numpy().copy() for t in range(2)]
+        mom = [np.zeros(r, np.float32) for r in rows]
+        for step in range(2):
+            idx = torch.cat([zipf_indices(1.3, r, B * L, 1, dedupe=False, generator=torch.Generator().manual_seed(10 * step + t))
+                             for t, r in enumerate(rows)])
+            idx[:450] = 3                                        # hot row: > EXACT_RUN lookups in table 0
+            off = torch.arange(2 * B + 1) * L
+            grad = torch.from_numpy(rng.standard_normal((B, 2 * D)).astype(np.float32))
+            psw = torch.from_numpy(rng.uniform(0.5, 1.5, idx.numel()).astype(np.float32)) if weighted else None
+            m.adagrad_step_(grad.to(DEV), idx.to(DEV), off.to(DEV), None if psw is None else psw.to(DEV))
+            for t in range(2):
+                s, e = t * B * L, (t + 1) * B * L
+                g = np.ascontiguousarray(grad.numpy()[:, t * D:(t + 1) * D])
+                W0, m0 = W[t].copy(), mom[t].copy()
+                coracle.bwd_rowwise_adagrad(W[t], mom[t], idx.numpy()[s:e], np.arange(B) * L, g,
+                                            None if psw is None else psw.numpy()[s:e], lr=0.05, eps=1e-6)
+                # the oracle against an fp64 form of the published algorithm
+                G = np.zeros(W0.shape)
+                w8 = np.ones(B * L) if psw is None else psw.numpy()[s:e].astype(np.float64)
+                np.add.at(G, idx.numpy()[s:e], g.astype(np.float64)[np.repeat(np.arange(B), L)] * w8[:, None])
+                touched = np.bincount(idx.numpy()[s:e], minlength=rows[t]) > 0
+                m64 = m0 + (G ** 2).mean(1)
+                W64 = W0 - 0.05 / (np.sqrt(m64)[:, None] + 1e-6) * G
+                assert np.allclose(mom[t][touched], m64[touched], rtol=2e-5, atol=1e-12)
+                assert np.allclose(W[t][touched], W64[touched], rtol=1e-4, atol=2e-5)
+                # the GPU against the oracle
+                gm = m.momentum_table(t).cpu().numpy()
+                gw = m.table(t).cpu().numpy()
+                assert np.array_equal(gw[~touched], W0[~touched]) and np.array_equal(gm[~touched], m0[~touched])
+                assert np.allclose(gm, mom[t], rtol=1e-5, atol=1e-12), (D, step, t)
+                assert np.allclose(gw, W[t], rtol=1e-5, atol=1e-6), (D, step, t)
+        # deterministic: a second module fed the same two steps ends bit-identical
+    ma = BatchedEmbeddingBagMI355([500], 128, device=DEV, init="normal", seed=1, optimizer="rowwise_adagrad")
+    mb = BatchedEmbeddingBagMI355([500], 128, device=DEV, init="normal", seed=1, optimizer="rowwise_adagrad")
+    idx = torch.randint(0, 500, (64 * 20,), device=DEV)
+    off = torch.arange(65, device=DEV) * 20
+    g = torch.randn(64, 128, device=DEV)
+    for mod in (ma, mb):
+        out = mod(idx, off)                 # autograd path: backward == fused Adagrad step
+        out.backward(g)
+    assert torch.equal(ma.table(0), mb.table(0)) and torch.equal(ma.momentum, mb.momentum) and float(ma.momentum.sum()) > 0

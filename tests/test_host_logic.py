@@ -136,7 +136,7 @@ def test_operator_registry_contract():
     with pytest.raises(ValueError, match="SUM"):
         op.build(2, 100, 8, 1, False, "fp32", "sgd")
     with pytest.raises(ValueError, match="SGD"):
-        op.build(2, 100, 8, 0, False, "fp32", "exact_row_wise_adagrad")
+        op.build(2, 100, 8, 0, False, "fp32", "adam")
 
 
 def test_generate_requests_layout():
