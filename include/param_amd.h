@@ -162,6 +162,19 @@ int pm_embbag_bwd_sorted_adagrad(const pm_embbag_batch* op, const float* grad, v
                                  pm_stream_t stream);
 
 /*
+ * DLRM input redistribution on the device: regroup what the lengths / indices all-to-alls deliver
+ * (train/comms/pt/dlrm.py:744-855) -- lengths [world][num_tables][batch] int64 and the indices
+ * concatenated block by block in that (rank, table) order -- into the TBE request of the batched
+ * kernel: out_indices table-major (within a table rank-major = global sample order) and out_offsets
+ * [num_tables*world*batch + 1].  Replaces splitPerTable (dlrm.py:430-504: O(world*tables) Python
+ * slicing / torch.cat with host syncs) with two launches and no host sync.
+ * scratch: world*num_tables int64 (device).  out_indices must hold as many entries as `indices`.
+ */
+int pm_dlrm_regroup(const int64_t* lengths, const int64_t* indices, int32_t world_size, int32_t num_tables,
+                    int64_t batch, int64_t* out_indices, int64_t* out_offsets, int64_t* scratch,
+                    pm_stream_t stream);
+
+/*
  * Validate a request on the device: every index in [0, rows[t]) and offsets
  * monotone within [0, num_indices].  Writes the number of violations to
  * *d_error_count (device int32, caller-zeroed is NOT required: the call zeroes

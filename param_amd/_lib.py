@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = (
     "pm_embbag_sort_indices",
     "pm_embbag_bwd_sorted",
     "pm_embbag_bwd_sorted_adagrad",
+    "pm_dlrm_regroup",
     "pm_embbag_check",
     "pm_fill_random",
     "pm_set_tuning",
@@ -107,6 +108,8 @@ def load() -> ctypes.CDLL:
         L.pm_embbag_bwd_sorted_adagrad.restype = ctypes.c_int
         L.pm_embbag_bwd_sorted_adagrad.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, vp, ctypes.c_float,
                                                    ctypes.c_float, i64, vp, i64, vp]
+        L.pm_dlrm_regroup.restype = ctypes.c_int
+        L.pm_dlrm_regroup.argtypes = [vp, vp, i32, i32, i64, vp, vp, vp, vp]
         L.pm_embbag_check.restype = ctypes.c_int
         L.pm_embbag_check.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp]
         L.pm_fill_random.restype = ctypes.c_int

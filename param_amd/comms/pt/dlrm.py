@@ -90,6 +90,20 @@ def regroup_per_table(lengths: torch.Tensor, indices: torch.Tensor, batch_size: 
     Same regrouping as the reference's splitPerTable (dlrm.py:430-504)."""
     W, F, B = world_size, num_my_features, batch_size
     dev = lengths.device
+    if lengths.is_cuda:
+        # product path: two HIP launches (block sums; scan + gather), no host sync -- pm_dlrm_regroup
+        from ... import _lib
+
+        lengths = lengths.to(torch.int64).contiguous()
+        indices = indices.to(torch.int64).contiguous()
+        out_idx = torch.empty_like(indices)
+        out_off = torch.empty(F * W * B + 1, dtype=torch.int64, device=dev)
+        scratch = torch.empty(W * F, dtype=torch.int64, device=dev)
+        _lib.check(_lib.load().pm_dlrm_regroup(lengths.data_ptr(), indices.data_ptr(), W, F, B, out_idx.data_ptr(),
+                                               out_off.data_ptr(), scratch.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream))
+        return out_idx, out_off
+    # host tensors (the world-2 gloo tests of the plumbing): the same regrouping with torch ops
     l3 = lengths.view(W, F, B).to(torch.int64)
     block = l3.sum(dim=2)                                  # [W, F] indices per (rank, table) block
     src_start = torch.cumsum(block.reshape(-1), 0) - block.reshape(-1)       # received order (r, f)

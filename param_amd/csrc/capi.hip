@@ -254,6 +254,17 @@ int pm_embbag_bwd_sorted_adagrad(const pm_embbag_batch* op, const float* grad, v
     return PM_OK;
 }
 
+int pm_dlrm_regroup(const int64_t* lengths, const int64_t* indices, int32_t world_size, int32_t num_tables,
+                    int64_t batch, int64_t* out_indices, int64_t* out_offsets, int64_t* scratch, pm_stream_t stream) {
+    if (world_size < 1 || num_tables < 1 || batch < 0) return fail(PM_ERR_INVALID, "world_size / num_tables / batch");
+    if (static_cast<int64_t>(world_size) * num_tables > 4096) return fail(PM_ERR_UNSUPPORTED, "world_size * num_tables > 4096");
+    if (!lengths || !out_offsets || !scratch) return fail(PM_ERR_INVALID, "lengths / out_offsets / scratch is NULL");
+    hipError_t h = pm::launch_dlrm_regroup(lengths, indices, world_size, num_tables, batch, out_indices, out_offsets,
+                                           scratch, static_cast<hipStream_t>(stream));
+    if (h != hipSuccess) return hip_fail(h, "pm_dlrm_regroup launch");
+    return PM_OK;
+}
+
 int pm_embbag_check(const pm_embbag_batch* op, int32_t* d_error_count, pm_stream_t stream) {
     pm::KParams p;
     int rc = make_params(op, op ? op->weight_dtype : -1, p);

@@ -120,6 +120,10 @@ hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, void* w
 hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, int max_dim, const void* workspace,
                             float* const* momentum, float lr, float eps, hipStream_t stream);
 
+// DLRM input redistribution (dlrm_regroup.hip)
+hipError_t launch_dlrm_regroup(const int64_t* lengths, const int64_t* indices, int W, int F, int64_t B,
+                               int64_t* out_indices, int64_t* out_offsets, int64_t* scratch, hipStream_t stream);
+
 // lanes per bag for a given widest row: next power of two >= max_dim / vec, clamped to [8, 64]
 inline int group_lanes(int max_dim, int vec) {
     int need = (max_dim + vec - 1) / vec;

@@ -199,3 +199,20 @@ def test_comms_compute_overlap_bench_single_gpu():
                                   "--direction", "backward", "--num-compute", "2", "--ntables", "4", "--num-emb-tables-batched", "2",
                                   "--num-embs", "50000", "--batch-size", "512"])
     assert res[0]["memSize"] == 0 and res[0]["compute_dev_us"] > 0
+
+
+def test_dlrm_regroup_hip_kernel(golden_dir):
+    """pm_dlrm_regroup (2 launches, no host sync) == the host regrouping == the reference's splitPerTable golden"""
+    from param_amd.comms.pt import dlrm as D_
+
+    s = json.load(open(os.path.join(golden_dir, "comms_pure.json")))["splitPerTable"]
+    lengths, indices = torch.tensor(s["lengths"], device=DEV), torch.tensor(s["indices"], device=DEV)
+    o, i = D_.splitPerTable(lengths, indices, s["batch"], s["features"], s["world"])
+    assert [x.tolist() for x in o] == s["offsets_out"] and [x.tolist() for x in i] == s["indices_out"]
+    g = torch.Generator().manual_seed(3)
+    for W, F, B, Lmax in [(8, 4, 8192, 40), (2, 3, 5, 4), (8, 26, 64, 3), (1, 1, 1, 1), (4, 2, 1000, 0)]:
+        lengths = torch.randint(0, Lmax + 1, (W * F * B,), generator=g)
+        indices = torch.randint(0, 1 << 40, (int(lengths.sum()),), generator=g)
+        ci, co = D_.regroup_per_table(lengths, indices, B, F, W)                      # host form (torch ops)
+        gi, go = D_.regroup_per_table(lengths.to(DEV), indices.to(DEV), B, F, W)     # HIP kernels
+        assert torch.equal(gi.cpu(), ci) and torch.equal(go.cpu(), co), (W, F, B)
