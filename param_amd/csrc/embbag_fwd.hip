@@ -68,10 +68,12 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
     constexpr int VEC = Elem<WT>::kVec;
     constexpr int NG = kBlock / G;  // bags processed concurrently per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_next;  // next unassigned bag of the tile: lane groups pull bags dynamically (ragged bag sizes)
 
     int t, tile;
     block_to_tile(p, t, tile);
     if (t >= p.T) return;
+    if (threadIdx.x == 0) s_next = NG;  // bags 0 .. NG-1 are taken statically; visible after stage_tile's barrier
 
     int nb;
     int64_t* s_off;
@@ -90,7 +92,7 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
     float* out_t = p.io + p.out_offsets[t];
     const bool nt = p.nt_loads != 0;
 
-    for (int bg = gid; bg < nb; bg += NG) {
+    for (int bg = gid; bg < nb;) {
         const int64_t s = s_off[bg];
         const int64_t e = s_off[bg + 1];
         float* orow = out_t + (bag0 + bg) * p.out_stride;
@@ -155,6 +157,11 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
                 __builtin_nontemporal_store(v, o4 + k / 4);
             }
         }
+        // next bag: one LDS atomic per bag, broadcast inside the group.  Which group pools which bag does not
+        // change any result (a bag is pooled by exactly one group, in index order), only the balance.
+        int nxt = 0;
+        if (lig == 0) nxt = atomicAdd(&s_next, 1);
+        bg = __shfl(nxt, 0, G);
     }
 }
 
