@@ -202,10 +202,6 @@ int pm_fill_random(void* dst, int64_t count, int32_t dtype, int32_t dist, float 
  */
 int pm_set_tuning(int32_t unroll, int32_t bags_per_block, int32_t xcd_affine, int32_t nt_loads);
 
-/* Named experiment switches (process-wide).  Unknown names return PM_ERR_INVALID.
- *   "bwd_atomic_scope": 0 = agent-scope atomics (default, always correct),
- *                       1 = workgroup-scope atomics (measurement only). */
-int pm_set_option(const char* name, int32_t value);
 
 #ifdef __cplusplus
 }

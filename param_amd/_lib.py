@@ -34,7 +34,6 @@ EXPORTED_SYMBOLS = (
     "pm_embbag_check",
     "pm_fill_random",
     "pm_set_tuning",
-    "pm_set_option",
 )
 
 
@@ -116,8 +115,6 @@ def load() -> ctypes.CDLL:
         L.pm_fill_random.argtypes = [vp, i64, i32, i32, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, vp]
         L.pm_set_tuning.restype = ctypes.c_int
         L.pm_set_tuning.argtypes = [i32, i32, i32, i32]
-        L.pm_set_option.restype = ctypes.c_int
-        L.pm_set_option.argtypes = [ctypes.c_char_p, i32]
         if L.pm_abi_version() != PM_ABI_VERSION:
             raise ImportError(f"{LIB_PATH}: ABI version {L.pm_abi_version()} != {PM_ABI_VERSION}")
         _lib = L
@@ -131,7 +128,3 @@ def check(rc: int) -> None:
 
 def set_tuning(unroll: int = 0, bags_per_block: int = 0, xcd_affine: int = -1, nt_loads: int = -1) -> None:
     check(load().pm_set_tuning(unroll, bags_per_block, xcd_affine, nt_loads))
-
-
-def set_option(name: str, value: int) -> None:
-    check(load().pm_set_option(name.encode(), int(value)))

@@ -13,7 +13,6 @@ std::atomic<int> g_unroll{0};
 std::atomic<int> g_bags_per_block{0};
 std::atomic<int> g_xcd_affine{-1};
 std::atomic<int> g_nt_loads{-1};
-std::atomic<int> g_bwd_atomic_scope{0};
 
 int fail(int code, const std::string& msg) {
     g_last_error = msg;
@@ -103,7 +102,6 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p) {
     const int nt = g_nt_loads.load();
     p.nt_loads = nt > 0 ? 1 : 0;
     p.alpha = 1.0f;
-    p.bwd_atomic_scope = g_bwd_atomic_scope.load();
     return PM_OK;
 }
 
@@ -128,17 +126,6 @@ int pm_set_tuning(int32_t unroll, int32_t bags_per_block, int32_t xcd_affine, in
     g_xcd_affine.store(xcd_affine);
     g_nt_loads.store(nt_loads);
     return PM_OK;
-}
-
-int pm_set_option(const char* name, int32_t value) {
-    if (!name) return fail(PM_ERR_INVALID, "option name is NULL");
-    const std::string n(name);
-    if (n == "bwd_atomic_scope") {  // 0 = agent scope (always correct); 1 = workgroup scope (experiment)
-        if (value != 0 && value != 1) return fail(PM_ERR_INVALID, "bwd_atomic_scope must be 0 or 1");
-        g_bwd_atomic_scope.store(value);
-        return PM_OK;
-    }
-    return fail(PM_ERR_INVALID, "unknown option '" + n + "'");
 }
 
 int pm_embbag_fwd(const pm_embbag_batch* op, float* out, pm_stream_t stream) {

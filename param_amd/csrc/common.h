@@ -39,7 +39,6 @@ struct KParams {
     int32_t xcd_affine;          // 1: table t is served by XCD t % 8 (requires T % 8 == 0)
     int32_t nt_loads;            // 1: non-temporal table-row loads
     float alpha;                 // bwd scale
-    int32_t bwd_atomic_scope;    // 0 agent, 1 workgroup (experiment; see embbag_bwd.hip)
 };
 
 __device__ __forceinline__ int64_t load_index(const void* p, int64_t i, int idx64) {

@@ -34,12 +34,6 @@ struct DstF32 {
 #pragma unroll
         for (int k = 0; k < 4; ++k) unsafeAtomicAdd(q + k, v[k]);
     }
-    // experiment: workgroup-scope RMW (performed in the issuing XCD's L2, not forwarded to memory)
-    __device__ static __forceinline__ void add_wg(char* row, const float (&v)[4]) {
-        float* q = reinterpret_cast<float*>(row);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) __hip_atomic_fetch_add(q + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
 };
 struct DstBF16 {
     static constexpr int kVec = 8;
@@ -124,12 +118,7 @@ __global__ void __launch_bounds__(kBlock) embbag_bwd_kernel(const KParams p) {
                     for (int k = 0; k < VEC; ++k) gw[k] = sc * g[k];
                     DST::add(Wc + r * row_bytes, gw);
                 } else {
-                    if constexpr (DST::kES == 4) {
-                        if (p.bwd_atomic_scope == 1) DST::add_wg(Wc + r * row_bytes, g);
-                        else DST::add(Wc + r * row_bytes, g);
-                    } else {
-                        DST::add(Wc + r * row_bytes, g);
-                    }
+                    DST::add(Wc + r * row_bytes, g);
                 }
             }
         }

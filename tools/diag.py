@@ -3,14 +3,12 @@
  (a) footprint scaling (tables in play 8..56): TLB / page-walk reach
  (b) sequential rows (streaming) vs random rows
  (c) batch sweep (dataset.py batches) and pooling sweep
- (d) backward: agent- vs workgroup-scope atomics
 Prints JSON lines."""
 import argparse, json, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import param_amd
-from param_amd import _lib
 from param_amd.compute.pt.pytorch_emb import algorithmic_bytes
 from param_amd.embedding_bag import _TableSet, _fwd
 from param_amd.indices import tbe_request
@@ -77,17 +75,3 @@ if "c" not in a.skip:
         run_fwd("pooling_sweep_uniform", Tn, B, Lc, idx, off)
     idx, off = tbe_request([R] * Tn, B, L, 0.0, device=dev, seed=2, index_dtype=torch.int32)
     run_fwd("int32_indices_uniform", Tn, B, L, idx, off)
-if "d" not in a.skip and dt == torch.float32:
-    Tn = min(48, T)
-    ts = _TableSet([m.table(t) for t in range(Tn)], "bd")
-    grad = torch.randn((B, Tn * D), device=dev)
-    bb = Tn * B * L * (2 * D * es + 8) + Tn * B * (D * 4 + 8)
-    from param_amd.embedding_bag import _bwd
-    for alpha in (0.0, 1.05):
-        idx, off = tbe_request([R] * Tn, B, L, alpha, device=dev, seed=2)
-        for scope in (0, 1):
-            _lib.set_option("bwd_atomic_scope", scope)
-            s = timeit(lambda: _bwd(ts, grad, idx, off, B, ts.d_ptrs, dt, -1e-6), 6)
-            emit(test="bwd_atomic_scope", scope=scope, alpha=alpha, ms=s * 1e3, Glookups_s=Tn * B * L / s / 1e9,
-                 alg_GBps=bb / s / 1e9, frac=bb / s / 1e9 / 8000)
-    _lib.set_option("bwd_atomic_scope", 0)
