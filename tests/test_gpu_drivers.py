@@ -216,3 +216,38 @@ def test_dlrm_regroup_hip_kernel(golden_dir):
         ci, co = D_.regroup_per_table(lengths, indices, B, F, W)                      # host form (torch ops)
         gi, go = D_.regroup_per_table(lengths.to(DEV), indices.to(DEV), B, F, W)     # HIP kernels
         assert torch.equal(gi.cpu(), ci) and torch.equal(go.cpu(), co), (W, F, B)
+
+
+def test_compute_python_json_config_runner(tmp_path):
+    """the reference's example configuration for this operator (examples/pytorch/configs/
+    split_table_batched_embeddings_ops.json: 1 table 228582 x 128 fp16, exact_row_wise_adagrad, batch 512, pooling 50)
+    expressed in the same schema, plus a 4-table fp32 SGD build"""
+    from param_amd.compute.python import run_benchmark
+
+    def arg(name, typ, value):
+        return {"type": typ, "name": name, "value": value}
+
+    cfg = {"SplitTableBatchedEmbeddingBagsCodegen": {
+        "build_iterator": "RangeConfigIterator", "input_iterator": "SplitTableBatchedEmbeddingBagsCodegenInputIterator",
+        "config": [
+            {"build": [{"args": [arg("num_tables", "int", 1), arg("rows", "int", 228582), arg("dim", "int", 128),
+                                 arg("pooling", "int", 0), arg("weighted", "bool", False), arg("weights_precision", "str", "fp16")],
+                        "kwargs": {"optimizer": {"type": "str", "value": "exact_row_wise_adagrad"}}}],
+             "input": [{"args": [arg("batch_size", "int", 512), arg("pooling_factor", "int", 50)]}]},
+            {"build": [{"args": [arg("num_tables", "int", 4), arg("rows", "int", 50000), arg("dim", "int", 64),
+                                 arg("pooling", "int", 0), arg("weighted", "bool", True), arg("weights_precision", "str", "fp32")],
+                        "kwargs": {"optimizer": {"type": "str", "value": "sgd"}, "lr": {"type": "float", "value": 0.05}}}],
+             "input": [{"args": [arg("batch_size", "int", 256), arg("pooling_factor", "int", 10)]},
+                       {"args": [arg("batch_size", "int", 1024), arg("pooling_factor", "int", 3)]}]}]}}
+    path = tmp_path / "cfg.json"
+    path.write_text(json.dumps(cfg))
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        res = run_benchmark.main(["-c", str(path), "-d", "cuda", "-b", "--warmup", "2", "--iteration", "3"])
+    assert [r["id"] for r in res] == ["0:0:0", "1:0:0", "1:0:1"]
+    for r in res:
+        assert r["op_name"] == "SplitTableBatchedEmbeddingBagsCodegen"
+        assert len(r["metric"]["forward"]["gpu.time"]) == 3 and len(r["metric"]["backward"]["gpu.time"]) == 3
+        assert all(0 < t < 1000 for t in r["metric"]["forward"]["gpu.time"] + r["metric"]["backward"]["gpu.time"])
+    lines = [json.loads(ln) for ln in buf.getvalue().splitlines() if ln.startswith("{")]
+    assert [ln["id"] for ln in lines] == ["0:0:0", "1:0:0", "1:0:1"] and lines[0]["config"]["build"]["args"][1] == 228582
