@@ -28,11 +28,12 @@ def _values(arg_list):
     return [a["value"] for a in arg_list]
 
 
-def run_op(name: str, op_cfg: dict, device: str, warmup: int, iters: int, backward: bool, out_stream=sys.stdout, alpha=1.0):
+def run_op(name: str, op_cfg: dict, device: str, warmup: int, iters: int, backward: bool, out_stream=None, alpha=1.0):
     if name not in op_map:
         raise KeyError(f"operator {name!r} is not registered (registered: {sorted(op_map)})")
     op = op_map[name]
     op.device = device
+    out_stream = sys.stdout if out_stream is None else out_stream
     results = []
     for ci, cfg in enumerate(op_cfg["config"]):
         for bi, build in enumerate(cfg["build"]):
