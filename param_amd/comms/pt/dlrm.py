@@ -158,6 +158,32 @@ def generate_sparse_batch(rows: Sequence[int], n: int, num_indices_per_lookup: i
     return torch.cat(lens_all), torch.cat(idx_all)
 
 
+def generate_sparse_batch_reference(m_den: int, rows: Sequence[int], n: int, num_indices_per_lookup: int, fixed: bool,
+                                    device, num_targets: int = 1):
+    """The reference's ``--data-generation random`` batch, draw for draw, from NumPy's GLOBAL generator
+    (dlrm_data.py:151-194 + 140-148): one ``rand(1, m_den)`` for the dense row, then per table and per sample
+    [``random(1)`` for the bag size unless fixed,] ``random(size)`` for the ids -> ``unique(round(r * (rows-1)))``,
+    and finally ``rand(n, num_targets)`` for the click targets.  The caller seeds NumPy with the rank before the
+    first batch (the reference overwrites ``--numpy-rand-seed`` with the rank, dlrm.py:629, and re-seeds on access
+    to batch 0).  Host-side and O(T * n) Python: for parity runs and fixtures (tests/golden/dlrm_np2), not for
+    the 26 x 8192 benchmark shape, where ``generate_sparse_batch`` draws the same distribution on the device."""
+    ra = np.random
+    ra.rand(1, m_den)
+    lens, idx = [], []
+    for size in rows:
+        for _ in range(n):
+            if fixed:
+                want = int(num_indices_per_lookup)
+            else:
+                want = int(np.round(max(1.0, ra.random(1)[0] * min(size, num_indices_per_lookup))))
+            group = np.unique(np.round(ra.random(want) * (size - 1)).astype(np.int64))
+            lens.append(group.size)
+            idx.append(group)
+    ra.rand(n, num_targets)
+    return (torch.tensor(lens, dtype=torch.int64, device=device),
+            torch.from_numpy(np.concatenate(idx) if idx else np.zeros(0, np.int64)).to(device))
+
+
 # ------------------------------------------------------------------------------------------------
 class DLRMSparsePath:
     """One rank's sparse-feature path: redistribute inputs, look up, exchange pooled embeddings,
@@ -297,6 +323,9 @@ class commsDLRMBench:
         parser.add_argument("--embed-data-type", type=str, default="float32", choices=["float32", "bfloat16", "float16"])
         parser.add_argument("--learning-rate", type=float, default=0.01)
         parser.add_argument("--print-comms", action="store_true")
+        parser.add_argument("--data-generation", type=str, default="device", choices=["device", "random"],
+                            help="device: vectorised generator on the GPU; random: the reference's NumPy sequence, "
+                                 "seeded with the rank (dlrm.py:629) -- identical batches, host-side")
         parser.add_argument("--use-device-time", action="store_true", default=False)  # reference bug R1: never registered there
         parser.add_argument("--log", type=str, default="ERROR")
         return parser.parse_args(argv)
@@ -347,10 +376,17 @@ class commsDLRMBench:
         gen = torch.Generator(device=dev)
         gen.manual_seed(args.numpy_rand_seed + rank)
         timers = ca.timers
+        m_den = int(args.arch_mlp_bot.split("-")[0])
         for batch in range(args.num_batches):
             timers["iter_start"] = time.monotonic()
-            lengths, indices = generate_sparse_batch(ln_emb, B, args.num_indices_per_lookup,
-                                                     args.num_indices_per_lookup_fixed, dev, gen)
+            if args.data_generation == "random":
+                if batch == 0:
+                    np.random.seed(rank)
+                lengths, indices = generate_sparse_batch_reference(m_den, ln_emb, B, args.num_indices_per_lookup,
+                                                                   args.num_indices_per_lookup_fixed, dev)
+            else:
+                lengths, indices = generate_sparse_batch(ln_emb, B, args.num_indices_per_lookup,
+                                                         args.num_indices_per_lookup_fixed, dev, gen)
             timers["length_calc_end"] = timers["mem_push_idx_end"] = time.monotonic()   # generated on the device
             idx_tbe, off_tbe = path.sparse_data_dist(lengths, indices)
             bf.sync_barrier(ca)
@@ -375,9 +411,8 @@ class commsDLRMBench:
         if args.print_comms:
             folder = os.path.join(os.getcwd(), f"dlrm_np{W}")
             os.makedirs(folder, exist_ok=True)
-            per_iter = len(path.commDetails) // max(1, args.num_batches)
-            with open(os.path.join(folder, f"rank{rank}.json"), "w") as f:
-                json.dump(path.commDetails[:per_iter], f, indent=2)
+            with open(os.path.join(folder, f"rank{rank}.json"), "w") as f:   # every batch, like dlrm.py:1393-1402
+                json.dump(path.commDetails, f)
         bf.shutdown()
         return report
 

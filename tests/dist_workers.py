@@ -186,7 +186,7 @@ def dlrm_driver(rank, world, port, outdir):
         "--master-ip", "127.0.0.1", "--master-port", str(port), "--backend", "gloo", "--device", "cpu",
         "--mini-batch-size", "8", "--num-batches", "4", "--warmup-batches", "1", "--arch-mlp-bot", "16-8",
         "--arch-mlp-top", "8-1", "--arch-sparse-feature-size", "8", "--arch-embedding-size", "100-200-300-400",
-        "--num-indices-per-lookup", "5", "--print-comms"])
+        "--num-indices-per-lookup", "5", "--print-comms", "--data-generation", "random"])
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         rep = bench.run(args, lookup_factory=factory)

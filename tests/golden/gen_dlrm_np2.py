@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/dlrm_np2/rank{0,1}.json: the per-rank ``--print-comms`` records of the REFERENCE's
+``train/comms/pt/dlrm.py`` run here as 2 gloo ranks on CPU (SURVEY Appendix B recipe).  Needs /root/reference;
+run in the build container only -- the fixture (data) is committed, nothing of the reference travels.
+
+The harness below only pre-registers ``--use-device-time`` (reference bug R1: dlrm.py reads the attribute but
+never adds the flag) and then calls the reference's own entry points."""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FLAGS = ["--backend", "gloo", "--device", "cpu", "--mini-batch-size", "8", "--num-batches", "4", "--warmup-batches", "1",
+         "--arch-mlp-bot", "16-8", "--arch-mlp-top", "8-1", "--arch-sparse-feature-size", "8",
+         "--arch-embedding-size", "100-200-300-400", "--num-indices-per-lookup", "5", "--print-comms"]
+HARNESS = '''
+import argparse
+import dlrm
+from param_bench.train.comms.pt import comms_utils
+env = comms_utils.read_comms_env_vars()
+b = dlrm.commsDLRMBench()
+p = argparse.ArgumentParser()
+p.add_argument("--use-device-time", action="store_true", default=False)
+args = b.readArgs(p); b.checkArgs(args); b.initBench(args, env)
+bi = comms_utils.bootstrap_info_holder(args.master_ip, args.master_port, args.num_tpu_cores, env)
+b.runBench(bi, comms_utils.commsDlrmParamsHolder(args, env), args)
+'''
+
+if __name__ == "__main__":
+    work = tempfile.mkdtemp()
+    os.makedirs(os.path.join(work, "pb"))
+    os.symlink("/root/reference", os.path.join(work, "pb", "param_bench"))
+    open(os.path.join(work, "harness.py"), "w").write(HARNESS)
+    port = "29547"
+    env = dict(os.environ, PYTHONPATH=f"{work}/pb:/root/reference/train/comms/pt", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=port, WORLD_SIZE="2", LOCAL_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, os.path.join(work, "harness.py"), "--master-ip", "127.0.0.1",
+                               "--master-port", port] + FLAGS, cwd=work, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for r in (0, 1)]
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    out = os.path.join(HERE, "dlrm_np2")
+    os.makedirs(out, exist_ok=True)
+    for r in (0, 1):
+        shutil.copy(os.path.join(work, "dlrm_np2", f"rank{r}.json"), os.path.join(out, f"rank{r}.json"))
+    print("wrote", out)

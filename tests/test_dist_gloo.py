@@ -55,22 +55,20 @@ def test_dlrm_sparse_path_over_gloo():
     _spawn(W.dlrm_sparse_path)
 
 
-def test_dlrm_driver_over_gloo_print_comms(tmp_path):
-    """Same flags as the survey's reference run: the per-rank --print-comms JSON has
-    the reference's record order and fixed-size entries (dlrm_np2/rank0.json there:
-    lengths a2a 256 B [16,16]/[16,16] int64, indices a2a, pooled a2a 1024 B [128,128]/[128,128] float32, ...)."""
+def test_dlrm_driver_over_gloo_print_comms(tmp_path, golden_dir):
+    """Same flags as the REFERENCE run that produced tests/golden/dlrm_np2 (gen_dlrm_np2.py: the reference's dlrm.py,
+    2 gloo ranks, here): with ``--data-generation random`` (the reference's NumPy draw sequence, seed = rank) every
+    one of the 28 per-rank --print-comms records -- collective order, msg_size, in/out splits incl. the data-dependent
+    index exchange, dtype, over all 4 batches -- equals the reference's, on both ranks."""
     _spawn(W.dlrm_driver, str(tmp_path))
+    for r in (0, 1):
+        mine = json.load(open(tmp_path / "dlrm_np2" / f"rank{r}.json"))
+        gold = json.load(open(os.path.join(golden_dir, "dlrm_np2", f"rank{r}.json")))
+        assert len(gold) == 28 and mine == gold, r
     rec = json.load(open(tmp_path / "dlrm_np2" / "rank0.json"))
-    assert [r["comms"] for r in rec] == ["all_to_all", "all_to_all", "all_to_all", "all_reduce", "all_reduce",
-                                         "all_to_all", "all_reduce"]
-    assert rec[0] == {"comms": "all_to_all", "msg_size": 256, "in_split": [16, 16], "out_split": [16, 16], "dtype": "torch.int64"}
-    assert rec[1]["dtype"] == "torch.int64" and sum(rec[1]["out_split"]) * 8 == rec[1]["msg_size"]
-    assert rec[2] == {"comms": "all_to_all", "msg_size": 1024, "in_split": [128, 128], "out_split": [128, 128], "dtype": "torch.float32"}
-    # top MLP "18-8-1": 5 features -> 10 unique pairs + 8 = 18 inputs; 18x8 fp32 = 576 B (the reference's value)
-    assert rec[3] == {"comms": "all_reduce", "msg_size": 576, "dtype": "torch.float32"}
-    assert rec[4] == {"comms": "all_reduce", "msg_size": 32, "dtype": "torch.float32"}
-    assert rec[5]["in_split"] == [128, 128] and rec[5]["msg_size"] == 1024                      # bwd a2a, splits swapped
-    assert rec[6] == {"comms": "all_reduce", "msg_size": 512, "dtype": "torch.float32"}       # bot MLP 16-8
+    assert [r["comms"] for r in rec[:7]] == ["all_to_all", "all_to_all", "all_to_all", "all_reduce", "all_reduce",
+                                             "all_to_all", "all_reduce"]
+    assert rec[1] == {"comms": "all_to_all", "msg_size": 664, "in_split": [39, 34], "out_split": [39, 44], "dtype": "torch.int64"}
     rep = json.load(open(tmp_path / "report0.json"))
     assert set(n for n in rep["report"] if not n.endswith("_bw")) == {
         "intermed_calc_length", "mem_push_idx", "intermed_bef_offset_xchg", "offset_xchg", "intermed_btw_offset_idx_xchg",
