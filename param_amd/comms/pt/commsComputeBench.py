@@ -45,21 +45,8 @@ class commsComputeBench(commsCollBench):
 
     def init_emb_lookup(self, args):
         """tables + requests of the compute kernel (reference init_emb_lookup, comms_utils.py:1956-2039)"""
-        from ...indices import tbe_request
-
-        ca, bf = self.collectiveArgs, self.backendFuncs
-        batched = args.ntables if args.num_emb_tables_batched in (-1, 0) else args.num_emb_tables_batched
-        if args.ntables % batched:
-            raise ValueError("--ntables must be a multiple of --num-emb-tables-batched")
-        ca.num_emb_ops = args.ntables // batched
-        ca.num_emb_tables_batched = batched
-        ca.emb_dim, ca.batch_size, ca.direction = args.emb_dim, args.batch_size, args.direction
-        ca.emb = [bf.alloc_batched_embedding_tables([args.num_embs] * batched, args.emb_dim, ca.device, torch.float32)
-                  for _ in range(ca.num_emb_ops)]
-        ca.embRequests = [tbe_request([args.num_embs] * batched, args.batch_size, args.bag_size, device=ca.device,
-                                      seed=17 * ca.global_rank + i) + (None,) for i in range(ca.num_emb_ops)]
-        if args.direction == "backward":
-            ca.grad_output = torch.randn(args.batch_size, batched * args.emb_dim, device=ca.device)
+        args.num_emb_tables_per_device = args.ntables
+        comms_utils.init_emb_lookup(self.collectiveArgs, args, self.backendFuncs)
 
     def runColl(self, comm_fn=None, compute_fn=None, dcheck=False):
         ca, bf = self.collectiveArgs, self.backendFuncs

@@ -197,3 +197,119 @@ def equal_splits(numElements: int, world_size: int):
     ``numElements // world_size`` elements; returns (elements actually used, split list)."""
     per = numElements // world_size
     return per * world_size, [per] * world_size
+
+
+# ------------------------------------------------------------------------------------------------
+# trace replay: one recorded operation, collective-name normalisation, embedding-lookup setup
+
+_NAME_ALIASES = {
+    "alltoall": "all_to_all", "alltoallv": "all_to_allv", "alltoallbase": "all_to_allv",
+    "alltoallsingle": "all_to_all_single", "allreduce": "all_reduce", "allgather": "all_gather",
+    "allgatherbase": "all_gather_base", "reducescatter": "reduce_scatter",
+    "reducescatterbase": "reduce_scatter_base", "recvanysource": "recv",
+}
+
+
+def paramToCommName(name: str, supported_comms=None) -> str:
+    """Map the spellings found in traces ("alltoallv", "ALL_TO_ALLV", "AllToAllBase" ...) to the internal
+    collective name (reference ``:446-486``): lower-case, letters only, then the alias table; unknown names
+    pass through unchanged.  With ``supported_comms`` an unknown result is a fatal configuration error."""
+    key = "".join(ch for ch in name.lower() if ch.isalpha())
+    new_name = _NAME_ALIASES.get(key, name)
+    if supported_comms is not None and new_name not in supported_comms:
+        logger.error(f"{name} is not a supported communication in PARAM! Supported comms: {list(supported_comms)}")
+        gracefulExit()
+    return new_name
+
+
+class commsArgs:
+    """One operation of a comms trace: a collective (``comms``) or a compute kernel (``compute``).
+    Same attribute and JSON-key names as the reference's ``commsArgs`` (``:552-713``) for the fields the replay of
+    collectives and of ``emb_lookup`` reads; sizes are in ELEMENTS.  The embedding-lookup fields carry the names
+    the reference's parser and ``init_emb_lookup`` actually use (``emb_dim, num_embs, batch_size,
+    num_emb_tables_per_device, num_emb_tables_batched, bag_size``); the reference's constructor declares
+    camel-case twins it never reads (``embDim`` ..., and ``toEmbLookupTuple`` reads an unset ``bagSize``)."""
+
+    _FIELDS = ("comms", "compute", "id", "req", "inMsgSize", "outMsgSize", "dtype", "inSplit", "outSplit", "startTimeNs",
+               "pgId", "groupRanks", "worldSize", "markerStack", "root", "src_rank", "dst_rank", "count",
+               "emb_dim", "num_embs", "batch_size", "num_emb_tables_per_device", "bag_size")
+
+    def __init__(self, **kwargs) -> None:
+        for f in self._FIELDS:
+            setattr(self, f, kwargs.get(f))
+        self.direction = kwargs.get("direction", "forward")
+        self.num_emb_tables_batched = kwargs.get("num_emb_tables_batched", -1)
+        self.device = kwargs.get("device")
+
+    def toDict(self) -> dict:
+        d = {}
+        if self.comms is not None:
+            d["comms"] = self.comms
+        if self.compute is not None:
+            d["compute"] = self.compute
+            if self.compute == "emb_lookup":
+                for key, val in (("direction", self.direction), ("emb_dim", self.emb_dim), ("num_embs", self.num_embs),
+                                 ("batch_size", self.batch_size), ("num_emb_tables", self.num_emb_tables_per_device),
+                                 ("bag_size", self.bag_size), ("count", self.count)):
+                    if val is not None:
+                        d[key] = val
+        if self.req is not None:
+            d["req"] = self.req
+        if self.inMsgSize is not None:
+            d["in_msg_size"], d["out_msg_size"], d["dtype"] = self.inMsgSize, self.outMsgSize, self.dtype
+        if self.inSplit is not None:
+            d["in_split"] = self.inSplit
+        if self.outSplit is not None:
+            d["out_split"] = self.outSplit
+        if self.startTimeNs is not None:
+            d["startTime_ns"] = self.startTimeNs
+        if self.pgId is not None:
+            d["pg_id"] = self.pgId
+        if self.worldSize is not None:
+            d["world_size"] = self.worldSize
+        if self.root is not None:
+            d["root"] = self.root
+        return d
+
+    def toEmbLookupTuple(self):
+        """key under which ``--reuse-tensors`` caches the tables/requests of an ``emb_lookup`` entry"""
+        return (self.direction, self.emb_dim, self.num_embs, self.batch_size, self.num_emb_tables_per_device, self.bag_size)
+
+    def __eq__(self, other) -> bool:
+        return isinstance(other, commsArgs) and self.__dict__ == other.__dict__
+
+    def __repr__(self) -> str:
+        return str(self.__dict__)
+
+
+def init_emb_lookup(collectiveArgs, commsParams, backendFuncs) -> None:
+    """Tables and requests of the ``emb_lookup`` compute kernel (reference ``:1956-2039``).  ``commsParams``
+    is anything carrying ``direction, emb_dim, num_embs, batch_size, num_emb_tables_per_device,
+    num_emb_tables_batched, bag_size`` -- the CLI namespace of commsComputeBench or a trace entry.
+    ``num_emb_tables_per_device // num_emb_tables_batched`` batched ops (-1: one op holding all tables), each
+    ``num_emb_tables_batched`` tables of ``num_embs x emb_dim`` fp32 rows served by the HIP kernels; one request
+    per op in the fbgemm layout (indices ``[T*B*L]`` table-major, offsets ``[T*B+1]``, uniform ids).  Backward:
+    a forward pass gives ``LookupOut``; ``grad_output = rand_like(LookupOut)``.  Where the reference logs an
+    error and returns when fbgemm is missing, this raises if the HIP library is missing."""
+    import torch
+
+    from ...indices import tbe_request
+
+    ca = collectiveArgs
+    ca.direction = commsParams.direction or "forward"
+    ca.emb_dim, ca.batch_size = commsParams.emb_dim, commsParams.batch_size
+    tables = commsParams.num_emb_tables_per_device
+    batched = getattr(commsParams, "num_emb_tables_batched", -1)
+    batched = tables if batched in (-1, 0, None) else batched
+    if tables % batched:
+        raise ValueError("the number of embedding tables per device must be a multiple of the batched-table count")
+    ca.num_emb_tables_batched = batched
+    ca.num_emb_ops = tables // batched
+    ca.emb = [backendFuncs.alloc_batched_embedding_tables([commsParams.num_embs] * batched, ca.emb_dim, ca.device, torch.float32)
+              for _ in range(ca.num_emb_ops)]
+    ca.embRequests = [tbe_request([commsParams.num_embs] * batched, ca.batch_size, commsParams.bag_size, device=ca.device,
+                                  seed=17 * max(ca.global_rank, 0) + i) + (None,) for i in range(ca.num_emb_ops)]
+    if ca.direction == "backward":
+        for i, (indices, offsets, weights) in enumerate(ca.embRequests):
+            ca.LookupOut = ca.emb[i].forward(indices, offsets, weights)
+        ca.grad_output = torch.rand_like(ca.LookupOut)

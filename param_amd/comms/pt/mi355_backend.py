@@ -125,11 +125,19 @@ class MI355XBackend(backendFunctions):
         return self.all_to_allv(collectiveArgs, retFlag)
 
     def wait(self, collectiveArgs, retFlag=False):
-        """wait on the FIRST outstanding request only (reference complete_single_op)"""
+        """With request ids recorded (trace replay: ``waitObjIds[req] = work``) wait on the request named by
+        ``collectiveArgs.collectiveId``; otherwise on the FIRST outstanding request only (reference
+        ``wait`` / ``complete_single_op``, pytorch_dist_backend.py:724-744)."""
+        if collectiveArgs.waitObjIds:
+            w = collectiveArgs.waitObjIds.get(collectiveArgs.collectiveId)
+            if w is not None:
+                w.wait()
+            return
         if collectiveArgs.waitObj:
             w = collectiveArgs.waitObj.pop(0)
             if w is not None:
                 w.wait()
+            self.device_sync(collectiveArgs)
 
     def complete_accel_ops(self, collectiveArgs, devSync=True):
         for w in collectiveArgs.waitObj:

@@ -240,3 +240,35 @@ def pipeline_layout(rank, world, port):
         pipe.all_to_all_only()
     finally:
         dist.destroy_process_group()
+
+
+def trace_replay(rank, world, port, outdir, golden_dir, blocking):
+    """replay the collective entries of tests/golden/basic_trace.json on 2 gloo ranks.  The recorded index exchange is
+    rank 0's ([39,34] -> [39,44]); rank 1 gets the mirror image so the two ranks' splits agree."""
+    import json
+
+    from param_amd.comms.pt import commsTraceReplay
+
+    _env(rank, world, port)
+    trace = [e for e in json.load(open(os.path.join(golden_dir, "basic_trace.json"))) if "comms" in e]
+    if rank == 1:
+        for e in trace:
+            if e.get("in_split") == [39, 34]:
+                e["in_split"], e["out_split"], e["in_msg_size"], e["out_msg_size"] = [44, 40], [34, 40], 84, 74
+    tdir = os.path.join(outdir, "traces")
+    os.makedirs(tdir, exist_ok=True)
+    json.dump(trace, open(os.path.join(tdir, f"{rank}.json"), "w"))
+    argv = ["--trace-path", tdir, "--backend", "gloo", "--device", "cpu", "--master-ip", "127.0.0.1",
+            "--master-port", str(port), "--num-replays", "2", "--do-warm-up", "--output-path", os.path.join(outdir, "perf"),
+            "--z", "1" if blocking else "0"]
+    if blocking:
+        argv += ["--c", "1", "--reuse-tensors"]
+    import contextlib
+    import io
+
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench = commsTraceReplay.main(argv)
+    with open(os.path.join(outdir, f"summary{rank}.json"), "w") as f:
+        json.dump({"collLat": {k: len(v) for k, v in bench.collLat.items()}, "stdout": buf.getvalue(),
+                   "total_us": bench.totalTraceLatency}, f)

@@ -79,6 +79,27 @@ def test_dlrm_driver_over_gloo_print_comms(tmp_path, golden_dir):
     assert rep["report"]["fwd_a2a_bw"]["busBW_GBps"] == pytest.approx(rep["report"]["fwd_a2a_bw"]["algBW_GBps"] / 2)
 
 
+@pytest.mark.parametrize("blocking", [False, True])
+def test_trace_replay_over_gloo(tmp_path, golden_dir, blocking):
+    """the collective entries of the golden basic trace replayed on 2 ranks: non-blocking (wait entries resolve the
+    recorded request ids) and blocking with the ones-in / expected-out data check"""
+    _spawn(W.trace_replay, str(tmp_path), golden_dir, blocking)
+    for r in (0, 1):
+        rec = json.load(open(tmp_path / "perf" / f"replayedCommsPerf.rank{r}.json"))
+        names = [x["comms"] for x in rec]
+        per_replay = ["all_to_all_single", "wait", "all_to_allv", "wait", "all_to_allv", "wait", "all_reduce", "wait",
+                      "all_reduce", "barrier"]
+        if blocking:                                   # blocking replay skips wait entries (a barrier follows every op)
+            per_replay = [n for n in per_replay if n != "wait"]
+        assert names == per_replay * 2
+        a2av = [x for x in rec if x["comms"] == "all_to_allv"][0]
+        assert a2av["in_split"] == ([39, 34] if r == 0 else [44, 40]) and a2av["dtype_size"] == 8
+        assert all(x["latency_us"] > 0 and x["global_latency_us"] >= x["latency_us"] for x in rec)
+        s = json.load(open(tmp_path / f"summary{r}.json"))
+        assert s["collLat"]["all_to_allv"] == 4 and s["collLat"]["all_reduce"] == 4 and s["total_us"] > 0
+        assert ("Replayed 4 all_to_allv" in s["stdout"]) == (r == 0)     # rank 0 reports
+
+
 def test_dlrm_helpers_match_reference_goldens(golden_dir):
     import torch
 

@@ -201,6 +201,32 @@ def test_comms_compute_overlap_bench_single_gpu():
     assert res[0]["memSize"] == 0 and res[0]["compute_dev_us"] > 0
 
 
+def test_trace_replay_single_gpu(tmp_path):
+    """examples/trace_replay/0.json (one DLRM iteration: a2a's, all_reduce, emb_lookup forward and backward as compute
+    entries) replayed on one GPU through RCCL + the HIP kernels: blocking (kernel time) and non-blocking (wait by request id)"""
+    from param_amd.comms.pt import commsTraceReplay
+
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_SIZE"):
+        os.environ.pop(k, None)
+    tdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "trace_replay")
+    for blocking in ("1", "0"):
+        out = tmp_path / f"z{blocking}"
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            b = commsTraceReplay.main(["--trace-path", tdir, "--device", "rocm", "--master-ip", "127.0.0.1",
+                                       "--master-port", str(_port()), "--num-replays", "3", "--do-warm-up", "--reuse-tensors",
+                                       "--z", blocking, "--output-path", str(out)])
+        assert len(b.compLat["emb_lookup"]) == 6 and min(b.compLat["emb_lookup"]) > 0
+        assert len(b.collLat["all_to_allv"]) == 9 and len(b.collLat["all_reduce"]) == 3
+        assert len(b.embLookupReuse) == 2                       # forward and backward entry shapes cached once
+        rec = json.load(open(out / "replayedCommsPerf.rank0.json"))
+        fwd = [r for r in rec if r.get("compute") == "emb_lookup" and r["direction"] == "forward"]
+        assert len(fwd) == 3 and fwd[0]["num_emb_tables"] == 8 and fwd[0]["latency_us"] > 0
+        assert "Replayed 6 emb_lookup (compute)" in buf.getvalue()
+        if blocking == "1":   # blocking replay times the kernels: 8 x 2048 x 20 lookups well under a millisecond each
+            assert np.median([r["latency_us"] for r in fwd]) < 5000
+
+
 def test_dlrm_regroup_hip_kernel(golden_dir):
     """pm_dlrm_regroup (2 launches, no host sync) == the host regrouping == the reference's splitPerTable golden"""
     from param_amd.comms.pt import dlrm as D_
