@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PM_ABI_VERSION 1
+#define PM_ABI_VERSION 2
 
 typedef void* pm_stream_t;
 
@@ -160,6 +160,32 @@ int pm_embbag_bwd_sorted_adagrad(const pm_embbag_batch* op, const float* grad, v
                                  int32_t table_dtype, float* const* momentum, float lr, float eps,
                                  int64_t max_rows, const void* workspace, int64_t workspace_bytes,
                                  pm_stream_t stream);
+
+/*
+ * The same with the remaining options the reference's TBE operator passes to the optimizer
+ * (train/compute/python/workloads/pytorch/split_table_batched_embeddings_ops.py:289-300: weight_decay,
+ * weight_decay_mode, stochastic_rounding=True; algorithm as published by fbgemm_gpu's rowwise_adagrad):
+ *     L2        : m[r] += (sum_d (G[d] + wd * W[r,d])^2) / D ;  W[r] = (1 - mult * wd) * W[r] - mult * G
+ *     DECOUPLE  : m[r] += (sum_d G[d]^2) / D                 ;  W[r] = (1 - lr * wd)   * W[r] - mult * G
+ * with mult = lr / (sqrt(m[r]) + eps).  stochastic_rounding (bf16 / fp16 tables only): the updated row is
+ * rounded to the table type with probability proportional to the distance to the two neighbours (unbiased:
+ * updates smaller than half an ulp are not lost on average); the random bits are a counter-based function of
+ * (seed, table, row, column) -- pass a different seed every step; results are reproducible for a given seed.
+ */
+enum { PM_WD_NONE = 0, PM_WD_L2 = 1, PM_WD_DECOUPLE = 2 };
+typedef struct pm_rowwise_adagrad {
+    float lr;
+    float eps;
+    float weight_decay;
+    int32_t weight_decay_mode;     /* PM_WD_* */
+    int32_t stochastic_rounding;   /* 0 / 1 */
+    int32_t reserved;
+    uint64_t seed;
+} pm_rowwise_adagrad;
+int pm_embbag_bwd_sorted_adagrad_ex(const pm_embbag_batch* op, const float* grad, void* const* tables,
+                                    int32_t table_dtype, float* const* momentum, const pm_rowwise_adagrad* opt,
+                                    int64_t max_rows, const void* workspace, int64_t workspace_bytes,
+                                    pm_stream_t stream);
 
 /*
  * DLRM input redistribution on the device: regroup what the lengths / indices all-to-alls deliver

@@ -217,12 +217,17 @@ int oracle_embbag_bwd_bf16(uint16_t* dst, float* scratch, int64_t rows, int32_t 
  *     G     = sum over the row's lookups, in lookup order, of psw[j] * grad[bag(j), :]     (fp32)
  *     m[r] += (sum_d G[d]^2) / dim
  *     W[r] -= lr / (sqrtf(m[r]) + eps) * G
+ *   weight decay (the options the reference's operator passes on, split_table_batched_embeddings_ops.py:
+ *   258-300; fbgemm WeightDecayMode NONE 0 / L2 1 / DECOUPLE 2, fbgemm's rowwise_adagrad as published):
+ *     L2       : m[r] += (sum_d (G[d] + wd * W[r,d])^2) / dim ;  W[r] = (1 - mult * wd) * W[r] - mult * G
+ *     DECOUPLE : m[r] += (sum_d G[d]^2) / dim                 ;  W[r] = (1 - lr * wd)   * W[r] - mult * G
  * scratch: rows*dim floats (aggregated gradient), touched: rows bytes.
  */
-int oracle_embbag_bwd_rowwise_adagrad_f32(float* W, float* mom, float* scratch, uint8_t* touched, int64_t rows,
-                                          int32_t dim, const int64_t* idx, int64_t N, const int64_t* off, int64_t B,
-                                          const float* psw, const float* grad, int64_t grad_stride, float lr,
-                                          float eps) {
+int oracle_embbag_bwd_rowwise_adagrad_wd_f32(float* W, float* mom, float* scratch, uint8_t* touched, int64_t rows,
+                                             int32_t dim, const int64_t* idx, int64_t N, const int64_t* off, int64_t B,
+                                             const float* psw, const float* grad, int64_t grad_stride, float lr,
+                                             float eps, float wd, int32_t wd_mode) {
+    if (wd_mode < 0 || wd_mode > 2) return ORACLE_ERR_DTYPE; /* not one of NONE / L2 / DECOUPLE */
     memset(scratch, 0, (size_t)rows * dim * sizeof(float));
     memset(touched, 0, (size_t)rows);
     int rc = oracle_embbag_bwd_f32(scratch, rows, dim, idx, N, off, B, psw, grad, grad_stride, 1.0f);
@@ -231,18 +236,43 @@ int oracle_embbag_bwd_rowwise_adagrad_f32(float* W, float* mom, float* scratch, 
     for (int64_t r = 0; r < rows; ++r) {
         if (!touched[r]) continue;
         const float* G = scratch + r * (int64_t)dim;
+        float* w = W + r * (int64_t)dim;
         double ss = 0.0;  /* fp64 sum of squares: the GPU reduces it in a tree; compared at 1e-6 relative */
-        for (int32_t d = 0; d < dim; ++d) ss += (double)G[d] * (double)G[d];
+        for (int32_t d = 0; d < dim; ++d) {
+            float gx = G[d];
+            if (wd_mode == 1) {
+                volatile float reg = wd * w[d];
+                gx = gx + reg;
+            }
+            ss += (double)gx * (double)gx;
+        }
         const float m = mom[r] + (float)(ss / (double)dim);
         mom[r] = m;
         const float mult = lr / (sqrtf(m) + eps);
-        float* w = W + r * (int64_t)dim;
-        for (int32_t d = 0; d < dim; ++d) {
-            volatile float step = mult * G[d];
-            w[d] = w[d] - step;
+        if (wd_mode == 0) {
+            for (int32_t d = 0; d < dim; ++d) {
+                volatile float step = mult * G[d];
+                w[d] = w[d] - step;
+            }
+        } else {
+            volatile float shrink = wd_mode == 1 ? mult * wd : lr * wd;
+            const float corr = 1.0f - shrink;
+            for (int32_t d = 0; d < dim; ++d) {
+                volatile float kept = corr * w[d];
+                volatile float step = mult * G[d];
+                w[d] = kept - step;
+            }
         }
     }
     return ORACLE_OK;
+}
+
+int oracle_embbag_bwd_rowwise_adagrad_f32(float* W, float* mom, float* scratch, uint8_t* touched, int64_t rows,
+                                          int32_t dim, const int64_t* idx, int64_t N, const int64_t* off, int64_t B,
+                                          const float* psw, const float* grad, int64_t grad_stride, float lr,
+                                          float eps) {
+    return oracle_embbag_bwd_rowwise_adagrad_wd_f32(W, mom, scratch, touched, rows, dim, idx, N, off, B, psw, grad,
+                                                    grad_stride, lr, eps, 0.0f, 0);
 }
 
 /* widen helpers exported for the tests */

@@ -154,6 +154,10 @@ class COracle:
         L.oracle_embbag_bwd_bf16.restype = ctypes.c_int
         L.oracle_embbag_bwd_bf16.argtypes = [ctypes.POINTER(ctypes.c_uint16), f32p, i64, i32, i64p, i64,
                                              i64p, i64, f32p, f32p, i64, ctypes.c_float]
+        L.oracle_embbag_bwd_rowwise_adagrad_wd_f32.restype = ctypes.c_int
+        L.oracle_embbag_bwd_rowwise_adagrad_wd_f32.argtypes = [f32p, f32p, f32p, ctypes.POINTER(ctypes.c_uint8), i64, i32,
+                                                               i64p, i64, i64p, i64, f32p, f32p, i64, ctypes.c_float,
+                                                               ctypes.c_float, ctypes.c_float, i32]
         L.oracle_embbag_bwd_rowwise_adagrad_f32.restype = ctypes.c_int
         L.oracle_embbag_bwd_rowwise_adagrad_f32.argtypes = [f32p, f32p, f32p, ctypes.POINTER(ctypes.c_uint8), i64, i32,
                                                             i64p, i64, i64p, i64, f32p, f32p, i64, ctypes.c_float,
@@ -236,7 +240,7 @@ class COracle:
         return dst
 
     def bwd_rowwise_adagrad(self, W: np.ndarray, mom: np.ndarray, idx, off, grad: np.ndarray, psw=None, lr=0.01,
-                            eps=1e-8):
+                            eps=1e-8, weight_decay=0.0, weight_decay_mode=0):
         """in place on W (fp32 [R,D]) and mom (fp32 [R]); PARITY UNPINNED (fbgemm absent), see the C header."""
         assert W.dtype == np.float32 and W.flags.c_contiguous and mom.dtype == np.float32 and mom.shape == (W.shape[0],)
         idx = np.ascontiguousarray(idx, dtype=np.int64)
@@ -245,11 +249,11 @@ class COracle:
         psw = None if psw is None else np.ascontiguousarray(psw, dtype=np.float32)
         scratch = np.empty_like(W)
         touched = np.empty(W.shape[0], dtype=np.uint8)
-        rc = self.L.oracle_embbag_bwd_rowwise_adagrad_f32(
+        rc = self.L.oracle_embbag_bwd_rowwise_adagrad_wd_f32(
             _ptr(W, ctypes.c_float), _ptr(mom, ctypes.c_float), _ptr(scratch, ctypes.c_float),
             _ptr(touched, ctypes.c_uint8), W.shape[0], W.shape[1], _ptr(idx, ctypes.c_int64), len(idx),
             _ptr(off, ctypes.c_int64), len(off), _ptr(psw, ctypes.c_float), _ptr(grad, ctypes.c_float), grad.shape[1],
-            float(lr), float(eps))
+            float(lr), float(eps), float(weight_decay), int(weight_decay_mode))
         self._check(rc)
         return W, mom
 

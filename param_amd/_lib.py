@@ -13,7 +13,8 @@ import threading
 
 PM_F32, PM_BF16, PM_F16, PM_I32, PM_I64 = 0, 1, 2, 10, 11
 PM_OK, PM_ERR_INVALID, PM_ERR_UNSUPPORTED, PM_ERR_HIP, PM_ERR_INDEX = 0, -1, -2, -3, -4
-PM_ABI_VERSION = 1
+PM_ABI_VERSION = 2
+PM_WD_NONE, PM_WD_L2, PM_WD_DECOUPLE = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libparam_amd.so")
@@ -30,11 +31,26 @@ EXPORTED_SYMBOLS = (
     "pm_embbag_sort_indices",
     "pm_embbag_bwd_sorted",
     "pm_embbag_bwd_sorted_adagrad",
+    "pm_embbag_bwd_sorted_adagrad_ex",
     "pm_dlrm_regroup",
     "pm_embbag_check",
     "pm_fill_random",
     "pm_set_tuning",
 )
+
+
+class pm_rowwise_adagrad(ctypes.Structure):
+    """Mirror of ``struct pm_rowwise_adagrad`` (include/param_amd.h)."""
+
+    _fields_ = [
+        ("lr", ctypes.c_float),
+        ("eps", ctypes.c_float),
+        ("weight_decay", ctypes.c_float),
+        ("weight_decay_mode", ctypes.c_int32),
+        ("stochastic_rounding", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("seed", ctypes.c_uint64),
+    ]
 
 
 class pm_embbag_batch(ctypes.Structure):
@@ -107,6 +123,9 @@ def load() -> ctypes.CDLL:
         L.pm_embbag_bwd_sorted_adagrad.restype = ctypes.c_int
         L.pm_embbag_bwd_sorted_adagrad.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, vp, ctypes.c_float,
                                                    ctypes.c_float, i64, vp, i64, vp]
+        L.pm_embbag_bwd_sorted_adagrad_ex.restype = ctypes.c_int
+        L.pm_embbag_bwd_sorted_adagrad_ex.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, vp,
+                                                      ctypes.POINTER(pm_rowwise_adagrad), i64, vp, i64, vp]
         L.pm_dlrm_regroup.restype = ctypes.c_int
         L.pm_dlrm_regroup.argtypes = [vp, vp, i32, i32, i64, vp, vp, vp, vp]
         L.pm_embbag_check.restype = ctypes.c_int

@@ -13,7 +13,8 @@ on across tables, ``T*B+1`` entries) and the generator's alpha switch (0: ``aran
 Stated differences: pooling must be SUM (PoolingMode 0, the only mode on the reference hot path); the
 optimizer fused into ``backward`` is plain SGD (``"sgd"``/``"exact_sgd"``) or exact row-wise Adagrad
 (``"exact_row_wise_adagrad"``, the reference's choice at comms_utils.py:2014) -- other optimizer names raise;
-weight decay and stochastic rounding are not implemented; ``device`` must be a ROCm device.
+weight decay (L2 / decoupled) and stochastic rounding of 16-bit tables apply to the row-wise Adagrad update (plain SGD
+updates round to nearest); ``device`` must be a ROCm device.
 """
 from __future__ import annotations
 
@@ -62,6 +63,17 @@ def generate_batched_request(num_tables: int, rows, batch_size: int, pooling_fac
     return (torch.cat(idx).to(dev), torch.cat(off).to(dev), torch.cat(wts).to(dev) if weighted else None)
 
 
+def _wd_mode(mode):
+    """fbgemm ``WeightDecayMode`` given as enum member, int (0 NONE, 1 L2, 2 DECOUPLE) or name"""
+    if mode is None:
+        return None
+    if hasattr(mode, "value"):
+        mode = mode.value
+    if isinstance(mode, str):
+        mode = mode.lower().rsplit(".", 1)[-1]
+    return mode
+
+
 class SplitTableBatchedEmbeddingBagsCodegenOp(OperatorInterface):
     def __init__(self):
         super().__init__()
@@ -92,7 +104,9 @@ class SplitTableBatchedEmbeddingBagsCodegenOp(OperatorInterface):
         self.weighted = weighted
         self.op = BatchedEmbeddingBagMI355(rows_list, dims_list, dtype=_PRECISION[str(weights_precision).lower()],
                                            device=dev, init="uniform_dlrm", learning_rate=lr, fused_update=True,
-                                           optimizer=opt, eps=eps)
+                                           optimizer=opt, eps=eps, weight_decay=weight_decay,
+                                           weight_decay_mode=_wd_mode(weight_decay_mode),
+                                           stochastic_rounding=True)   # the reference's fixed choice (:291)
 
     def cleanup(self):
         self.op = None

@@ -209,19 +209,22 @@ int pm_embbag_bwd_sorted(const pm_embbag_batch* op, const float* grad, void* con
     p.io = const_cast<float*>(grad);
     p.tables = const_cast<const void* const*>(dst_tables);
     p.alpha = alpha;
-    h = pm::bwd_sorted_apply(p, max_rows, dst_dtype, op->max_dim, workspace, nullptr, 0.0f, 0.0f,
+    h = pm::bwd_sorted_apply(p, max_rows, dst_dtype, op->max_dim, workspace, nullptr, nullptr,
                              static_cast<hipStream_t>(stream));
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_bwd_sorted launch");
     return PM_OK;
 }
 
-int pm_embbag_bwd_sorted_adagrad(const pm_embbag_batch* op, const float* grad, void* const* tables, int32_t table_dtype,
-                                 float* const* momentum, float lr, float eps, int64_t max_rows, const void* workspace,
-                                 int64_t workspace_bytes, pm_stream_t stream) {
+int pm_embbag_bwd_sorted_adagrad_ex(const pm_embbag_batch* op, const float* grad, void* const* tables, int32_t table_dtype,
+                                    float* const* momentum, const pm_rowwise_adagrad* opt, int64_t max_rows,
+                                    const void* workspace, int64_t workspace_bytes, pm_stream_t stream) {
     pm::KParams p;
     int rc = make_params(op, table_dtype, p);
     if (rc != PM_OK) return rc;
     if ((rc = sorted_args_ok(op, max_rows)) != PM_OK) return rc;
+    if (!opt) return fail(PM_ERR_INVALID, "optimizer options are NULL");
+    if (opt->weight_decay_mode != PM_WD_NONE && opt->weight_decay_mode != PM_WD_L2 && opt->weight_decay_mode != PM_WD_DECOUPLE)
+        return fail(PM_ERR_INVALID, "weight_decay_mode must be PM_WD_NONE, PM_WD_L2 or PM_WD_DECOUPLE");
     if (p.N == 0 || p.bag_count == 0) return PM_OK;
     if (!grad || !tables || !momentum) return fail(PM_ERR_INVALID, "grad / tables / momentum is NULL");
     const int vec = (table_dtype == PM_F32) ? 4 : 8;
@@ -235,10 +238,17 @@ int pm_embbag_bwd_sorted_adagrad(const pm_embbag_batch* op, const float* grad, v
     p.io = const_cast<float*>(grad);
     p.tables = const_cast<const void* const*>(tables);
     p.alpha = 1.0f;
-    h = pm::bwd_sorted_apply(p, max_rows, table_dtype, op->max_dim, workspace, momentum, lr, eps,
-                             static_cast<hipStream_t>(stream));
+    h = pm::bwd_sorted_apply(p, max_rows, table_dtype, op->max_dim, workspace, momentum, opt, static_cast<hipStream_t>(stream));
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_bwd_sorted_adagrad launch");
     return PM_OK;
+}
+
+int pm_embbag_bwd_sorted_adagrad(const pm_embbag_batch* op, const float* grad, void* const* tables, int32_t table_dtype,
+                                 float* const* momentum, float lr, float eps, int64_t max_rows, const void* workspace,
+                                 int64_t workspace_bytes, pm_stream_t stream) {
+    pm_rowwise_adagrad opt = {lr, eps, 0.0f, PM_WD_NONE, 0, 0, 0};
+    return pm_embbag_bwd_sorted_adagrad_ex(op, grad, tables, table_dtype, momentum, &opt, max_rows, workspace,
+                                           workspace_bytes, stream);
 }
 
 int pm_dlrm_regroup(const int64_t* lengths, const int64_t* indices, int32_t world_size, int32_t num_tables,

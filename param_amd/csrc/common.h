@@ -117,7 +117,7 @@ hipError_t launch_fill_random(void* dst, int64_t count, int dtype, int dist, flo
 hipError_t sorted_workspace_bytes(const KParams& p, int64_t max_rows, int max_dim, size_t& bytes);
 hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, void* workspace, hipStream_t stream);
 hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, int max_dim, const void* workspace,
-                            float* const* momentum, float lr, float eps, hipStream_t stream);
+                            float* const* momentum, const pm_rowwise_adagrad* opt, hipStream_t stream);
 
 // DLRM input redistribution (dlrm_regroup.hip)
 hipError_t launch_dlrm_regroup(const int64_t* lengths, const int64_t* indices, int W, int F, int64_t B,

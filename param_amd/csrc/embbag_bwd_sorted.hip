@@ -56,6 +56,10 @@ struct SortedParams {
     float* const* mom;       // row-wise Adagrad: device array [T] of per-row fp32 state (else NULL)
     float lr;
     float eps;
+    float wd;                // weight decay (row-wise Adagrad)
+    int32_t wd_mode;         // PM_WD_NONE / PM_WD_L2 / PM_WD_DECOUPLE
+    int32_t sr;              // 1: stochastic rounding of the updated row (16-bit tables)
+    uint64_t sr_seed;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -111,8 +115,20 @@ __device__ __forceinline__ void raw16_store(char* p, const u32x4 v, bool nt) {
     if (nt) __builtin_nontemporal_store(v, q); else *q = v;
 }
 
+// counter-based random bits for stochastic rounding: one 64-bit splitmix output per (seed, row key, column pair)
+__device__ __forceinline__ uint32_t sr_bits(uint64_t seed, uint64_t rowkey, int col_pair) {
+    uint64_t x = seed ^ (rowkey * 0x9E3779B97F4A7C15ull) ^ (static_cast<uint64_t>(col_pair) * 0xD1B54A32D192ED03ull);
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return static_cast<uint32_t>((x ^ (x >> 31)) >> 32);
+}
+
 struct SDstF32 {
     static constexpr int kVec = 4, kES = 4;
+    __device__ static __forceinline__ void store_sr(char* p, const float (&a)[4], bool nt, uint64_t, uint64_t, int) {
+        store(p, a, nt);   // fp32 tables: nothing to round
+    }
     __device__ static __forceinline__ void load(const char* p, float (&a)[4], bool nt = false) {
         const u32x4 v = raw16_load(p, nt);
         a[0] = __uint_as_float(v.x); a[1] = __uint_as_float(v.y); a[2] = __uint_as_float(v.z); a[3] = __uint_as_float(v.w);
@@ -126,8 +142,24 @@ __device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
     if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
+// fp32 -> bf16, stochastic: add 16 uniform random bits below the kept mantissa, truncate.  P(round up) equals the
+// discarded fraction, so the expectation is the fp32 value; Inf/NaN pass through the nearest-even path.
+__device__ __forceinline__ uint32_t f32_to_bf16_sr(float f, uint32_t r16) {
+    const uint32_t u = __float_as_uint(f);
+    if ((u & 0x7f800000u) == 0x7f800000u) return f32_to_bf16_rne(f);
+    return (u + (r16 & 0xffffu)) >> 16;
+}
 struct SDstBF16 {
     static constexpr int kVec = 8, kES = 2;
+    __device__ static __forceinline__ void store_sr(char* p, const float (&a)[8], bool nt, uint64_t seed, uint64_t rowkey, int c) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t r = sr_bits(seed, rowkey, (c >> 1) + i);
+            w[i] = f32_to_bf16_sr(a[2 * i], r) | (f32_to_bf16_sr(a[2 * i + 1], r >> 16) << 16);
+        }
+        raw16_store(p, u32x4{w[0], w[1], w[2], w[3]}, nt);
+    }
     __device__ static __forceinline__ void load(const char* p, float (&a)[8], bool nt = false) {
         const u32x4 v = raw16_load(p, nt);
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -141,8 +173,24 @@ struct SDstBF16 {
         raw16_store(p, u32x4{w[0], w[1], w[2], w[3]}, nt);
     }
 };
+// fp32 -> fp16, stochastic: 13 random bits below the 10 kept mantissa bits, then a truncating conversion
+// (the low 13 bits are cleared, so the cast is exact in fp16's normal range; same scheme as fbgemm's)
+__device__ __forceinline__ uint32_t f32_to_f16_sr(float f, uint32_t r13) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7f800000u) != 0x7f800000u) u = (u + (r13 & 0x1fffu)) & 0xffffe000u;
+    return static_cast<uint32_t>(__builtin_bit_cast(uint16_t, static_cast<_Float16>(__uint_as_float(u))));
+}
 struct SDstF16 {
     static constexpr int kVec = 8, kES = 2;
+    __device__ static __forceinline__ void store_sr(char* p, const float (&a)[8], bool nt, uint64_t seed, uint64_t rowkey, int c) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t r = sr_bits(seed, rowkey, (c >> 1) + i);
+            w[i] = f32_to_f16_sr(a[2 * i], r) | (f32_to_f16_sr(a[2 * i + 1], r >> 16) << 16);
+        }
+        raw16_store(p, u32x4{w[0], w[1], w[2], w[3]}, nt);
+    }
     __device__ static __forceinline__ void load(const char* p, float (&a)[8], bool nt = false) {
         const u32x4 v = raw16_load(p, nt);
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -331,7 +379,7 @@ hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, void* w
 }
 
 hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, int max_dim, const void* workspace,
-                            float* const* momentum, float lr, float eps, hipStream_t stream) {
+                            float* const* momentum, const pm_rowwise_adagrad* opt, hipStream_t stream) {
     const SortedGeom g = sorted_geom(p, max_rows);
     SortWs ws;
     hipError_t rc = ws_layout(const_cast<void*>(workspace), p.N, g.key_bytes, g.kbits + 1, g.weighted, max_dim, ws);
@@ -357,8 +405,12 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
     sp.nt_rows = p.nt_loads;
     sp.alpha = p.alpha;
     sp.mom = momentum;
-    sp.lr = lr;
-    sp.eps = eps;
+    sp.lr = opt ? opt->lr : 0.0f;
+    sp.eps = opt ? opt->eps : 0.0f;
+    sp.wd = opt ? opt->weight_decay : 0.0f;
+    sp.wd_mode = opt ? opt->weight_decay_mode : PM_WD_NONE;
+    sp.sr = (opt && opt->stochastic_rounding && dst_dtype != PM_F32) ? 1 : 0;
+    sp.sr_seed = opt ? opt->seed : 0;
     if (sp.n == 0) return hipSuccess;
     return g.key_bytes == 4 ? launch_apply_k<uint32_t>(sp, dst_dtype, max_dim, stream)
                             : launch_apply_k<uint64_t>(sp, dst_dtype, max_dim, stream);

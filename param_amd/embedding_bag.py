@@ -203,9 +203,16 @@ def check_request(ts: _TableSet, indices, offsets, B, psw=None) -> None:
         raise IndexError(f"param_amd: {n} out-of-range indices / invalid offsets in EmbeddingBag request")
 
 
+_WD_MODES = {None: _lib.PM_WD_NONE, "none": _lib.PM_WD_NONE, 0: _lib.PM_WD_NONE, "l2": _lib.PM_WD_L2, 1: _lib.PM_WD_L2,
+             "decouple": _lib.PM_WD_DECOUPLE, "decoupled": _lib.PM_WD_DECOUPLE, 2: _lib.PM_WD_DECOUPLE}
+
+
 def _adagrad(ts: _TableSet, grad, indices, offsets, B, mom_ptrs_dev, lr: float, eps: float, psw=None,
-             presorted: bool = False):
-    """Fused backward + exact row-wise Adagrad on the tables of ``ts`` (``pm_embbag_bwd_sorted_adagrad``)."""
+             presorted: bool = False, weight_decay: float = 0.0, weight_decay_mode=None, stochastic_rounding: bool = False,
+             seed: int = 0):
+    """Fused backward + exact row-wise Adagrad on the tables of ``ts`` (``pm_embbag_bwd_sorted_adagrad_ex``)."""
+    if weight_decay_mode not in _WD_MODES:
+        raise ValueError(f"weight_decay_mode must be one of none / l2 / decouple, got {weight_decay_mode!r}")
     _require_device(grad, "grad")
     _, _, shape = ts.out_desc(B)
     if grad.dtype != torch.float32 or tuple(grad.shape) != tuple(shape):
@@ -216,9 +223,11 @@ def _adagrad(ts: _TableSet, grad, indices, offsets, B, mom_ptrs_dev, lr: float, 
     ws = _workspace(ts, op)
     if not presorted:
         _lib.check(L.pm_embbag_sort_indices(ctypes.byref(op), max(ts.rows), ws.data_ptr(), ws.numel(), _stream_ptr()))
-    _lib.check(L.pm_embbag_bwd_sorted_adagrad(ctypes.byref(op), grad.data_ptr(), ts.d_ptrs.data_ptr(), _WDTYPE[ts.dtype],
-                                              mom_ptrs_dev.data_ptr(), float(lr), float(eps), max(ts.rows),
-                                              ws.data_ptr(), ws.numel(), _stream_ptr()))
+    opt = _lib.pm_rowwise_adagrad(float(lr), float(eps), float(weight_decay), _WD_MODES[weight_decay_mode],
+                                  1 if stochastic_rounding else 0, 0, int(seed) & (2**64 - 1))
+    _lib.check(L.pm_embbag_bwd_sorted_adagrad_ex(ctypes.byref(op), grad.data_ptr(), ts.d_ptrs.data_ptr(), _WDTYPE[ts.dtype],
+                                                 mom_ptrs_dev.data_ptr(), ctypes.byref(opt), max(ts.rows),
+                                                 ws.data_ptr(), ws.numel(), _stream_ptr()))
 
 
 class _DenseGradFn(torch.autograd.Function):
@@ -314,7 +323,8 @@ class BatchedEmbeddingBagMI355(nn.Module):
 
     def __init__(self, rows: Sequence[int], dims, dtype: torch.dtype = torch.float32, device="cuda",
                  layout: str = "bd", init: Optional[str] = "uniform_dlrm", seed: int = 0,
-                 learning_rate: float = 0.01, fused_update: bool = True, optimizer: str = "sgd", eps: float = 1.0e-8):
+                 learning_rate: float = 0.01, fused_update: bool = True, optimizer: str = "sgd", eps: float = 1.0e-8,
+                 weight_decay: float = 0.0, weight_decay_mode=None, stochastic_rounding: bool = False):
         super().__init__()
         rows = [int(r) for r in rows]
         dims = [int(dims)] * len(rows) if isinstance(dims, int) else [int(d) for d in dims]
@@ -324,6 +334,12 @@ class BatchedEmbeddingBagMI355(nn.Module):
         if optimizer not in ("sgd", "rowwise_adagrad"):
             raise ValueError('optimizer must be "sgd" or "rowwise_adagrad"')
         self.optimizer, self.eps = optimizer, eps
+        if weight_decay_mode not in _WD_MODES:
+            raise ValueError(f"weight_decay_mode must be one of none / l2 / decouple, got {weight_decay_mode!r}")
+        # row-wise Adagrad options of the reference's TBE operator (split_table_batched_embeddings_ops.py:289-300)
+        self.weight_decay, self.weight_decay_mode = weight_decay, weight_decay_mode
+        self.stochastic_rounding = stochastic_rounding      # 16-bit tables only; fp32 tables ignore it
+        self._sr_step = 0
         self.momentum: Optional[torch.Tensor] = None      # row-wise Adagrad state: one fp32 per row
         self._mom_ptrs: Optional[torch.Tensor] = None
         sizes = [r * d for r, d in zip(rows, dims)]
@@ -413,11 +429,15 @@ class BatchedEmbeddingBagMI355(nn.Module):
     def adagrad_step_(self, grad, indices, offsets, per_sample_weights=None, batch: Optional[int] = None,
                       presorted: bool = False):
         """Fused backward + exact row-wise Adagrad (TBE ``EXACT_ROWWISE_ADAGRAD``, the optimizer the reference
-        configures at comms_utils.py:2014): ``m[r] += mean_d(G[r,d]^2); W[r] -= lr / (sqrt(m[r]) + eps) * G[r]``."""
+        configures at comms_utils.py:2014): ``m[r] += mean_d(G[r,d]^2); W[r] -= lr / (sqrt(m[r]) + eps) * G[r]``,
+        with the module's ``weight_decay`` / ``weight_decay_mode`` (l2 | decouple) and, for 16-bit tables,
+        ``stochastic_rounding``."""
         self.momentum_table(0)
         B = self._batch_of(offsets) if batch is None else batch
+        self._sr_step += 1          # a fresh stochastic-rounding stream every step, reproducible run to run
         _adagrad(self._tables(), grad, indices, offsets, B, self._mom_ptrs, self.learning_rate, self.eps,
-                 per_sample_weights, presorted)
+                 per_sample_weights, presorted, self.weight_decay, self.weight_decay_mode, self.stochastic_rounding,
+                 seed=0x5EED0000 + self._sr_step)
 
     def optimizer_step_(self, grad, indices, offsets, per_sample_weights=None, batch: Optional[int] = None,
                         presorted: bool = False):

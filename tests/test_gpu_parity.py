@@ -558,3 +558,79 @@ def test_fused_rowwise_adagrad_vs_oracle(coracle):
         out = mod(idx, off)                 # autograd path: backward == fused Adagrad step
         out.backward(g)
     assert torch.equal(ma.table(0), mb.table(0)) and torch.equal(ma.momentum, mb.momentum) and float(ma.momentum.sum()) > 0
+
+
+@pytest.mark.parametrize("mode,code", [("l2", 1), ("decouple", 2)])
+def test_rowwise_adagrad_weight_decay_vs_oracle(coracle, mode, code):
+    """weight decay modes of the fused row-wise Adagrad (the options the reference's TBE operator forwards,
+    split_table_batched_embeddings_ops.py:258-300) vs the oracle's restatement of fbgemm's rule -- parity UNPINNED
+    (fbgemm absent); the oracle is itself checked against an fp64 form.  Two steps, duplicates, a hot row."""
+    from param_amd import BatchedEmbeddingBagMI355
+
+    rng = np.random.default_rng(31)
+    rows, D, B, L, lr, eps, wd = [3000, 900], 64, 200, 8, 0.05, 1e-6, 0.02
+    m = BatchedEmbeddingBagMI355(rows, D, device=DEV, init="normal", seed=5, learning_rate=lr, optimizer="rowwise_adagrad",
+                                 eps=eps, weight_decay=wd, weight_decay_mode=mode)
+    W = [m.table(t).cpu().numpy().copy() for t in range(2)]
+    mom = [np.zeros(r, np.float32) for r in rows]
+    for step in range(2):
+        idx = np.concatenate([rng.integers(0, r, B * L) for r in rows]).astype(np.int64)
+        idx[:300] = 7                                         # > 256 lookups of one row: chunk-partial path
+        off = np.arange(2 * B + 1, dtype=np.int64) * L
+        grad = rng.standard_normal((B, 2 * D)).astype(np.float32)
+        m.adagrad_step_(torch.from_numpy(grad).to(DEV), torch.from_numpy(idx).to(DEV), torch.from_numpy(off).to(DEV))
+        for t in range(2):
+            s, e = t * B * L, (t + 1) * B * L
+            g = np.ascontiguousarray(grad[:, t * D:(t + 1) * D])
+            W0, m0 = W[t].astype(np.float64), mom[t].astype(np.float64)
+            coracle.bwd_rowwise_adagrad(W[t], mom[t], idx[s:e], np.arange(B) * L, g, None, lr=lr, eps=eps,
+                                        weight_decay=wd, weight_decay_mode=code)
+            G = np.zeros(W0.shape)
+            np.add.at(G, idx[s:e], g.astype(np.float64)[np.repeat(np.arange(B), L)])
+            touched = np.bincount(idx[s:e], minlength=rows[t]) > 0
+            gx = G + wd * W0 if code == 1 else G
+            m64 = m0 + (gx ** 2).mean(1)
+            mult = lr / (np.sqrt(m64) + eps)
+            corr = np.ones(rows[t]) - (mult * wd if code == 1 else lr * wd)
+            W64 = corr[:, None] * W0 - mult[:, None] * G
+            assert np.allclose(mom[t][touched], m64[touched], rtol=2e-5) and np.allclose(W[t][touched], W64[touched], rtol=1e-4, atol=2e-5)
+            assert np.array_equal(W[t][~touched], W0[~touched].astype(np.float32))          # untouched rows do not decay
+            assert np.allclose(m.momentum_table(t).cpu().numpy(), mom[t], rtol=2e-5, atol=1e-12), (step, t)
+            assert np.allclose(m.table(t).cpu().numpy(), W[t], rtol=2e-5, atol=2e-6), (step, t)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_rowwise_adagrad_stochastic_rounding(dtype):
+    """16-bit tables, stochastic_rounding=True (the reference operator's fixed choice, :291): every stored element is
+    one of the two table-type neighbours of the exact fp32 update, the MEAN over many rows that receive the same update
+    equals it (round-to-nearest would be off by a fixed bias), and the run is reproducible for a given step."""
+    from param_amd import BatchedEmbeddingBagMI355
+
+    R, D, lr = 8192, 64, 0.01
+
+    def run(sr):
+        m = BatchedEmbeddingBagMI355([R], D, dtype=dtype, device=DEV, init=None, learning_rate=lr, optimizer="rowwise_adagrad",
+                                     eps=1e-8, stochastic_rounding=sr)
+        m.table(0).fill_(1.0)
+        idx = torch.arange(R, device=DEV)                      # every row looked up once, same gradient
+        off = torch.arange(R + 1, device=DEV)
+        g = torch.full((R, D), 0.37, device=DEV)
+        m.adagrad_step_(g, idx, off)
+        return m.table(0).clone()
+
+    # exact fp32 update of every element: m = 0.37^2, mult = lr / 0.37 -> w = 1 - lr (up to fp32 rounding)
+    g32 = np.float32(0.37)
+    mom = np.float32(g32 * g32 * D) / np.float32(D)
+    exact = float(np.float32(1.0) - np.float32(np.float32(lr) / (np.sqrt(mom, dtype=np.float32) + np.float32(1e-8))) * g32)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11     # spacing just below 1.0
+    lo_f = np.floor(exact / ulp) * ulp
+    hi_f = lo_f + ulp
+    w = run(True).float().cpu().numpy()
+    assert set(np.unique(w)) <= {np.float32(lo_f), np.float32(hi_f)} and len(np.unique(w)) == 2
+    p_up = (exact - lo_f) / ulp
+    n = w.size
+    assert abs(w.mean() - exact) < 5 * ulp * np.sqrt(p_up * (1 - p_up) / n) + 1e-7
+    assert abs((w == np.float32(hi_f)).mean() - p_up) < 0.01
+    rne = run(False).float().cpu().numpy()
+    assert len(np.unique(rne)) == 1 and abs(rne.mean() - exact) > 0.2 * min(p_up, 1 - p_up) * ulp   # nearest: a fixed bias
+    assert np.array_equal(run(True).float().cpu().numpy(), w)                                      # reproducible

@@ -128,3 +128,27 @@ def test_error_behaviour(coracle):
         coracle.fwd(W, np.array([0, 1, 2]), np.array([2, 1]))
     with pytest.raises(IndexError):
         O.embbag_fwd_np(W, np.array([9]), np.array([0]))
+
+
+def test_oracle_rowwise_adagrad_weight_decay_modes(coracle):
+    """the oracle's weight-decay rules (fbgemm rowwise_adagrad as published; parity unpinned) against an fp64 form"""
+    rng = np.random.default_rng(4)
+    R, D, B, L, lr, eps, wd = 50, 16, 12, 4, 0.1, 1e-6, 0.05
+    idx = rng.integers(0, R, B * L).astype(np.int64)
+    off = np.arange(B, dtype=np.int64) * L
+    g = rng.standard_normal((B, D)).astype(np.float32)
+    for mode in (0, 1, 2):
+        W = rng.standard_normal((R, D)).astype(np.float32)
+        mom = rng.uniform(0, 1, R).astype(np.float32)
+        W0, m0 = W.astype(np.float64), mom.astype(np.float64)
+        coracle.bwd_rowwise_adagrad(W, mom, idx, off, g, None, lr=lr, eps=eps, weight_decay=wd, weight_decay_mode=mode)
+        G = np.zeros((R, D))
+        np.add.at(G, idx, g.astype(np.float64)[np.repeat(np.arange(B), L)])
+        touched = np.bincount(idx, minlength=R) > 0
+        gx = G + wd * W0 if mode == 1 else G
+        m64 = m0 + (gx ** 2).mean(1)
+        mult = lr / (np.sqrt(m64) + eps)
+        corr = np.ones(R) - (mult * wd if mode == 1 else lr * wd if mode == 2 else 0.0)
+        W64 = corr[:, None] * W0 - mult[:, None] * G
+        assert np.allclose(W[touched], W64[touched], rtol=1e-5, atol=1e-6) and np.allclose(mom[touched], m64[touched], rtol=1e-6)
+        assert np.array_equal(W[~touched], W0[~touched].astype(np.float32)) and np.array_equal(mom[~touched], m0[~touched].astype(np.float32))
