@@ -1,15 +1,26 @@
 """JSON-config operator microbenchmark -- the slice of reference ``train/compute/python/pytorch/run_benchmark.py``
-(``:24-365``) + ``lib/pytorch/build_executor.py`` / ``op_executor.py`` needed to run the batched EmbeddingBag
-operator from the reference's config files (schema of ``examples/pytorch/configs/
-split_table_batched_embeddings_ops.json``: op name -> ``config: [{build: [{args, kwargs}], input: [{args}]}]``).
+(``:24-365``) + ``lib/pytorch/build_executor.py`` / ``op_executor.py`` / ``lib/iterator.py`` needed to run the batched
+EmbeddingBag operator from the reference's config files (schema of ``examples/pytorch/configs/
+split_table_batched_embeddings_ops.json``: op name -> ``build_iterator``, ``input_iterator``, ``config: [{build: [{args,
+kwargs}], input: [{args}]}]``).
 
-    python -m param_amd.compute.python.run_benchmark -c my_config.json -d cuda -b --warmup 5 --iteration 20
+    python -m param_amd.compute.python.run_benchmark -c my_config.json -d cuda -b --warmup 5 --iteration 20 \
+        [--exec-mode discrete|continuous|continuous_events] [--cuda-l2-cache on|off] [-o prefix]
 
-Per (op, build, input) combination one JSON line ``{"op_name", "id", "metric": {"forward": {"gpu.time": [...ms]},
-"backward": {...}}, "config"}`` (reference ``output_stats``, ``build_executor.py:511-541``).  Timing = the
-reference's ``Timer``: host clock around the call closed by a device synchronize (``lib/pytorch/timer.py:19-27``).
-Stated limits: plain ``value`` entries (no ``__range__`` / ``__list__`` macros), no L2-flush option (the
-reference's flush table has no gfx950 entry and raises KeyError there), operators registered in this package only.
+Per (op, build, input) combination one JSON line ``{"op_name", "id": "<config>|<build id>|<input id>", "metric": {"forward":
+{"gpu.time": [...ms], "gpu.memory": [...MB]}, "backward": {...}}, "config": {"build", "input"}}`` (reference
+``output_stats``, ``build_executor.py:511-541``).  Kept from the reference:
+
+* ``"build_iterator": "RangeConfigIterator"`` expands ``__range__`` arguments of the build configs (config_iter.py,
+  pinned to the reference's iterator); the operator's input iterator expands ``__range__`` / ``__list__`` on
+  ``[batch_size, pooling_factor]``;
+* execution modes (``op_executor.py:157-477``): ``discrete`` -- every call timed on the host clock closed by a device
+  synchronize (``timer.py:19-27``), optionally with the caches flushed before each call; ``continuous`` -- one clock
+  around all iterations, backward = (forward + backward loop) - forward; ``continuous_events`` -- one start/stop
+  device-event pair per call, no host synchronisation inside the loop;
+* ``--cuda-l2-cache off``: the reference flushes by writing a buffer the size of the L2 and has no entry for gfx950
+  (``op_executor.py:16-28`` raises KeyError there); here the flush writes 2 x (8 x 4 MiB L2 + 256 MiB MALL).
+Not kept: CUDA-graph capture (``--cuda-graph``), the NSight / CUPTI / kineto launchers, resume/stop run ids.
 """
 from __future__ import annotations
 
@@ -21,55 +32,152 @@ import time
 import torch
 
 from . import op_map
+from .config_iter import BUILD_ITERATORS, tbe_input_iterator
 from .split_table_batched_embeddings_ops import generate_batched_request
 
+_FLUSH_BYTES = 2 * (8 * 4 * 1024 * 1024 + 256 * 1024 * 1024)   # MI355X: 8 XCD L2s + the memory-side cache, twice over
+_flush_bufs = {}
 
-def _values(arg_list):
-    return [a["value"] for a in arg_list]
+
+def _clear_cache(device) -> None:
+    buf = _flush_bufs.get(str(device))
+    if buf is None:
+        buf = _flush_bufs[str(device)] = torch.empty(_FLUSH_BYTES // 4, dtype=torch.float32, device=device)
+    buf.fill_(2.0)
 
 
-def run_op(name: str, op_cfg: dict, device: str, warmup: int, iters: int, backward: bool, out_stream=None, alpha=1.0):
+def _arg_values(arg_list):
+    def val(a):
+        v = a["value"]
+        if a.get("type") in ("genericlist", "tuple"):
+            return [val(x) if isinstance(x, dict) else x for x in v]
+        return v
+    return [val(a) for a in arg_list]
+
+
+class OpExecutor:
+    """runs one built operator on one request under one execution mode; returns the reference's metric dict"""
+
+    def __init__(self, op, device: str, warmup: int, iteration: int, backward: bool, exec_mode: str, l2_cache: bool):
+        self.op, self.device = op, device
+        self.warmup, self.iteration, self.backward = warmup, iteration, backward
+        self.exec_mode, self.l2_cache = exec_mode, l2_cache
+
+    def _timed(self, fn):
+        if not self.l2_cache:
+            _clear_cache(self.device)
+        torch.cuda.reset_peak_memory_stats(self.device)
+        torch.cuda.synchronize(self.device)
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize(self.device)
+        return (time.perf_counter() - t0) * 1e3, torch.cuda.max_memory_allocated(self.device) / 1048576
+
+    def _discrete(self, count, data):
+        fw_t, fw_m, bw_t, bw_m = [], [], [], []
+        for _ in range(count):
+            t, m = self._timed(lambda: self.op.forward(*data))
+            fw_t.append(t)
+            fw_m.append(m)
+            if self.backward:
+                self.op.create_grad()
+                t, m = self._timed(self.op.backward)
+                bw_t.append(t)
+                bw_m.append(m)
+        return fw_t, fw_m, bw_t, bw_m
+
+    def _continuous(self, count, data):
+        dev = self.device
+        torch.cuda.reset_peak_memory_stats(dev)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(count):
+            self.op.forward(*data)
+        torch.cuda.synchronize(dev)
+        fw = (time.perf_counter() - t0) * 1e3 / count
+        fw_m, bw_t, bw_m = [torch.cuda.max_memory_allocated(dev) / 1048576], [], []
+        if self.backward:
+            self.op.create_grad()
+            torch.cuda.reset_peak_memory_stats(dev)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(count):
+                self.op.forward(*data)
+                self.op.backward()
+            torch.cuda.synchronize(dev)
+            bw_t = [(time.perf_counter() - t0) * 1e3 / count - fw]      # forward time subtracted (op_executor.py:405)
+            bw_m = [torch.cuda.max_memory_allocated(dev) / 1048576]
+        return [fw], fw_m, bw_t, bw_m
+
+    def _continuous_events(self, count, data):
+        dev = self.device
+
+        def pairs():
+            return [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(count)]
+
+        ev = pairs()
+        torch.cuda.reset_peak_memory_stats(dev)
+        torch.cuda.synchronize(dev)
+        for a, b in ev:
+            a.record()
+            self.op.forward(*data)
+            b.record()
+        torch.cuda.synchronize(dev)
+        fw_t, fw_m, bw_t, bw_m = [a.elapsed_time(b) for a, b in ev], [torch.cuda.max_memory_allocated(dev) / 1048576], [], []
+        if self.backward:
+            self.op.create_grad()
+            ev = pairs()
+            torch.cuda.reset_peak_memory_stats(dev)
+            torch.cuda.synchronize(dev)
+            for a, b in ev:
+                self.op.forward(*data)
+                a.record()
+                self.op.backward()
+                b.record()
+            torch.cuda.synchronize(dev)
+            bw_t, bw_m = [a.elapsed_time(b) for a, b in ev], [torch.cuda.max_memory_allocated(dev) / 1048576]
+        return fw_t, fw_m, bw_t, bw_m
+
+    def run(self, data):
+        bench = {"discrete": self._discrete, "continuous": self._continuous, "continuous_events": self._continuous_events}[self.exec_mode]
+        if self.warmup:
+            bench(self.warmup, data)
+        fw_t, fw_m, bw_t, bw_m = bench(self.iteration, data) if self.iteration else ([], [], [], [])
+        metrics = {"forward": {"gpu.time": fw_t, "gpu.memory": fw_m}}
+        if self.backward:
+            metrics["backward"] = {"gpu.time": bw_t, "gpu.memory": bw_m}
+        return metrics
+
+
+def run_op(name: str, op_cfg: dict, device: str, warmup: int, iters: int, backward: bool, out_stream=None, alpha=1.0,
+           exec_mode: str = "discrete", l2_cache: bool = True):
     if name not in op_map:
         raise KeyError(f"operator {name!r} is not registered (registered: {sorted(op_map)})")
+    build_iter = op_cfg.get("build_iterator")
+    if build_iter not in BUILD_ITERATORS:
+        raise KeyError(f"build_iterator {build_iter!r} is not one of {[k for k in BUILD_ITERATORS if k]}")
     op = op_map[name]
     op.device = device
+    dev = "cuda" if device.startswith(("cuda", "rocm")) else device
     out_stream = sys.stdout if out_stream is None else out_stream
     results = []
     for ci, cfg in enumerate(op_cfg["config"]):
-        for bi, build in enumerate(cfg["build"]):
-            bargs = _values(build["args"])
-            bkw = {k: v["value"] for k, v in build.get("kwargs", {}).items()}
-            op.cleanup()
-            kw = dict(bkw)
-            if len(bargs) < 7:
-                kw.setdefault("optimizer", "exact_row_wise_adagrad")  # the reference's choice (comms_utils.py:2014)
-            op.build(*bargs, **kw)
+        for build_id, build in BUILD_ITERATORS[build_iter](cfg["build"]):
+            bargs = _arg_values(build.get("args", []))
+            bkw = {k: v["value"] for k, v in (build.get("kwargs") or {}).items()}
             num_tables, rows, _dim, _pool, weighted = bargs[0], bargs[1], bargs[2], bargs[3], bargs[4]
-            for ii, inp in enumerate(cfg["input"]):
-                batch_size, pooling_factor = _values(inp["args"])[:2]
+            for input_id, (batch_size, pooling_factor) in tbe_input_iterator(cfg["input"]):
+                op.cleanup()
+                kw = dict(bkw)
+                if len(bargs) < 7:
+                    kw.setdefault("optimizer", "exact_row_wise_adagrad")  # the reference's choice (comms_utils.py:2014)
+                op.build(*bargs, **kw)
                 data = generate_batched_request(num_tables, rows, batch_size, pooling_factor, alpha=alpha,
-                                                weighted=weighted, device="cuda" if device.startswith(("cuda", "rocm")) else device)
-                metrics = {"forward": {"gpu.time": []}}
-                if backward:
-                    metrics["backward"] = {"gpu.time": []}
-                for it in range(warmup + iters):
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    op.forward(*data)
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    if it >= warmup:
-                        metrics["forward"]["gpu.time"].append((t1 - t0) * 1e3)
-                    if backward:
-                        op.create_grad()
-                        torch.cuda.synchronize()
-                        t0 = time.perf_counter()
-                        op.backward()
-                        torch.cuda.synchronize()
-                        t1 = time.perf_counter()
-                        if it >= warmup:
-                            metrics["backward"]["gpu.time"].append((t1 - t0) * 1e3)
-                stats = {"op_name": name, "id": f"{ci}:{bi}:{ii}", "metric": metrics,
+                                                weighted=weighted, device=dev)
+                metrics = OpExecutor(op, dev, warmup, iters, backward, exec_mode, l2_cache).run(data)
+                # reference run id: "<config>|<build id>|<input id>" (benchmark.py:79,101 + build_executor.py:466; the
+                # reference appends every further build id of a config to the previous one -- not reproduced)
+                stats = {"op_name": name, "id": f"{ci}|{build_id}|{input_id}", "metric": metrics,
                          "config": {"build": {"args": bargs, "kwargs": bkw}, "input": {"args": [batch_size, pooling_factor]}}}
                 out_stream.write(json.dumps(stats) + "\n")
                 out_stream.flush()
@@ -85,12 +193,22 @@ def main(argv=None):
     ap.add_argument("-w", "--warmup", type=int, default=1)
     ap.add_argument("-i", "--iteration", type=int, default=1)
     ap.add_argument("-b", "--backward", action="store_true")
+    ap.add_argument("-o", "--output-prefix", type=str, default=None, help="write <prefix>.json instead of stdout")
+    ap.add_argument("--exec-mode", type=str, default="discrete", choices=["discrete", "continuous", "continuous_events"])
+    ap.add_argument("--cuda-l2-cache", type=str, default="on", choices=["on", "off"],
+                    help="off: flush the L2s and the memory-side cache before every timed call (discrete mode)")
     ap.add_argument("--alpha", type=float, default=1.0, help="generate_requests distribution switch (reference :93-135)")
     a = ap.parse_args(argv)
     cfg = json.load(open(a.config))
+    stream = open(a.output_prefix + ".json", "w") if a.output_prefix else None
     out = []
-    for name, op_cfg in cfg.items():
-        out += run_op(name, op_cfg, a.device, a.warmup, a.iteration, a.backward, alpha=a.alpha)
+    try:
+        for name, op_cfg in cfg.items():
+            out += run_op(name, op_cfg, a.device, a.warmup, a.iteration, a.backward, out_stream=stream, alpha=a.alpha,
+                          exec_mode=a.exec_mode, l2_cache=a.cuda_l2_cache == "on")
+    finally:
+        if stream:
+            stream.close()
     return out
 
 

@@ -270,10 +270,35 @@ def test_compute_python_json_config_runner(tmp_path):
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         res = run_benchmark.main(["-c", str(path), "-d", "cuda", "-b", "--warmup", "2", "--iteration", "3"])
-    assert [r["id"] for r in res] == ["0:0:0", "1:0:0", "1:0:1"]
+    assert [r["id"] for r in res] == ["0|0_0|0_0", "1|0_0|0_0", "1|0_0|0_0"]   # the operator's input iterator restarts per input
     for r in res:
         assert r["op_name"] == "SplitTableBatchedEmbeddingBagsCodegen"
         assert len(r["metric"]["forward"]["gpu.time"]) == 3 and len(r["metric"]["backward"]["gpu.time"]) == 3
         assert all(0 < t < 1000 for t in r["metric"]["forward"]["gpu.time"] + r["metric"]["backward"]["gpu.time"])
     lines = [json.loads(ln) for ln in buf.getvalue().splitlines() if ln.startswith("{")]
-    assert [ln["id"] for ln in lines] == ["0:0:0", "1:0:0", "1:0:1"] and lines[0]["config"]["build"]["args"][1] == 228582
+    assert [ln["id"] for ln in lines] == [r["id"] for r in res] and lines[0]["config"]["build"]["args"][1] == 228582
+    assert all(len(r["metric"]["forward"]["gpu.memory"]) == 3 for r in res)
+
+    # ranged build + ranged / listed inputs, the two other execution modes, cache flush between calls
+    rng = {"SplitTableBatchedEmbeddingBagsCodegen": {
+        "build_iterator": "RangeConfigIterator", "input_iterator": "SplitTableBatchedEmbeddingBagsCodegenInputIterator",
+        "config": [{"build": [{"args": [arg("num_tables", "int", 2), arg("rows", "int", 20000),
+                                        dict(arg("dim", "int", [64, 128, 64]), __range__=["value"]), arg("pooling", "int", 0),
+                                        arg("weighted", "bool", False),
+                                        dict(arg("weights_precision", "str", ["fp16", "fp32"]), __range__=["value"])]}],
+                    "input": [{"args": [dict(arg("batch_size", "int", [128, 256, 128]), __range__=["value"]),
+                                        dict(arg("pooling_factor", "int", [5, 20]), __list__=["value"])]}]}]}}
+    path.write_text(json.dumps(rng))
+    with contextlib.redirect_stdout(io.StringIO()):
+        ev = run_benchmark.main(["-c", str(path), "-d", "cuda", "-b", "-w", "1", "-i", "4", "--exec-mode", "continuous_events"])
+        co = run_benchmark.main(["-c", str(path), "-d", "cuda", "-b", "-w", "1", "-i", "4", "--exec-mode", "continuous",
+                                 "-o", str(tmp_path / "res")])
+        fl = run_benchmark.main(["-c", str(path), "-d", "cuda", "-w", "1", "-i", "2", "--cuda-l2-cache", "off"])
+    assert [r["id"] for r in ev] == [f"0|0_{b}|0_{i}" for b in range(4) for i in range(4)]
+    assert [r["config"]["build"]["args"][2] for r in ev][::4] == [64, 64, 128, 128]
+    assert [r["config"]["build"]["args"][5] for r in ev][::4] == ["fp16", "fp32", "fp16", "fp32"]
+    assert [r["config"]["input"]["args"] for r in ev][:4] == [[128, 5], [128, 20], [256, 5], [256, 20]]
+    assert all(len(r["metric"]["backward"]["gpu.time"]) == 4 and min(r["metric"]["backward"]["gpu.time"]) > 0 for r in ev)
+    assert all(len(r["metric"]["forward"]["gpu.time"]) == 1 and len(r["metric"]["backward"]["gpu.time"]) == 1 for r in co)
+    assert len((tmp_path / "res.json").read_text().splitlines()) == 16
+    assert len(fl) == 16 and "backward" not in fl[0]["metric"] and len(fl[0]["metric"]["forward"]["gpu.time"]) == 2

@@ -154,3 +154,35 @@ def test_generate_requests_layout():
     assert int(i.max()) < 1000 and (i < 10).float().mean() > 0.3            # zipf % E: mass on small ids
     idx, off, wts = generate_batched_request(3, [10, 20, 30], 4, [2, 3, 1], alpha=1.0, device="cpu")
     assert off.tolist() == [0, 2, 4, 6, 8, 11, 14, 17, 20, 21, 22, 23, 24] and idx.numel() == 24 and wts is None
+
+
+def test_range_config_iterator_matches_reference(golden_dir):
+    """``__range__`` expansion of build configs vs tests/golden/range_configs.json (the reference's RangeConfigIterator,
+    generated by tests/golden/gen_range_configs.py); the operator's input iterator (not importable without fbgemm) restated"""
+    import json
+    import os
+
+    from param_amd.compute.python.config_iter import default_config_iterator, full_range, range_config_iterator, tbe_input_iterator
+
+    def val(a):
+        return [val(x) for x in a["value"]] if a.get("type") in ("genericlist", "tuple") else a["value"]
+
+    def values(c):
+        return {"args": [val(a) for a in c.get("args", [])], "kwargs": {k: val(a) for k, a in c.get("kwargs", {}).items()}}
+
+    gold = json.load(open(os.path.join(golden_dir, "range_configs.json")))
+    assert set(gold) == {"scalars", "two_variants", "genericlist", "no_ranges"}
+    for name, case in gold.items():
+        mine = [[i, values(c)] for i, c in range_config_iterator(case["variants"])]
+        assert mine == case["range_iterator"], name
+        for _, c in range_config_iterator(case["variants"]):
+            assert not any("__range__" in a for a in c["args"])
+    assert [[i, values(c)] for i, c in default_config_iterator(gold["no_ranges"]["variants"])] == gold["no_ranges"]["default_iterator"]
+    # the reference's own generator tests (test/test_generator.py:13-31)
+    assert list(full_range(-3, 2, 1)) == [-3, -2, -1, 0, 1, 2] and list(full_range(5, 11, 2)) == [5, 7, 9, 11]
+    assert list(full_range(3, 11, 3)) == [3, 6, 9]
+    inputs = [{"args": [{"type": "int", "value": [512, 1024, 512], "__range__": ["value"]},
+                        {"type": "int", "value": [20, 50], "__list__": ["value"]}]},
+              {"args": [{"type": "int", "value": 64}, {"type": "int", "value": 7}]}]
+    assert list(tbe_input_iterator(inputs)) == [("0_0", [512, 20]), ("0_1", [512, 50]), ("0_2", [1024, 20]),
+                                                ("0_3", [1024, 50]), ("0_0", [64, 7])]
