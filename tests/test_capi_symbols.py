@@ -56,3 +56,10 @@ def test_argument_validation_without_gpu():
     # empty request: nothing to launch, succeeds without a device
     op.batch = op.bag_begin = op.bag_count = 0
     assert L.pm_embbag_fwd(ctypes.byref(op), None, None) == _lib.PM_OK
+
+
+def test_graft_entry_build_runs():
+    """the driver's build check: compiles (a no-op when up to date), loads the library, checks the ABI version"""
+    import __graft_entry__ as g
+
+    g.build()
