@@ -20,7 +20,8 @@ Per (op, build, input) combination one JSON line ``{"op_name", "id": "<config>|<
   device-event pair per call, no host synchronisation inside the loop;
 * ``--cuda-l2-cache off``: the reference flushes by writing a buffer the size of the L2 and has no entry for gfx950
   (``op_executor.py:16-28`` raises KeyError there); here the flush writes 2 x (8 x 4 MiB L2 + 256 MiB MALL).
-Not kept: CUDA-graph capture (``--cuda-graph``), the NSight / CUPTI / kineto launchers, resume/stop run ids.
+* ``--cuda-graph``: forward and backward captured once in HIP graphs and replayed (``op_executor.py:82-97``).
+Not kept: the NSight / CUPTI / kineto launchers, resume/stop run ids.
 """
 from __future__ import annotations
 
@@ -58,10 +59,43 @@ def _arg_values(arg_list):
 class OpExecutor:
     """runs one built operator on one request under one execution mode; returns the reference's metric dict"""
 
-    def __init__(self, op, device: str, warmup: int, iteration: int, backward: bool, exec_mode: str, l2_cache: bool):
+    def __init__(self, op, device: str, warmup: int, iteration: int, backward: bool, exec_mode: str, l2_cache: bool,
+                 use_graph: bool = False):
         self.op, self.device = op, device
         self.warmup, self.iteration, self.backward = warmup, iteration, backward
-        self.exec_mode, self.l2_cache = exec_mode, l2_cache
+        self.exec_mode, self.l2_cache, self.use_graph = exec_mode, l2_cache, use_graph
+        self._fwd = self._bwd = None
+
+    def _bind(self, data) -> None:
+        """the two callables the timing loops launch: eager calls, or replays of HIP graphs captured once
+        (``--cuda-graph``, reference ``op_executor.py:82-97``; the kernels go through the C ABI on the capturing stream,
+        rocPRIM's sort included; the stochastic-rounding seed of a captured Adagrad step is frozen)"""
+        if not self.use_graph:
+            self._fwd = lambda: self.op.forward(*data)
+
+            def bwd():
+                self.op.create_grad()
+                self.op.backward()
+            self._bwd = bwd
+            return
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):              # warm up off the default stream, as graph capture requires
+            self.op.forward(*data)
+            if self.backward:
+                self.op.create_grad()
+                self.op.backward()
+        torch.cuda.current_stream().wait_stream(side)
+        fg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(fg):
+            self.op.forward(*data)
+        self._fwd = fg.replay
+        if self.backward:
+            self.op.create_grad()
+            bg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(bg):
+                self.op.backward()
+            self._bwd = bg.replay
 
     def _timed(self, fn):
         if not self.l2_cache:
@@ -76,12 +110,11 @@ class OpExecutor:
     def _discrete(self, count, data):
         fw_t, fw_m, bw_t, bw_m = [], [], [], []
         for _ in range(count):
-            t, m = self._timed(lambda: self.op.forward(*data))
+            t, m = self._timed(self._fwd)
             fw_t.append(t)
             fw_m.append(m)
             if self.backward:
-                self.op.create_grad()
-                t, m = self._timed(self.op.backward)
+                t, m = self._timed(self._bwd)
                 bw_t.append(t)
                 bw_m.append(m)
         return fw_t, fw_m, bw_t, bw_m
@@ -92,18 +125,17 @@ class OpExecutor:
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(count):
-            self.op.forward(*data)
+            self._fwd()
         torch.cuda.synchronize(dev)
         fw = (time.perf_counter() - t0) * 1e3 / count
         fw_m, bw_t, bw_m = [torch.cuda.max_memory_allocated(dev) / 1048576], [], []
         if self.backward:
-            self.op.create_grad()
             torch.cuda.reset_peak_memory_stats(dev)
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             for _ in range(count):
-                self.op.forward(*data)
-                self.op.backward()
+                self._fwd()
+                self._bwd()
             torch.cuda.synchronize(dev)
             bw_t = [(time.perf_counter() - t0) * 1e3 / count - fw]      # forward time subtracted (op_executor.py:405)
             bw_m = [torch.cuda.max_memory_allocated(dev) / 1048576]
@@ -120,19 +152,18 @@ class OpExecutor:
         torch.cuda.synchronize(dev)
         for a, b in ev:
             a.record()
-            self.op.forward(*data)
+            self._fwd()
             b.record()
         torch.cuda.synchronize(dev)
         fw_t, fw_m, bw_t, bw_m = [a.elapsed_time(b) for a, b in ev], [torch.cuda.max_memory_allocated(dev) / 1048576], [], []
         if self.backward:
-            self.op.create_grad()
             ev = pairs()
             torch.cuda.reset_peak_memory_stats(dev)
             torch.cuda.synchronize(dev)
             for a, b in ev:
-                self.op.forward(*data)
+                self._fwd()
                 a.record()
-                self.op.backward()
+                self._bwd()
                 b.record()
             torch.cuda.synchronize(dev)
             bw_t, bw_m = [a.elapsed_time(b) for a, b in ev], [torch.cuda.max_memory_allocated(dev) / 1048576]
@@ -140,6 +171,7 @@ class OpExecutor:
 
     def run(self, data):
         bench = {"discrete": self._discrete, "continuous": self._continuous, "continuous_events": self._continuous_events}[self.exec_mode]
+        self._bind(data)
         if self.warmup:
             bench(self.warmup, data)
         fw_t, fw_m, bw_t, bw_m = bench(self.iteration, data) if self.iteration else ([], [], [], [])
@@ -150,7 +182,7 @@ class OpExecutor:
 
 
 def run_op(name: str, op_cfg: dict, device: str, warmup: int, iters: int, backward: bool, out_stream=None, alpha=1.0,
-           exec_mode: str = "discrete", l2_cache: bool = True):
+           exec_mode: str = "discrete", l2_cache: bool = True, use_graph: bool = False):
     if name not in op_map:
         raise KeyError(f"operator {name!r} is not registered (registered: {sorted(op_map)})")
     build_iter = op_cfg.get("build_iterator")
@@ -174,7 +206,7 @@ def run_op(name: str, op_cfg: dict, device: str, warmup: int, iters: int, backwa
                 op.build(*bargs, **kw)
                 data = generate_batched_request(num_tables, rows, batch_size, pooling_factor, alpha=alpha,
                                                 weighted=weighted, device=dev)
-                metrics = OpExecutor(op, dev, warmup, iters, backward, exec_mode, l2_cache).run(data)
+                metrics = OpExecutor(op, dev, warmup, iters, backward, exec_mode, l2_cache, use_graph).run(data)
                 # reference run id: "<config>|<build id>|<input id>" (benchmark.py:79,101 + build_executor.py:466; the
                 # reference appends every further build id of a config to the previous one -- not reproduced)
                 stats = {"op_name": name, "id": f"{ci}|{build_id}|{input_id}", "metric": metrics,
@@ -197,6 +229,7 @@ def main(argv=None):
     ap.add_argument("--exec-mode", type=str, default="discrete", choices=["discrete", "continuous", "continuous_events"])
     ap.add_argument("--cuda-l2-cache", type=str, default="on", choices=["on", "off"],
                     help="off: flush the L2s and the memory-side cache before every timed call (discrete mode)")
+    ap.add_argument("--cuda-graph", action="store_true", help="capture forward / backward in HIP graphs once and replay them")
     ap.add_argument("--alpha", type=float, default=1.0, help="generate_requests distribution switch (reference :93-135)")
     a = ap.parse_args(argv)
     cfg = json.load(open(a.config))
@@ -205,7 +238,7 @@ def main(argv=None):
     try:
         for name, op_cfg in cfg.items():
             out += run_op(name, op_cfg, a.device, a.warmup, a.iteration, a.backward, out_stream=stream, alpha=a.alpha,
-                          exec_mode=a.exec_mode, l2_cache=a.cuda_l2_cache == "on")
+                          exec_mode=a.exec_mode, l2_cache=a.cuda_l2_cache == "on", use_graph=a.cuda_graph)
     finally:
         if stream:
             stream.close()

@@ -294,6 +294,8 @@ def test_compute_python_json_config_runner(tmp_path):
         co = run_benchmark.main(["-c", str(path), "-d", "cuda", "-b", "-w", "1", "-i", "4", "--exec-mode", "continuous",
                                  "-o", str(tmp_path / "res")])
         fl = run_benchmark.main(["-c", str(path), "-d", "cuda", "-w", "1", "-i", "2", "--cuda-l2-cache", "off"])
+        gr = run_benchmark.main(["-c", str(path), "-d", "cuda", "-b", "-w", "1", "-i", "3", "--cuda-graph", "--exec-mode", "continuous_events"])
+    assert len(gr) == 16 and all(min(r["metric"]["forward"]["gpu.time"] + r["metric"]["backward"]["gpu.time"]) > 0 for r in gr)
     assert [r["id"] for r in ev] == [f"0|0_{b}|0_{i}" for b in range(4) for i in range(4)]
     assert [r["config"]["build"]["args"][2] for r in ev][::4] == [64, 64, 128, 128]
     assert [r["config"]["build"]["args"][5] for r in ev][::4] == ["fp16", "fp32", "fp16", "fp32"]
