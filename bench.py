@@ -342,6 +342,16 @@ def main():
             "apply_only_GBps": bwd_bytes / ba / 1e9, "apply_only_frac": bwd_bytes / ba / 1e9 / HBM_PEAK_GBPS,
             "bytes_per_lookup": bwd_bytes / lookups_step_rank,
             "atomic_kernel_s": bt, "atomic_kernel_frac": bwd_bytes / bt / 1e9 / HBM_PEAK_GBPS}
+        # the optimizer the reference configures for its TBE ops (EXACT_ROWWISE_ADAGRAD): same kernels, fused epilogue,
+        # + 4 B of state read-modify-write per touched row
+        try:
+            model.learning_rate = 1e-6
+            _, ag = time_steps(lambda: model.adagrad_step_(grad, idx, off, batch=B_glob, presorted=True), n_b, 2, barrier)
+            result["bwd_rowwise_adagrad"] = {"avg_s_apply_only": ag, "apply_only_GBps": bwd_bytes / ag / 1e9,
+                                             "apply_only_frac": bwd_bytes / ag / 1e9 / HBM_PEAK_GBPS,
+                                             "avg_s_sort_plus_apply": ag + (bs - ba)}
+        except Exception as exc:  # wide rows (> 64 lanes x vector) have no fused Adagrad
+            result["bwd_rowwise_adagrad"] = {"error": str(exc)}
         # BASELINE configs[2]: one fwd + bwd training step.  The key sort needs only the request, so it runs on a
         # second HIP stream UNDER the forward lookup; the apply kernels wait for both.
         side = torch.cuda.Stream(device=dev)

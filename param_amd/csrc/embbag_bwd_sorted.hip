@@ -311,7 +311,8 @@ hipError_t launch_apply_w(const SortedParams& sp, hipStream_t stream) {
     const dim3 g1(static_cast<unsigned>(grid)), g2(static_cast<unsigned>(fgrid)), blk(kBlock);
 #define PM_LAUNCH_SORTED(W_, OPT_)                                                                             \
     do {                                                                                                       \
-        hipLaunchKernelGGL((bwd_sorted_main_kernel<DST, K, G, W_, OPT_>), g1, blk, 0, stream, sp);             \
+        hipLaunchKernelGGL((bwd_sorted_main_kernel<DST, K, G, W_, OPT_>), g1, blk,                             \
+                           static_cast<size_t>(sp.T) * ((OPT_) == 1 ? 28 : 20), stream, sp);                  \
         hipLaunchKernelGGL((bwd_sorted_fixup_kernel<DST, K, G, W_, OPT_>), g2, blk, 0, stream, sp, n_chunks); \
     } while (0)
     if (sp.mom) {  // row-wise Adagrad: one column pass with all G lanes (cross-lane reduction)
