@@ -57,7 +57,9 @@ def parse():
     p.add_argument("--pooling", type=int, default=20)
     p.add_argument("--alpha", type=float, default=1.05, help="Zipf exponent of the headline run (0 = uniform)")
     p.add_argument("--dtype", choices=sorted(_DT), default="fp32")
-    p.add_argument("--a2a-groups", type=int, default=4, help="N>1: table groups pipelined against the all-to-all")
+    p.add_argument("--a2a-groups", type=int, default=1, help="N>1: table groups pipelined against the all-to-all inside a step")
+    p.add_argument("--pipeline-depth", type=int, default=2,
+                   help="N>1: steps in flight; 2 = step k's exchange completes under step k+1's lookups (double-buffered)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--dist-debug", action="store_true", help="run the N>1 (pipeline + RCCL) code path even at world size 1")
     p.add_argument("--no-uniform", action="store_true", help="skip the extra uniform-index (pure HBM) measurement")
@@ -227,7 +229,7 @@ def main():
             _fwd(tsets[g], ig, og, B_glob, out=out_g)
 
         # lookup(g) -> RCCL all_to_all(g) on the process group's own stream, under lookup(g+1)
-        pipe = LookupAllToAll(hip_lookup, world, B_local, [Tg * D] * groups, dev)
+        pipe = LookupAllToAll(hip_lookup, world, B_local, [Tg * D] * groups, dev, depth=a.pipeline_depth)
 
         def split_request(i, o):
             return split_request_by_group(i, o, T_loc, groups, B_glob)
@@ -237,7 +239,9 @@ def main():
         def step(rq=None):
             pipe.step(reqs if rq is None else rq)
 
-    wall, dev_s = time_steps(step, a.steps, a.warmup, barrier)
+    wall, dev_s = time_steps(step, a.steps, a.warmup, barrier)   # the closing device sync covers exchanges still in flight
+    if multi:
+        pipe.flush()
     if dist is not None:
         t = torch.tensor([wall, dev_s], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -261,7 +265,8 @@ def main():
                          + (f"; 1 GPU holds {T_loc} of {a.tables} tables ({T_loc * table_bytes / 1e9:.1f} GB): "
                             f"{a.tables} x {table_bytes / 1e9:.2f} GB exceeds 288 GB HBM" if world == 1 and T_loc < a.tables else "")
                          + (f"; table-wise sharded {T_loc}/GPU, global batch {B_glob}, pooled all-to-all in "
-                            f"{groups} table groups overlapped with lookup" if world > 1 else "")),
+                            f"{groups} table group(s), {a.pipeline_depth} step(s) in flight (exchange of step k under the "
+                            f"lookups of step k+1)" if world > 1 else "")),
             "tables_total": a.tables if world > 1 else T_loc, "tables_per_gpu": T_loc,
             "rows": R if a.workload != "criteo" else "criteo_v2 (3 .. 40M rows, 204.2 M total)", "dim": D,
             "batch_per_rank": B_local, "global_batch": B_glob, "pooling": L, "alpha": a.alpha,

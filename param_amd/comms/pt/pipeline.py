@@ -42,13 +42,21 @@ def split_request_by_group(indices: torch.Tensor, offsets: torch.Tensor, tables:
 
 class LookupAllToAll:
     def __init__(self, lookup: Callable, world: int, local_batch: int, group_dims: Sequence[int], device,
-                 group=None, dtype=torch.float32):
-        """``group_dims[g]`` = sum of embedding dims of table group g (``Tg * D``)."""
+                 group=None, dtype=torch.float32, depth: int = 1):
+        """``group_dims[g]`` = sum of embedding dims of table group g (``Tg * D``).  ``depth`` = number of steps in
+        flight: 1 = every exchange is waited for inside its own step; 2 = the exchanges of step k complete under the
+        lookups of step k+1 (double-buffered send / receive tensors) -- what a training loop does, and the only way to hide
+        the exchange of the LAST table group."""
         self.lookup, self.world, self.local_batch, self.pg = lookup, world, local_batch, group
         self.groups = len(group_dims)
+        self.depth = max(1, int(depth))
         n = world * local_batch
-        self.send = [torch.empty((n, d), dtype=dtype, device=device) for d in group_dims]
-        self.recv = [torch.empty((world, local_batch, d), dtype=dtype, device=device) for d in group_dims]
+        self._send = [[torch.empty((n, d), dtype=dtype, device=device) for d in group_dims] for _ in range(self.depth)]
+        self._recv = [[torch.empty((world, local_batch, d), dtype=dtype, device=device) for d in group_dims]
+                      for _ in range(self.depth)]
+        self._pending: List[list] = [[] for _ in range(self.depth)]
+        self._k = 0
+        self.send, self.recv = self._send[0], self._recv[0]
 
     def lookups_only(self, requests) -> None:
         for g in range(self.groups):
@@ -60,19 +68,36 @@ class LookupAllToAll:
         for w in works:
             w.wait()
 
-    def step(self, requests) -> List[torch.Tensor]:
-        """lookup(g) -> async all_to_all(g) for every group, then wait for all exchanges."""
-        works = []
-        for g in range(self.groups):
-            self.lookup(g, requests[g][0], requests[g][1], self.send[g])
-            # equal splits: B_local rows to / from every rank.  The collective runs on the process
-            # group's stream after the lookup above and under the next group's lookup.
-            works.append(dist.all_to_all_single(self.recv[g].view(-1, self.recv[g].shape[-1]), self.send[g],
-                                                group=self.pg, async_op=True))
+    @staticmethod
+    def _wait(works) -> None:
         for w in works:
             if w is not None:
                 w.wait()
-        return self.recv
+        works.clear()
+
+    def step(self, requests) -> List[torch.Tensor]:
+        """lookup(g) -> async all_to_all(g) for every group.  depth 1: waits for all exchanges and returns this step's
+        receive tensors.  depth d: waits only for the step issued d steps ago (whose buffers are reused now) and returns
+        the receive tensors of the step just issued -- valid after :meth:`flush` or after d more steps."""
+        slot = self._k % self.depth
+        self._wait(self._pending[slot])                      # the exchange still reading / writing this slot's tensors
+        send, recv = self._send[slot], self._recv[slot]
+        for g in range(self.groups):
+            self.lookup(g, requests[g][0], requests[g][1], send[g])
+            # equal splits: B_local rows to / from every rank.  The collective runs on the process group's stream after
+            # the lookup above, under the next group's lookup (and, with depth > 1, under the next step's lookups).
+            self._pending[slot].append(dist.all_to_all_single(recv[g].view(-1, recv[g].shape[-1]), send[g],
+                                                              group=self.pg, async_op=True))
+        if self.depth == 1:
+            self._wait(self._pending[slot])
+        self._k += 1
+        self.send, self.recv = send, recv
+        return recv
+
+    def flush(self) -> None:
+        """wait for every exchange still in flight (makes the current stream wait; no host sync)"""
+        for works in self._pending:
+            self._wait(works)
 
     def bytes_per_rank(self) -> int:
         """output-tensor bytes per rank: the reference's ``memSize`` for algBW (pytorch_dist_backend.py:860-897)"""

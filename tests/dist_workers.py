@@ -238,6 +238,32 @@ def pipeline_layout(rank, world, port):
                         assert torch.allclose(recv[gi][src, b, t * D:(t + 1) * D], exp, atol=1e-5), (src, gi, t, b)
         pipe.lookups_only(reqs)
         pipe.all_to_all_only()
+
+        # two steps in flight (double-buffered): three steps with DIFFERENT requests; after flush() the tensors returned
+        # by each of the last two steps hold that step's exchange, untouched by the steps issued after it
+        def request_k(owner, k):
+            gg = torch.Generator().manual_seed(1000 * k + 7 + owner)
+            return torch.randint(0, R, (T_loc * B_glob * L,), generator=gg), torch.arange(T_loc * B_glob + 1) * L
+
+        pipe2 = LookupAllToAll(stub_lookup, world, B_local, [Tg * D] * groups, torch.device("cpu"), depth=2)
+        outs = []
+        for k in range(3):
+            ik, ok = request_k(rank, k)
+            outs.append(pipe2.step(split_request_by_group(ik, ok, T_loc, groups, B_glob)))
+        pipe2.flush()
+        assert outs[0][0].data_ptr() == outs[2][0].data_ptr() != outs[1][0].data_ptr()     # slots alternate
+        for k in (1, 2):
+            for src in range(world):
+                gs = torch.Generator().manual_seed(100 + src)
+                src_tables = [torch.randn(R, D, generator=gs) for _ in range(T_loc)]
+                s_idx, s_off = request_k(src, k)
+                for gi in range(groups):
+                    for t in range(Tg):
+                        tt = gi * Tg + t
+                        for b in range(B_local):
+                            bag = tt * B_glob + rank * B_local + b
+                            exp = src_tables[tt][s_idx[int(s_off[bag]):int(s_off[bag + 1])]].sum(0)
+                            assert torch.allclose(outs[k][gi][src, b, t * D:(t + 1) * D], exp, atol=1e-5), (k, src, gi, t, b)
     finally:
         dist.destroy_process_group()
 
