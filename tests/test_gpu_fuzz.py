@@ -2,6 +2,8 @@
 ragged/empty bags, weights, layouts, batch slices) through the C ABI, each checked against the C oracle:
 forward bit-exact; sorted backward bit-exact on rows with <= 256 lookups and 1e-5 vs fp64 otherwise;
 atomic backward 1e-5; Adagrad 2e-5.  Seeds are fixed: a failure reproduces."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -50,7 +52,10 @@ def _t(a, dtype=None):
     return t if dtype is None else t.to(dtype)
 
 
-@pytest.mark.parametrize("seed", range(60))
+_SEEDS = int(os.environ.get("PARAM_AMD_FUZZ_SEEDS", "60"))      # one-off soak runs: PARAM_AMD_FUZZ_SEEDS=1000
+
+
+@pytest.mark.parametrize("seed", range(_SEEDS))
 def test_random_request_vs_oracle(seed, coracle):
     from oracle import embbag_oracle as O
     from param_amd import BatchedEmbeddingBagMI355
@@ -130,8 +135,9 @@ def test_random_request_vs_oracle(seed, coracle):
                 assert np.array_equal(got[cold], bits[cold]), ("in-place bf16", t)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(max(12, _SEEDS // 5)))
 def test_random_adagrad_vs_oracle(seed, coracle):
+    from oracle import embbag_oracle as O
     from param_amd import BatchedEmbeddingBagMI355
 
     rng = np.random.default_rng(5000 + seed)
@@ -142,6 +148,7 @@ def test_random_adagrad_vs_oracle(seed, coracle):
     m = BatchedEmbeddingBagMI355(rows, dims, device=DEV, layout=c["layout"], init="normal", seed=seed, learning_rate=0.03,
                                  optimizer="rowwise_adagrad", eps=1e-5)
     W = [m.table(t).cpu().numpy().copy() for t in range(T)]
+    W0 = [w.copy() for w in W]
     shape = (B, sum(dims)) if c["layout"] == "bd" else (T, B, dims[0])
     grad = rng.standard_normal(shape).astype(np.float32)
     psw_t = None if c["psw"] is None else _t(c["psw"])
@@ -154,5 +161,30 @@ def test_random_adagrad_vs_oracle(seed, coracle):
         mom = np.zeros(rows[t], np.float32)
         coracle.bwd_rowwise_adagrad(W[t], mom, c["idx"][s:e], loc, g, None if c["psw"] is None else c["psw"][s:e],
                                     lr=0.03, eps=1e-5)
-        assert np.allclose(m.momentum_table(t).cpu().numpy(), mom, rtol=3e-5, atol=1e-10), ("momentum", t)
-        assert np.allclose(m.table(t).cpu().numpy(), W[t], rtol=3e-5, atol=3e-6), ("weights", t)
+        # rows within the exact-run limit: the oracle's own order, tight.  Hotter rows: the gradient sum G is formed in
+        # another (deterministic) order; its error is bounded relative to sum|contributions| (north_star: 1e-5), and with
+        # signed per-sample weights G itself can be much smaller than that sum, so the bound on the update is derived from
+        # an fp64 evaluation: |dW| <= mult * dG (+ the state's share), not from |W|
+        cnt = np.bincount(c["idx"][s:e], minlength=rows[t])
+        gm, gw = m.momentum_table(t).cpu().numpy(), m.table(t).cpu().numpy()
+        cold = cnt <= EXACT_RUN
+        assert np.allclose(gm[cold], mom[cold], rtol=3e-5, atol=1e-10), ("momentum", t)
+        assert np.allclose(gw[cold], W[t][cold], rtol=3e-5, atol=3e-6), ("weights", t)
+        if (~cold).any():
+            start, end = O.bag_bounds(loc, B, e - s)
+            bag_of = np.repeat(np.arange(B), end - start)
+            pw = np.ones(e - s) if c["psw"] is None else c["psw"][s:e].astype(np.float64)
+            contrib = g.astype(np.float64)[bag_of] * pw[:, None]
+            G, mag = np.zeros((rows[t], dims[t])), np.zeros((rows[t], dims[t]))
+            np.add.at(G, c["idx"][s:e], contrib)
+            np.add.at(mag, c["idx"][s:e], np.abs(contrib))
+            m64 = (G ** 2).mean(1)
+            mult = 0.03 / (np.sqrt(m64) + 1e-5)
+            W64 = W0[t].astype(np.float64) - mult[:, None] * G
+            dG = 1e-5 * mag + 1e-30
+            dm = (2 * np.abs(G) * dG).mean(1)                                   # first-order change of the state
+            dmult = mult * 0.5 * dm / np.maximum(m64, 1e-30)
+            bound = mult[:, None] * dG + dmult[:, None] * np.abs(G) + 3e-5 * np.abs(W64) + 3e-6
+            hot = ~cold
+            assert (np.abs(gw[hot] - W64[hot]) <= bound[hot]).all(), ("weights, hot rows", t)
+            assert (np.abs(gm[hot] - m64[hot]) <= dm[hot] + 3e-5 * m64[hot] + 1e-10).all(), ("momentum, hot rows", t)
