@@ -102,6 +102,15 @@ const char* pm_last_error(void); /* thread-local; "" if none */
 int pm_embbag_fwd(const pm_embbag_batch* op, float* out, pm_stream_t stream);
 
 /*
+ * The same lookup for FEW, LONG bags (inference-style requests: a handful of bags of thousands of lookups): one
+ * workgroup per bag, the bag's lookups split over the workgroup's lane groups, partial sums combined with wavefront
+ * shuffles and through LDS in a fixed order.  Deterministic, but NOT the sequential order: the result agrees with
+ * pm_embbag_fwd to fp32 rounding (1e-5 relative to sum |row|), not bit for bit -- hence a separate entry point.
+ * Same arguments and layout rules as pm_embbag_fwd; T * bag_count workgroups are launched.
+ */
+int pm_embbag_fwd_split(const pm_embbag_batch* op, float* out, pm_stream_t stream);
+
+/*
  * Backward scatter-add:
  *     dst_t[indices[j], :] += alpha * psw[j] * grad(t, bag(j))[:]
  * `grad` is addressed like `out` above.  dst_tables is a device array [T] of

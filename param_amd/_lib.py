@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = (
     "pm_build_info",
     "pm_last_error",
     "pm_embbag_fwd",
+    "pm_embbag_fwd_split",
     "pm_embbag_bwd",
     "pm_embbag_bwd_sorted_workspace",
     "pm_embbag_sort_indices",
@@ -111,6 +112,8 @@ def load() -> ctypes.CDLL:
         L.pm_last_error.argtypes = []
         L.pm_embbag_fwd.restype = ctypes.c_int
         L.pm_embbag_fwd.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp]
+        L.pm_embbag_fwd_split.restype = ctypes.c_int
+        L.pm_embbag_fwd_split.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp]
         L.pm_embbag_bwd.restype = ctypes.c_int
         L.pm_embbag_bwd.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, ctypes.c_float, vp]
         L.pm_embbag_bwd_sorted_workspace.restype = ctypes.c_int64

@@ -142,6 +142,18 @@ int pm_embbag_fwd(const pm_embbag_batch* op, float* out, pm_stream_t stream) {
     return PM_OK;
 }
 
+int pm_embbag_fwd_split(const pm_embbag_batch* op, float* out, pm_stream_t stream) {
+    pm::KParams p;
+    int rc = make_params(op, op ? op->weight_dtype : -1, p);
+    if (rc != PM_OK) return rc;
+    if (p.bag_count == 0) return PM_OK;
+    if (!out) return fail(PM_ERR_INVALID, "out is NULL");
+    p.io = out;
+    hipError_t h = pm::launch_embbag_fwd_split(p, op->weight_dtype, op->max_dim, static_cast<hipStream_t>(stream));
+    if (h != hipSuccess) return hip_fail(h, "pm_embbag_fwd_split launch");
+    return PM_OK;
+}
+
 int pm_embbag_bwd(const pm_embbag_batch* op, const float* grad, void* const* dst_tables, int32_t dst_dtype,
                   float alpha, pm_stream_t stream) {
     pm::KParams p;

@@ -108,6 +108,7 @@ inline size_t tile_lds_bytes(int bags_per_block, int idx_cap, bool weighted) {
 // ---- host-side launchers implemented in the kernel files ----------------------------------
 hipError_t launch_embbag_fwd(const KParams& p, int weight_dtype, int max_dim, int unroll,
                              hipStream_t stream);
+hipError_t launch_embbag_fwd_split(const KParams& p, int weight_dtype, int max_dim, hipStream_t stream);
 hipError_t launch_embbag_bwd(const KParams& p, int dst_dtype, int max_dim, hipStream_t stream);
 hipError_t launch_embbag_check(const KParams& p, int32_t* d_err, hipStream_t stream);
 hipError_t launch_fill_random(void* dst, int64_t count, int dtype, int dist, float lo, float hi,

@@ -136,14 +136,17 @@ class _TableSet:
         return op
 
 
-def _fwd(ts: _TableSet, indices, offsets, B, psw=None, out=None, bag_begin=0, bag_count=None):
+def _fwd(ts: _TableSet, indices, offsets, B, psw=None, out=None, bag_begin=0, bag_count=None, split_bags: bool = False):
+    """``split_bags``: one workgroup per bag with wave-shuffle / LDS partial reductions (``pm_embbag_fwd_split``) -- for
+    few, long bags; agrees with the default kernel to fp32 rounding, not bit for bit."""
     op = ts.request(indices, offsets, B, psw, bag_begin, bag_count)
     _, _, shape = ts.out_desc(B)
     if out is None:
         out = torch.empty(shape, dtype=torch.float32, device=ts.device)
     elif out.dtype != torch.float32 or tuple(out.shape) != tuple(shape) or not out.is_contiguous():
         raise ValueError(f"out must be a contiguous float32 tensor of shape {shape}")
-    _lib.check(_lib.load().pm_embbag_fwd(ctypes.byref(op), out.data_ptr(), _stream_ptr()))
+    L = _lib.load()
+    _lib.check((L.pm_embbag_fwd_split if split_bags else L.pm_embbag_fwd)(ctypes.byref(op), out.data_ptr(), _stream_ptr()))
     return out
 
 
@@ -388,11 +391,12 @@ class BatchedEmbeddingBagMI355(nn.Module):
 
     # -- ops ---------------------------------------------------------------------------------
     def lookup(self, indices, offsets, per_sample_weights=None, out=None, bag_begin=0, bag_count=None,
-               batch: Optional[int] = None):
-        """Forward without autograd glue; ``bag_begin/bag_count`` select a batch slice."""
+               batch: Optional[int] = None, split_bags: bool = False):
+        """Forward without autograd glue; ``bag_begin/bag_count`` select a batch slice.  ``split_bags=True`` selects the
+        one-workgroup-per-bag kernel for few, long bags (deterministic, fp32-rounding-close to the default, not bit-equal)."""
         _require_device(self.weights, "BatchedEmbeddingBagMI355.weights")
         B = self._batch_of(offsets) if batch is None else batch
-        return _fwd(self._tables(), indices, offsets, B, per_sample_weights, out, bag_begin, bag_count)
+        return _fwd(self._tables(), indices, offsets, B, per_sample_weights, out, bag_begin, bag_count, split_bags)
 
     def forward(self, indices, offsets, per_sample_weights=None):
         if self.fused_update and torch.is_grad_enabled():

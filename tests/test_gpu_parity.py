@@ -683,3 +683,55 @@ def test_sorted_backward_runs_around_chunk_and_tile_boundaries(coracle, D, idt):
         ref = coracle.bwd_f32(W[t].copy(), idx[s:e], np.arange(B) * L, g, psw[s:e], alpha=-0.25)
         cold = np.bincount(idx[s:e], minlength=rows[t]) <= 256
         assert np.array_equal(m.table(t).cpu().numpy()[cold], ref[cold]), (D, t)
+
+
+@pytest.mark.parametrize("wdt,D", [(torch.float32, 128), (torch.float32, 16), (torch.float32, 512), (torch.bfloat16, 128),
+                                   (torch.float16, 64)])
+def test_split_bag_forward_long_bags(coracle, wdt, D):
+    """pm_embbag_fwd_split (one workgroup per bag, wave-shuffle + LDS partial reductions) on few, long, ragged bags incl.
+    empty ones and bags longer than the LDS index chunk: within 1e-5 of sum|row| of the oracle's sequential sum (the order
+    differs by design), deterministic, weighted and unweighted, both index types; and faster than the sequential-per-bag
+    kernel on this shape."""
+    from param_amd import BatchedEmbeddingBagMI355
+
+    rng = np.random.default_rng(D)
+    rows, B = [50000, 777], 6
+    lens = np.array([5000, 0, 2049, 1, 300, 9000, 64, 2048, 0, 4097, 33, 7], np.int64)      # 2 tables x 6 bags
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    idx = np.concatenate([rng.integers(0, rows[t], int(lens[t * B:(t + 1) * B].sum())) for t in range(2)]).astype(np.int64)
+    m = BatchedEmbeddingBagMI355(rows, D, dtype=wdt, device=DEV, init="normal", seed=3, fused_update=False)
+    tabs = [m.table(t).float().cpu().numpy() for t in range(2)]
+    for weighted in (False, True):
+        psw = rng.standard_normal(idx.size).astype(np.float32) if weighted else None
+        for it in (torch.int64, torch.int32):
+            i_t, o_t = torch.from_numpy(idx).to(DEV).to(it), torch.from_numpy(off).to(DEV).to(it)
+            p_t = None if psw is None else torch.from_numpy(psw).to(DEV)
+            got = m.lookup(i_t, o_t, p_t, batch=B, split_bags=True)
+            exp = coracle.fwd_batched(tabs, idx, off, B, psw=psw, layout="bd")
+            mag = coracle.fwd_batched([np.abs(x) for x in tabs], idx, off, B, psw=None if psw is None else np.abs(psw), layout="bd")
+            assert (np.abs(got.cpu().numpy() - exp) <= 1e-5 * mag + 1e-30).all(), (weighted, it)
+            assert torch.equal(got, m.lookup(i_t, o_t, p_t, batch=B, split_bags=True))              # deterministic
+            seq = m.lookup(i_t, o_t, p_t, batch=B)
+            assert np.array_equal(seq.cpu().numpy(), exp)                                           # the default stays bit-exact
+    # a batch slice writes exactly its rows
+    o2 = torch.full_like(got, float("nan"))
+    m.lookup(i_t, o_t, p_t, out=o2, batch=B, bag_begin=2, bag_count=3, split_bags=True)
+    assert torch.equal(o2[2:5], got[2:5]) and torch.isnan(o2[:2]).all() and torch.isnan(o2[5:]).all()
+    if D == 128 and wdt == torch.float32:
+        big = BatchedEmbeddingBagMI355([2_000_000] * 4, 128, device=DEV, init="normal", seed=5, fused_update=False)
+        bi = torch.randint(0, 2_000_000, (4 * 8 * 20000,), device=DEV)
+        bo = torch.arange(4 * 8 + 1, device=DEV) * 20000                         # 32 bags of 20 000 lookups
+
+        def ms(split):
+            for _ in range(2):
+                big.lookup(bi, bo, batch=8, split_bags=split)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                big.lookup(bi, bo, batch=8, split_bags=split)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / 5
+        t_seq, t_split = ms(False), ms(True)
+        print(f"32 bags x 20000 lookups: sequential-per-bag {t_seq:.3f} ms, split {t_split:.3f} ms")
+        assert t_split < t_seq
