@@ -30,7 +30,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .pytorch_backend_utils import backendFunctions, collectiveArgsHolder, register_customized_backend
+from .pytorch_backend_utils import backendFunctions, register_customized_backend
 
 logger = logging.getLogger(__name__)
 

@@ -7,7 +7,6 @@ import os
 import socket
 import types
 
-import numpy as np
 import torch
 import torch.distributed as dist
 

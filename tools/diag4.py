@@ -5,7 +5,6 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import param_amd
-from param_amd.compute.pt.pytorch_emb import algorithmic_bytes
 dev = torch.device("cuda:0")
 T, R, D, B, L = 48, 10_000_000, 128, 8192, 20
 m = param_amd.BatchedEmbeddingBagMI355([R] * T, D, device=dev, init="normal", seed=1, fused_update=False)
