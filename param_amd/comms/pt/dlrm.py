@@ -103,7 +103,9 @@ def regroup_per_table(lengths: torch.Tensor, indices: torch.Tensor, batch_size: 
                                                out_off.data_ptr(), scratch.data_ptr(),
                                                torch.cuda.current_stream().cuda_stream))
         return out_idx, out_off
-    # host tensors (the world-2 gloo tests of the plumbing): the same regrouping with torch ops
+    # host tensors = the driver's `--device cpu` mode (the reference has the same mode; here it exists for the world-2
+    # gloo tests of the plumbing).  Not a fallback: device tensors never reach this branch, and the branch above raises if
+    # libparam_amd.so is missing.  Same regrouping, written with torch index ops.
     l3 = lengths.view(W, F, B).to(torch.int64)
     block = l3.sum(dim=2)                                  # [W, F] indices per (rank, table) block
     src_start = torch.cumsum(block.reshape(-1), 0) - block.reshape(-1)       # received order (r, f)
