@@ -31,6 +31,7 @@ def label_rows(rows):
     out = defaultdict(list)
     n_fwd = 0
     n_fill = 0
+    n_main = n_fix = 0
     for name, val in rows:
         if "fill_random_kernel" in name:
             n_fill += 1
@@ -47,10 +48,12 @@ def label_rows(rows):
                 out["fwd_zipf"].append(val)
         elif "embbag_bwd_kernel" in name:
             out["bwd_atomic_uniform"].append(val)
-        elif "bwd_sorted_main_kernel" in name:
-            out["bwd_uniform"].append(val)          # the dominant backward kernel (apply)
+        elif "bwd_sorted_main_kernel" in name:        # the dominant backward kernel: `reps` uniform steps, then `reps` Zipf
+            n_main += 1
+            out["bwd_uniform" if n_main <= reps else "bwd_zipf"].append(val)
         elif "bwd_sorted_fixup_kernel" in name:
-            out["bwd_fixup_uniform"].append(val)
+            n_fix += 1
+            out["bwd_fixup_uniform" if n_fix <= reps else "bwd_fixup_zipf"].append(val)
         elif "radix_sort" in name and "onesweep" in name:
             out["bwd_sort_pass_uniform"].append(val)
     if out["_fill_all"]:

@@ -6,7 +6,7 @@ counts, so the PMC rows (FETCH_SIZE / WRITE_SIZE / TCC_HIT / TCC_MISS) can be ca
   calib_read  : torch sum over the same 8 GiB fp32   (reads exactly 8 GiB)
   fwd uniform : embbag_fwd_kernel, alpha=0           (no reuse: HBM bytes ~ algorithmic bytes)
   fwd zipf    : embbag_fwd_kernel, alpha=1.05        (hot rows hit L2/MALL: HBM bytes < algorithmic)
-  bwd uniform : embbag_bwd_kernel (atomics)
+  bwd uniform / zipf : sort + bwd_sorted_main_kernel + bwd_sorted_fixup_kernel (the deterministic backward)
 
 Launch order is fixed and printed, so dispatches can be matched by order in the CSV.
 """
@@ -65,6 +65,10 @@ if a.bwd:
     for _ in range(a.reps):
         m.scatter_add_(grad, iu, ou, alpha=-1e-6, batch=B)
         manifest["order"].append("bwd_uniform")
+    torch.cuda.synchronize()
+    for _ in range(a.reps):
+        m.scatter_add_(grad, iz, oz, alpha=-1e-6, batch=B)
+        manifest["order"].append("bwd_zipf")
     torch.cuda.synchronize()
 if a.manifest:
     json.dump(manifest, open(a.manifest, "w"), indent=1)

@@ -1,0 +1,9 @@
+cd /tmp; export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out; TAG=r01d
+i=0
+for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${TAG}_pmc/pmc_$i -o pmc -- \
+      python $GRAFT_REPO_ROOT/tools/pmc_probe.py --bwd --manifest $OUT/${TAG}_pmc/pmc_manifest.json > $OUT/${TAG}_pmc_$i.log 2>&1
+done
+ls $OUT/${TAG}_pmc
