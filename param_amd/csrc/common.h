@@ -16,6 +16,16 @@ constexpr int kXcds = 8;     // MI355X: 8 XCDs, block b is dispatched to XCD b %
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Table pointers reach the kernels through a device array (tables[t]) or LDS copies of it, so the compiler cannot
+// tell they point to global memory and emits FLAT loads/stores/atomics for the rows.  FLAT instructions count against
+// lgkmcnt as well as vmcnt: every wait for an LDS read (the staged indices) then also waits for all row loads in flight.
+// The row accesses therefore go through explicit global-address-space pointers (global_load_dwordx4 ...).
+#define PM_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ const PM_GLOBAL T* as_global(const void* p) { return (const PM_GLOBAL T*)(p); }
+template <typename T>
+__device__ __forceinline__ PM_GLOBAL T* as_global(void* p) { return (PM_GLOBAL T*)(p); }
+
 // Kernel-argument block shared by forward / backward / check (passed by value: SGPRs).
 struct KParams {
     const void* const* tables;   // fwd: source tables; bwd: destination tables
@@ -42,8 +52,7 @@ struct KParams {
 };
 
 __device__ __forceinline__ int64_t load_index(const void* p, int64_t i, int idx64) {
-    return idx64 ? reinterpret_cast<const int64_t*>(p)[i]
-                 : static_cast<int64_t>(reinterpret_cast<const int32_t*>(p)[i]);
+    return idx64 ? as_global<int64_t>(p)[i] : static_cast<int64_t>(as_global<int32_t>(p)[i]);
 }
 
 // End of global bag g (g in [0, T*B)): next offset, or N for the very last bag
@@ -93,7 +102,7 @@ __device__ __forceinline__ bool stage_tile(const KParams& p, int t, int tile, ch
     if (staged) {
         for (int i = threadIdx.x; i < static_cast<int>(cnt); i += kBlock) {
             s_idx[i] = static_cast<int32_t>(load_index(p.indices, base + i, p.idx64));
-            if (WEIGHTED) s_w[i] = p.psw[base + i];
+            if (WEIGHTED) s_w[i] = as_global<float>(p.psw)[base + i];
         }
         __syncthreads();
     }

@@ -24,15 +24,14 @@ namespace {
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
-#define PM_GLOBAL __attribute__((address_space(1)))
 
 struct DstF32 {
     static constexpr int kVec = 4;  // elements per lane
     static constexpr int kES = 4;
     __device__ static __forceinline__ void add(char* row, const float (&v)[4]) {
-        float* q = reinterpret_cast<float*>(row);
+        PM_GLOBAL float* q = as_global<float>(row);   // global_atomic_add_f32 (no return), not flat_atomic
 #pragma unroll
-        for (int k = 0; k < 4; ++k) unsafeAtomicAdd(q + k, v[k]);
+        for (int k = 0; k < 4; ++k) __builtin_amdgcn_global_atomic_fadd_f32(q + k, v[k]);
     }
 };
 struct DstBF16 {
@@ -112,7 +111,7 @@ __global__ void __launch_bounds__(kBlock) embbag_bwd_kernel(const KParams p) {
                 const int64_t r = staged ? static_cast<int64_t>(s_idx[j - base])
                                          : load_index(p.indices, j, p.idx64);
                 if (WEIGHTED) {
-                    const float sc = p.alpha * (staged ? s_w[j - base] : p.psw[j]);
+                    const float sc = p.alpha * (staged ? s_w[j - base] : as_global<float>(p.psw)[j]);
                     float gw[VEC];
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) gw[k] = sc * g[k];

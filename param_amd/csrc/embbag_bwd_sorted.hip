@@ -108,11 +108,11 @@ __global__ void __launch_bounds__(kBlock) build_keys_kernel(const KParams p, K* 
 // 16-byte destination-row accesses; nt = streaming hint (every touched row is read once and written
 // once per call, so it should not displace the gradient rows that ARE re-read from L2)
 __device__ __forceinline__ u32x4 raw16_load(const char* p, bool nt) {
-    const u32x4* q = reinterpret_cast<const u32x4*>(p);
+    const PM_GLOBAL u32x4* q = as_global<u32x4>(p);   // global, not flat (common.h)
     return nt ? __builtin_nontemporal_load(q) : *q;
 }
 __device__ __forceinline__ void raw16_store(char* p, const u32x4 v, bool nt) {
-    u32x4* q = reinterpret_cast<u32x4*>(p);
+    PM_GLOBAL u32x4* q = as_global<u32x4>(p);
     if (nt) __builtin_nontemporal_store(v, q); else *q = v;
 }
 

@@ -59,7 +59,7 @@ template <> struct Elem<f16_t> {
 };
 
 __device__ __forceinline__ u32x4 load16(const char* p, bool nt) {
-    const u32x4* q = reinterpret_cast<const u32x4*>(p);
+    const PM_GLOBAL u32x4* q = as_global<u32x4>(p);   // global_load_dwordx4, not flat_load (common.h)
     return nt ? __builtin_nontemporal_load(q) : *q;
 }
 
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
                     const int64_t jj = j + u;
                     const int64_t r = staged ? static_cast<int64_t>(s_idx[jj - base])
                                              : load_index(p.indices, jj, p.idx64);
-                    if (WEIGHTED) w[u] = staged ? s_w[jj - base] : p.psw[jj];
+                    if (WEIGHTED) w[u] = staged ? s_w[jj - base] : as_global<float>(p.psw)[jj];
                     raw[u] = load16(Wc + r * row_bytes, nt);
                 }
 #pragma unroll
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
                     if (jj < e) {
                         const int64_t r = staged ? static_cast<int64_t>(s_idx[jj - base])
                                                  : load_index(p.indices, jj, p.idx64);
-                        if (WEIGHTED) w[u] = staged ? s_w[jj - base] : p.psw[jj];
+                        if (WEIGHTED) w[u] = staged ? s_w[jj - base] : as_global<float>(p.psw)[jj];
                         raw[u] = load16(Wc + r * row_bytes, nt);
                     }
                 }

@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_split_kernel(const KParams 
                     for (int u = 0; u < UNROLL; ++u) {
                         const int jj = j + u * NG;
                         if (jj < n) {
-                            raw[u] = *reinterpret_cast<const u32x4*>(Wc + static_cast<int64_t>(s_idx[jj]) * row_bytes);
+                            raw[u] = *as_global<u32x4>(Wc + static_cast<int64_t>(s_idx[jj]) * row_bytes);
                             if (WEIGHTED) w[u] = s_w[jj];
                         }
                     }
