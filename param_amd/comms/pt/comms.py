@@ -67,7 +67,8 @@ class commsParamsHolder:
 
 
 def format_header() -> str:
-    return "\n\tCOMMS-RES-{}-{}".format("{collective}", "{dtype}") + HEADER_FMT.format(
+    """the reference's preamble line (``printPreamble``, comms.py:956-1001): plain ``COMMS-RES`` + the column titles"""
+    return "\n\tCOMMS-RES" + HEADER_FMT.format(
         "total-size (B)", "nElementsPerRank", "Time(us):p50", "p75", "p95", "Min", "Max", "AlgBW(GB/s)",
         "BusBW(GB/s)", "TotalTime(us):p50")
 
@@ -261,7 +262,7 @@ class commsCollBench:
         comm_fn = bf.collectiveFunc[commsParams.collective]
         comms_utils.fixBeginSize(commsParams, ca.world_size)
         if ca.global_rank == 0:
-            print(format_header().format(collective=ca.collective, dtype=ca.data_type))
+            print(format_header())
         for curSize in comms_utils.getSizes(commsParams.beginSize, commsParams.endSize, commsParams.stepFactor,
                                             commsParams.stepBytes):
             numElements = self.prepComm(commsParams, curSize)
