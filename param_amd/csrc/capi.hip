@@ -101,6 +101,9 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p) {
     p.xcd_affine = (op->num_tables % pm::kXcds == 0 && xa != 0) ? 1 : 0;
     const int nt = g_nt_loads.load();
     p.nt_loads = nt > 0 ? 1 : 0;
+    // lookups that do not divide evenly over the bags: certainly ragged (fixed-size requests -- every benchmark shape --
+    // always divide; a ragged request that happens to divide merely runs the unordered kernel)
+    p.ordered = (total_bags > 0 && op->num_indices % total_bags != 0) ? 1 : 0;
     p.alpha = 1.0f;
     return PM_OK;
 }

@@ -48,6 +48,7 @@ struct KParams {
     int32_t idx64;               // 1: int64 indices/offsets, 0: int32
     int32_t xcd_affine;          // 1: table t is served by XCD t % 8 (requires T % 8 == 0)
     int32_t nt_loads;            // 1: non-temporal table-row loads
+    int32_t ordered;             // forward: 1 = ragged request, lane groups take the longest bags of a tile first
     float alpha;                 // bwd scale
 };
 
