@@ -103,7 +103,8 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p) {
     p.nt_loads = nt > 0 ? 1 : 0;
     // lookups that do not divide evenly over the bags: certainly ragged (fixed-size requests -- every benchmark shape --
     // always divide; a ragged request that happens to divide merely runs the unordered kernel)
-    p.ordered = (total_bags > 0 && op->num_indices % total_bags != 0) ? 1 : 0;
+    // ... and only where the order can matter: with one bag per lane group (short-bag tiles) nothing is pulled
+    p.ordered = (total_bags > 0 && op->num_indices % total_bags != 0 && bpb > NG) ? 1 : 0;
     p.alpha = 1.0f;
     return PM_OK;
 }
