@@ -735,3 +735,49 @@ def test_split_bag_forward_long_bags(coracle, wdt, D):
         t_seq, t_split = ms(False), ms(True)
         print(f"32 bags x 20000 lookups: sequential-per-bag {t_seq:.3f} ms, split {t_split:.3f} ms")
         assert t_split < t_seq
+
+
+def test_forward_more_than_2_31_lookups():
+    """64-bit positions end to end: 2.2e9 lookups in one request (17.6 GB of int64 indices), bag starts beyond 2^31.
+    Table W[r, :] = r and indices j % 1024 make every pooled value an exact small integer with a closed form."""
+    from param_amd import BatchedEmbeddingBagMI355
+
+    R, D, B, L = 1024, 4, 1 << 20, 2100
+    n = B * L
+    assert n > 2 ** 31
+    m = BatchedEmbeddingBagMI355([R], D, device=DEV, init=None, fused_update=False)
+    m.table(0).copy_(torch.arange(R, device=DEV, dtype=torch.float32).unsqueeze(1).expand(R, D))
+    idx = torch.arange(n, device=DEV, dtype=torch.int64).remainder_(R)
+    off = torch.arange(B + 1, device=DEV, dtype=torch.int64) * L
+    out = m.lookup(idx, off, batch=B)
+    # sum over j in [b*L, (b+1)*L) of (j mod R): prefix sums of the periodic sequence
+    def prefix(x):                                   # sum_{j < x} (j mod R), int64 tensor
+        q, r = x // R, x % R
+        return q * (R * (R - 1) // 2) + r * (r - 1) // 2
+    exp = (prefix(off[1:]) - prefix(off[:-1])).to(torch.float32)
+    assert float(exp.max()) < 2 ** 24                 # exact in fp32 whatever the order
+    assert torch.equal(out, exp.unsqueeze(1).expand(B, D))
+    del idx, out
+    torch.cuda.empty_cache()
+
+
+def test_sorted_backward_more_than_2_31_lookups():
+    """the deterministic backward on the same 2.2e9-lookup request: 64-bit positions through key building, the radix sort
+    (4-byte keys / values: positions and bags stay below 2^32), 69 M chunks, runs of 2.1 M lookups (chunk partials summed
+    by the fix-up).  Gradient 1 everywhere makes every row's update an exact integer: its lookup count."""
+    from param_amd import BatchedEmbeddingBagMI355
+
+    R, D, B, L = 1024, 4, 1 << 20, 2100
+    n = B * L
+    m = BatchedEmbeddingBagMI355([R], D, device=DEV, init=None, fused_update=False)
+    m.table(0).zero_()
+    idx = torch.arange(n, device=DEV, dtype=torch.int64).remainder_(R)
+    off = torch.arange(B + 1, device=DEV, dtype=torch.int64) * L
+    grad = torch.ones((B, D), device=DEV)
+    m.scatter_add_(grad, idx, off, alpha=1.0, batch=B)
+    counts = torch.bincount(idx, minlength=R).to(torch.float32)
+    assert float(counts.max()) < 2 ** 24
+    assert torch.equal(m.table(0), counts.unsqueeze(1).expand(R, D))
+    del idx, grad
+    m._ts = None
+    torch.cuda.empty_cache()
