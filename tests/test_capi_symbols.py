@@ -58,6 +58,18 @@ def test_argument_validation_without_gpu():
     # empty request: nothing to launch, succeeds without a device
     op.batch = op.bag_begin = op.bag_count = 0
     assert L.pm_embbag_fwd(ctypes.byref(op), None, None) == _lib.PM_OK
+    assert L.pm_embbag_fwd_split(ctypes.byref(op), None, None) == _lib.PM_OK
+    # the sorted backward carries positions and bags in 32 bits: 2^32 lookups (or a 2^31-row table) are refused, not wrapped
+    op.batch, op.bag_count, op.num_indices, op.indices, op.offsets = 4, 4, 1 << 32, 8, 8
+    assert L.pm_embbag_bwd_sorted_workspace(ctypes.byref(op), 1000) == _lib.PM_ERR_UNSUPPORTED
+    assert b"2^32" in L.pm_last_error()
+    op.num_indices = 100
+    assert L.pm_embbag_bwd_sorted_workspace(ctypes.byref(op), (1 << 31) + 1) == _lib.PM_ERR_INVALID
+    opt = _lib.pm_rowwise_adagrad(0.01, 1e-8, 0.0, 7, 0, 0, 0)                      # unknown weight-decay mode
+    assert L.pm_embbag_bwd_sorted_adagrad_ex(ctypes.byref(op), 8, 8, _lib.PM_F32, 8, ctypes.byref(opt), 1000, 8, 1 << 40,
+                                             None) == _lib.PM_ERR_INVALID
+    assert b"weight_decay_mode" in L.pm_last_error()
+    assert L.pm_dlrm_regroup(8, 8, 65, 64, 4, 8, 8, 8, None) == _lib.PM_ERR_UNSUPPORTED   # world * tables > 4096
 
 
 def test_graft_entry_build_runs():
