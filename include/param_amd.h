@@ -211,7 +211,10 @@ int pm_dlrm_regroup(const int64_t* lengths, const int64_t* indices, int32_t worl
 
 /*
  * Validate a request on the device: every index in [0, rows[t]) and offsets
- * monotone within [0, num_indices].  Writes the number of violations to
+ * monotone within [0, num_indices]; plus what the kernels assume about the
+ * per-table device arrays: rows[t] in [1, 2^31), dims[t] a multiple of 4 (fp32) /
+ * 8 (16-bit) and <= max_dim, out_offsets[t] a multiple of 4 elements, table base
+ * pointers 16-byte aligned.  Writes the number of violations to
  * *d_error_count (device int32, caller-zeroed is NOT required: the call zeroes
  * it first).  torch raises on such inputs (CPU) / device-asserts (GPU); the
  * forward/backward kernels themselves do not check.

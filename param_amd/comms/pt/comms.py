@@ -126,8 +126,10 @@ class commsCollBench:
             args.b = 1
         if args.e < args.b:
             logger.warning(f"the begin-size (--b {args.b}) is larger than the end-size (--e {args.e})")
-        if args.device == "cpu" and args.backend in ("nccl", BACKEND_NAME):
+        if args.device == "cpu" and args.backend == "nccl":
             raise ValueError(f"backend {args.backend} does not support device cpu")
+        # --backend rccl_xgmi --device cpu: the plug-in moves host tensors over gloo (MI355XBackend._pg_backend), which is
+        # how it runs under the reference's own comms.py on a box without GPUs (tests/golden/gen_ref_plugin_rows.py)
         if args.c == 1 and args.z == 0:
             logger.warning("data validation requires blocking mode: forcing --z 1")
             args.z = 1
@@ -329,7 +331,7 @@ def main(argv=None):
         env["local_rank"] = env["global_rank"] % max(1, env["local_size"])
     info = comms_utils.bootstrap_info_holder(args.master_ip, args.master_port, 0, env)
     bf = bench.initBackend(info, args)
-    bf.sayHello(env["global_rank"], env["local_rank"], env["world_size"], args.master_ip)
+    bf.sayHello()  # the reference's call form (comms.py:1533)
     try:
         return bench.runBench(args)
     finally:

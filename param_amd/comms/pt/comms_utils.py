@@ -299,11 +299,12 @@ def init_emb_lookup(collectiveArgs, commsParams, backendFuncs) -> None:
     ca.direction = commsParams.direction or "forward"
     ca.emb_dim, ca.batch_size = commsParams.emb_dim, commsParams.batch_size
     tables = commsParams.num_emb_tables_per_device
-    batched = getattr(commsParams, "num_emb_tables_batched", -1)
-    batched = tables if batched in (-1, 0, None) else batched
+    raw = getattr(commsParams, "num_emb_tables_batched", -1)
+    raw = -1 if raw in (0, None) else raw
+    batched = tables if raw == -1 else raw
     if tables % batched:
         raise ValueError("the number of embedding tables per device must be a multiple of the batched-table count")
-    ca.num_emb_tables_batched = batched
+    ca.num_emb_tables_batched = raw      # -1 stays -1 (reference :1983): "not batched with the all-to-all"
     ca.num_emb_ops = tables // batched
     ca.emb = [backendFuncs.alloc_batched_embedding_tables([commsParams.num_embs] * batched, ca.emb_dim, ca.device, torch.float32)
               for _ in range(ca.num_emb_ops)]

@@ -43,9 +43,22 @@ class MI355XBackend(backendFunctions):
         self.bootstrap_info = bootstrap_info
         self.commsParams = commsParams
         self.use_ext_dist = False
+        # the fused lookup -> all-to-all entry of ``all_to_all`` is what the reference only takes with its
+        # ``extend_distributed`` package (pytorch_dist_backend.py:214); here it is an explicit opt-in
+        self.fused_lookup_a2a = bool(self._cp("fused_lookup_a2a", False)) or os.environ.get("PARAM_AMD_FUSED_LOOKUP_A2A") == "1"
         self.groups = {}
         self.num_pgs = 0
-        self.collectiveFunc["wait"] = self.wait
+        self.round_robin_group = None
+        # every entry of the reference ABC's table (pytorch_backend_utils.py:161-180) + its PyTorchDistBackend extras
+        # (pytorch_dist_backend.py:1100-1115): the reference drivers index this dict by ``--collective`` name
+        self.collectiveFunc.update({
+            "broadcast": self.broadcast, "broadcast_object_list": self.broadcast_object_list, "gather": self.gather,
+            "all_gather": self.all_gather, "all_gather_base": self.all_gather_base,
+            "all_gather_object": self.all_gather_object, "reduce_scatter": self.reduce_scatter,
+            "reduce_scatter_base": self.reduce_scatter_base, "scatter": self.scatter, "incast": self.incast,
+            "multicast": self.multicast, "wait": self.wait, "send": self.send, "recv": self.recv,
+            "isend": self.isend, "irecv": self.irecv, "pt2pt": self.noop,
+        })
         self.computeFunc["emb_lookup"] = self.emb_lookup
 
     # ------------------------------------------------------------------ helpers
@@ -59,90 +72,238 @@ class MI355XBackend(backendFunctions):
     def _group(self, collectiveArgs):
         return collectiveArgs.group if collectiveArgs.group is not None else self.get_default_group()
 
+    get_collective_group = _group   # the reference's name for it (pytorch_dist_backend.py:79)
+
     def _post(self, collectiveArgs, work, retFlag):
-        if collectiveArgs.asyncOp:
+        if collectiveArgs.asyncOp and work is not None:
             collectiveArgs.waitObj.append(work)
         if retFlag:
             return work
         return None
 
-    def sayHello(self, global_rank, local_rank, world_size, master_ip):
+    @staticmethod
+    def _io(collectiveArgs, pair, pairIdx):
+        """(input, output) tensors of the call: the pair-mode twins when ``pair`` (comms.py:392-409)"""
+        if pair:
+            return collectiveArgs.ipTensor_pair[pairIdx], collectiveArgs.opTensor_pair[pairIdx]
+        return collectiveArgs.ipTensor, collectiveArgs.opTensor
+
+    def sayHello(self, *_ignored):
+        """Where each process runs.  The reference drivers call it with no arguments (comms.py:1533, dlrm.py:1350,
+        commsTraceReplay.py:1331; implementation pytorch_dist_backend.py:85-99: every rank posts its line to the
+        TCP store, rank 0 prints them all); positional arguments of the ABC's declared signature
+        (pytorch_backend_utils.py:273-277) are accepted and ignored -- the values are read from the backend itself."""
         myhost = os.uname()[1]
+        global_rank, local_rank, world_size = self.get_global_rank(), self.get_local_rank(), self.get_world_size()
         dev = self.get_device()
-        hw = torch.cuda.get_device_name(dev) if self._is_gpu() and torch.cuda.is_available() else "cpu"
-        print(f"[Rank {global_rank:>3}] host {myhost}, device: {dev} ({hw}), local_rank: {local_rank} "
-              f"world_size: {world_size}, master_ip: {master_ip}")
+        hw = f" ({torch.cuda.get_device_name(dev)})" if self._is_gpu() and torch.cuda.is_available() else ""
+        msg = (f"[Rank {global_rank:3}] host {myhost}, device: {dev}{hw}, local_rank: {local_rank} "
+               f"world_size: {world_size}, master_ip: {self.bootstrap_info.master_ip}")
+        if self.tcp_store is None:
+            print(msg)
+            return
+        self.store_set(f"hello_msg_{global_rank}", msg)
+        if global_rank == 0:
+            for rank in range(world_size):
+                print(f"Hello from Rank {rank}: {self.store_get(f'hello_msg_{rank}').decode()}")
 
     # ------------------------------------------------------------------ collectives
     def all_reduce(self, collectiveArgs, retFlag=False, pair=False, pairIdx=0):
-        work = dist.all_reduce(collectiveArgs.ipTensor, op=collectiveArgs.op or dist.ReduceOp.SUM,
+        ip, _ = self._io(collectiveArgs, pair, pairIdx)
+        work = dist.all_reduce(ip, op=collectiveArgs.op or dist.ReduceOp.SUM,
                                group=self._group(collectiveArgs), async_op=bool(collectiveArgs.asyncOp))
         return self._post(collectiveArgs, work, retFlag)
 
     def reduce(self, collectiveArgs, retFlag=False, pair=False, pairIdx=0):
-        work = dist.reduce(collectiveArgs.ipTensor, dst=collectiveArgs.srcOrDst,
+        ip, _ = self._io(collectiveArgs, pair, pairIdx)
+        work = dist.reduce(ip, dst=collectiveArgs.srcOrDst,
                            op=collectiveArgs.op or dist.ReduceOp.SUM, group=self._group(collectiveArgs),
                            async_op=bool(collectiveArgs.asyncOp))
         return self._post(collectiveArgs, work, retFlag)
 
     def all_to_all(self, collectiveArgs, retFlag=False, pair=False, pairIdx=0):
-        """List-form all_to_all (``opTensor`` / ``ipTensor`` are lists of per-peer tensors), or the
-        fused lookup+all-to-all when batched embedding tables are attached (reference
-        ``pytorch_dist_backend.py:207-260``)."""
-        if collectiveArgs.num_emb_tables_batched > 0 and collectiveArgs.emb is not None:
-            work = self.lookup_all_to_all(collectiveArgs)
-        elif isinstance(collectiveArgs.opTensor, (list, tuple)):
+        """List-form all_to_all (``opTensor`` / ``ipTensor`` are lists of per-peer tensors).  With batched
+        embedding tables attached AND the fused path opted into (``fused_lookup_a2a``; the reference requires its
+        ``extend_distributed`` package for this branch, ``pytorch_dist_backend.py:214``) it is the pipelined
+        lookup -> pooled all-to-all instead."""
+        ip, op = self._io(collectiveArgs, pair, pairIdx)
+        if (not pair and collectiveArgs.num_emb_tables_batched > 0 and collectiveArgs.emb is not None
+                and (self.use_ext_dist or self.fused_lookup_a2a)):
+            return self.lookup_all_to_all(collectiveArgs, retFlag)
+        if isinstance(op, (list, tuple)):
             if dist.get_backend(self._group(collectiveArgs)) == "gloo":
                 # gloo has no list-form alltoall (reference survey probe): flatten to the single-tensor form
-                ip = torch.cat([t.reshape(-1) for t in collectiveArgs.ipTensor])
-                op = torch.empty(sum(t.numel() for t in collectiveArgs.opTensor), dtype=ip.dtype, device=ip.device)
-                w = dist.all_to_all_single(op, ip, [t.numel() for t in collectiveArgs.opTensor],
-                                           [t.numel() for t in collectiveArgs.ipTensor],
-                                           group=self._group(collectiveArgs))
-                assert w is None
+                flat_in = torch.cat([t.reshape(-1) for t in ip])
+                flat_out = torch.empty(sum(t.numel() for t in op), dtype=flat_in.dtype, device=flat_in.device)
+                dist.all_to_all_single(flat_out, flat_in, [t.numel() for t in op], [t.numel() for t in ip],
+                                       group=self._group(collectiveArgs))
                 o = 0
-                for t in collectiveArgs.opTensor:
-                    t.copy_(op[o:o + t.numel()].view_as(t))
+                for t in op:
+                    t.copy_(flat_out[o:o + t.numel()].view_as(t))
                     o += t.numel()
                 work = None
             else:
-                work = dist.all_to_all(collectiveArgs.opTensor, collectiveArgs.ipTensor,
-                                       group=self._group(collectiveArgs), async_op=bool(collectiveArgs.asyncOp))
+                work = dist.all_to_all(op, ip, group=self._group(collectiveArgs), async_op=bool(collectiveArgs.asyncOp))
         else:
-            work = dist.all_to_all_single(collectiveArgs.opTensor, collectiveArgs.ipTensor,
-                                          group=self._group(collectiveArgs), async_op=bool(collectiveArgs.asyncOp))
+            work = dist.all_to_all_single(op, ip, group=self._group(collectiveArgs), async_op=bool(collectiveArgs.asyncOp))
         return self._post(collectiveArgs, work, retFlag)
 
     def all_to_allv(self, collectiveArgs, retFlag=False, pair=False, pairIdx=0):
+        ip, op = self._io(collectiveArgs, pair, pairIdx)
+        if pair:
+            osp, isp = collectiveArgs.opTensor_split_pair[pairIdx], collectiveArgs.ipTensor_split_pair[pairIdx]
+        else:
+            osp, isp = collectiveArgs.opTensor_split, collectiveArgs.ipTensor_split
         work = dist.all_to_all_single(
-            collectiveArgs.opTensor, collectiveArgs.ipTensor,
-            list(collectiveArgs.opTensor_split) if collectiveArgs.opTensor_split is not None and len(collectiveArgs.opTensor_split) else None,
-            list(collectiveArgs.ipTensor_split) if collectiveArgs.ipTensor_split is not None and len(collectiveArgs.ipTensor_split) else None,
+            op, ip, list(osp) if osp is not None and len(osp) else None, list(isp) if isp is not None and len(isp) else None,
             group=self._group(collectiveArgs), async_op=bool(collectiveArgs.asyncOp))
         return self._post(collectiveArgs, work, retFlag)
 
     def all_to_all_single(self, collectiveArgs, retFlag=False, pair=False, pairIdx=0):
-        return self.all_to_allv(collectiveArgs, retFlag)
+        return self.all_to_allv(collectiveArgs, retFlag, pair, pairIdx)
+
+    # The rest of the reference ABC's collective table (pytorch_backend_utils.py:161-180).  Only the all-to-all family is
+    # on the DLRM sparse path, but the reference's own drivers need these to run at all: comms.py gathers every rank's
+    # latencies through ``all_gather`` after each size (comms.py:951), dlrm.py does the same for its report (:1220, :1283).
+    # They are thin c10d calls, as in pytorch_dist_backend.py:359-624.
+    def all_gather(self, collectiveArgs, retFlag=False, pair=False, pairIdx=0):
+        ip, op = self._io(collectiveArgs, pair, pairIdx)
+        work = dist.all_gather(tensor_list=op, tensor=ip, group=self._group(collectiveArgs),
+                               async_op=bool(collectiveArgs.asyncOp))
+        return self._post(collectiveArgs, work, retFlag)
+
+    def all_gather_base(self, collectiveArgs, retFlag=False, pair=False, pairIdx=0):
+        ip, op = self._io(collectiveArgs, pair, pairIdx)
+        work = dist.all_gather_into_tensor(output_tensor=op, input_tensor=ip, group=self._group(collectiveArgs),
+                                           async_op=bool(collectiveArgs.asyncOp))
+        return self._post(collectiveArgs, work, retFlag)
+
+    def all_gather_object(self, collectiveArgs, retFlag=False, pair=False, pairIdx=0):
+        ip, op = self._io(collectiveArgs, pair, pairIdx)
+        dist.all_gather_object(object_list=op, obj=ip, group=self._group(collectiveArgs))
+        return None
+
+    def gather(self, collectiveArgs, retFlag=False, pair=False, pairIdx=0):
+        ip, op = self._io(collectiveArgs, pair, pairIdx)
+        work = dist.gather(gather_list=op if collectiveArgs.global_rank == collectiveArgs.srcOrDst else None, tensor=ip,
+                           dst=collectiveArgs.srcOrDst, group=self._group(collectiveArgs),
+                           async_op=bool(collectiveArgs.asyncOp))
+        return self._post(collectiveArgs, work, retFlag)
+
+    def scatter(self, collectiveArgs, retFlag=False, pair=False, pairIdx=0):
+        ip, op = self._io(collectiveArgs, pair, pairIdx)
+        work = dist.scatter(tensor=op, scatter_list=ip if collectiveArgs.global_rank == collectiveArgs.srcOrDst else None,
+                            src=collectiveArgs.srcOrDst, group=self._group(collectiveArgs),
+                            async_op=bool(collectiveArgs.asyncOp))
+        return self._post(collectiveArgs, work, retFlag)
+
+    def reduce_scatter(self, collectiveArgs, retFlag=False, pair=False, pairIdx=0):
+        ip, op = self._io(collectiveArgs, pair, pairIdx)
+        work = dist.reduce_scatter(output=op, input_list=ip, op=collectiveArgs.op or dist.ReduceOp.SUM,
+                                   group=self._group(collectiveArgs), async_op=bool(collectiveArgs.asyncOp))
+        return self._post(collectiveArgs, work, retFlag)
+
+    def reduce_scatter_base(self, collectiveArgs, retFlag=False, pair=False, pairIdx=0):
+        ip, op = self._io(collectiveArgs, pair, pairIdx)
+        work = dist.reduce_scatter_tensor(output=op, input=ip, op=collectiveArgs.op or dist.ReduceOp.SUM,
+                                          group=self._group(collectiveArgs), async_op=bool(collectiveArgs.asyncOp))
+        return self._post(collectiveArgs, work, retFlag)
+
+    def broadcast(self, collectiveArgs, retFlag=False, pair=False, pairIdx=0):
+        _, op = self._io(collectiveArgs, pair, pairIdx)
+        work = dist.broadcast(tensor=op, src=collectiveArgs.srcOrDst, group=self._group(collectiveArgs),
+                              async_op=bool(collectiveArgs.asyncOp))
+        return self._post(collectiveArgs, work, retFlag)
+
+    def broadcast_object_list(self, collectiveArgs, retFlag=False, pair=False, pairIdx=0):
+        _, op = self._io(collectiveArgs, pair, pairIdx)
+        dist.broadcast_object_list(object_list=op, src=collectiveArgs.srcOrDst, group=self._group(collectiveArgs))
+        return None
+
+    def incast(self, collectiveArgs):
+        """many-to-one: the root posts one irecv per source rank, the sources isend (pytorch_dist_backend.py:554-573)"""
+        if collectiveArgs.global_rank == collectiveArgs.srcOrDst:
+            for idx, src in enumerate(collectiveArgs.src_ranks):
+                collectiveArgs.waitObj.append(dist.irecv(tensor=collectiveArgs.opTensor[idx], src=src,
+                                                         group=self._group(collectiveArgs), tag=0))
+        elif collectiveArgs.global_rank in collectiveArgs.src_ranks:
+            if collectiveArgs.asyncOp:
+                self._isend_to(collectiveArgs, collectiveArgs.srcOrDst)
+            else:
+                dist.send(tensor=collectiveArgs.ipTensor, dst=collectiveArgs.srcOrDst, group=self._group(collectiveArgs), tag=0)
+
+    def multicast(self, collectiveArgs):
+        """one-to-many: the root isends to every destination rank, which recv (pytorch_dist_backend.py:611-624)"""
+        if collectiveArgs.global_rank == collectiveArgs.srcOrDst:
+            for dst in collectiveArgs.dst_ranks:
+                self._isend_to(collectiveArgs, dst)
+        elif collectiveArgs.global_rank in collectiveArgs.dst_ranks:
+            dist.recv(tensor=collectiveArgs.opTensor, src=collectiveArgs.srcOrDst, group=self._group(collectiveArgs), tag=0)
+
+    # point to point (comms.py:573-700 pt2pt benchmarks, trace replay)
+    def send(self, collectiveArgs, retFlag=False, tag=0):
+        dist.send(tensor=collectiveArgs.ipTensor, dst=collectiveArgs.dst_rank, group=self._group(collectiveArgs), tag=tag)
+
+    def recv(self, collectiveArgs, retFlag=False, tag=0):
+        dist.recv(tensor=collectiveArgs.opTensor, src=collectiveArgs.src_rank, group=self._group(collectiveArgs), tag=tag)
+
+    def _isend_to(self, collectiveArgs, dst, tag=0):
+        work = dist.isend(tensor=collectiveArgs.ipTensor, dst=dst, group=self._group(collectiveArgs), tag=tag)
+        collectiveArgs.waitObj.append(work)
+        return work
+
+    def isend(self, collectiveArgs, retFlag=False, tag=0):
+        work = self._isend_to(collectiveArgs, collectiveArgs.dst_rank, tag)
+        return work if retFlag else None
+
+    def irecv(self, collectiveArgs, retFlag=False, tag=0):
+        work = dist.irecv(tensor=collectiveArgs.opTensor, src=collectiveArgs.src_rank, group=self._group(collectiveArgs), tag=tag)
+        collectiveArgs.waitObj.append(work)
+        return work if retFlag else None
+
+    def P2POp(self, collectiveArgs, retFlag=False, tag=0):
+        if collectiveArgs.collective in ("send", "isend"):
+            op, tensor, peer = dist.isend, collectiveArgs.ipTensor, collectiveArgs.dst_rank
+        elif collectiveArgs.collective in ("recv", "irecv"):
+            op, tensor, peer = dist.irecv, collectiveArgs.opTensor, collectiveArgs.src_rank
+        else:
+            raise RuntimeError(f"Unknown operation type {collectiveArgs.collective}")
+        req = dist.P2POp(op=op, tensor=tensor, peer=peer, group=self._group(collectiveArgs), tag=tag)
+        collectiveArgs.p2pOps.append(req)
+        return req if retFlag else None
+
+    def batch_isend_irecv(self, collectiveArgs, retFlag=False):
+        if not collectiveArgs.p2pOps:
+            return
+        reqs = dist.batch_isend_irecv(collectiveArgs.p2pOps)
+        collectiveArgs.p2pOps.clear()
+        collectiveArgs.waitObj.extend(reqs)
 
     def wait(self, collectiveArgs, retFlag=False):
         """With request ids recorded (trace replay: ``waitObjIds[req] = work``) wait on the request named by
         ``collectiveArgs.collectiveId``; otherwise on the FIRST outstanding request only (reference
         ``wait`` / ``complete_single_op``, pytorch_dist_backend.py:724-744)."""
         if collectiveArgs.waitObjIds:
-            w = collectiveArgs.waitObjIds.get(collectiveArgs.collectiveId)
-            if w is not None:
-                w.wait()
+            self._wait_on(collectiveArgs.waitObjIds.get(collectiveArgs.collectiveId))
             return
         if collectiveArgs.waitObj:
-            w = collectiveArgs.waitObj.pop(0)
-            if w is not None:
-                w.wait()
+            self._wait_on(collectiveArgs.waitObj.pop(0))
             self.device_sync(collectiveArgs)
+
+    complete_single_op = wait   # the reference's name for the second form (pytorch_dist_backend.py:724)
+
+    @staticmethod
+    def _wait_on(w):
+        """a work handle, or the list of handles one pipelined lookup -> all-to-all call returns"""
+        if w is None:
+            return
+        for x in (w if isinstance(w, (list, tuple)) else (w,)):
+            if x is not None:
+                x.wait()
 
     def complete_accel_ops(self, collectiveArgs, devSync=True):
         for w in collectiveArgs.waitObj:
-            if w is not None:
-                w.wait()
+            self._wait_on(w)
         if devSync:
             self.device_sync(collectiveArgs)
         collectiveArgs.waitObj.clear()
@@ -173,20 +334,26 @@ class MI355XBackend(backendFunctions):
 
     def emb_lookup(self, collectiveArgs):
         """Batched embedding lookup as the compute kernel (reference ``pytorch_dist_backend.py:832-857``):
-        forward = one HIP launch per op over all of its tables; backward = fused in-place update."""
+        forward = one HIP launch per op over all of its tables; backward = the fused backward + exact row-wise
+        Adagrad step the reference's ``LookupOut.backward`` runs through fbgemm (its TBE ops are built with
+        ``OptimType.EXACT_ROWWISE_ADAGRAD``, comms_utils.py:2014).  Skipped -- as in the reference -- when the
+        lookup is pooled into the all-to-all instead (``all_to_all`` with the fused path on)."""
+        if (collectiveArgs.collective == "all_to_all" and collectiveArgs.num_emb_tables_batched != -1
+                and (self.use_ext_dist or self.fused_lookup_a2a)):
+            return
         if collectiveArgs.direction == "forward":
             for i, (indices, offsets, weights) in enumerate(collectiveArgs.embRequests):
                 collectiveArgs.LookupOut = collectiveArgs.emb[i].forward(indices, offsets, weights)
         else:
             for i, (indices, offsets, weights) in enumerate(collectiveArgs.embRequests):
-                collectiveArgs.emb[i].scatter_add_(collectiveArgs.grad_output, indices, offsets,
-                                                   alpha=-collectiveArgs.emb[i].learning_rate,
-                                                   per_sample_weights=weights)
+                collectiveArgs.emb[i].optimizer_step_(collectiveArgs.grad_output, indices, offsets,
+                                                      per_sample_weights=weights)
 
-    def lookup_all_to_all(self, collectiveArgs):
+    def lookup_all_to_all(self, collectiveArgs, retFlag=False):
         """Pipelined lookup -> pooled all-to-all (reference ``:214-234``): op i's pooled embeddings
-        ``[global_batch, tables_i * D]`` leave through RCCL while op i+1 is being looked up.  Returns the
-        list of work handles (already waited unless ``asyncOp``)."""
+        ``[global_batch, tables_i * D]`` leave through RCCL while op i+1 is being looked up.  Blocking mode waits
+        for every exchange (as the reference does); with ``asyncOp`` the individual work handles join
+        ``collectiveArgs.waitObj``.  Returns the list of handles iff ``retFlag``."""
         works = []
         outs = getattr(collectiveArgs, "a2a_recv", None)
         if outs is None:
@@ -197,20 +364,30 @@ class MI355XBackend(backendFunctions):
             if outs[i] is None or outs[i].shape != pooled.shape:
                 outs[i] = torch.empty_like(pooled)
             works.append(dist.all_to_all_single(outs[i], pooled, group=self._group(collectiveArgs), async_op=True))
-        if not collectiveArgs.asyncOp:
+        if collectiveArgs.asyncOp:
+            collectiveArgs.waitObj.extend(works)
+        else:
             for w in works:
                 w.wait()
-        return works
+        return works if retFlag else None
 
     # ------------------------------------------------------------------ memory
     def get_mem_size(self, collectiveArgs, pair=False, pairIdx=0) -> int:
-        """bytes of the OUTPUT tensor(s) (reference ``:860-897``): the algBW numerator"""
-        op, ip = collectiveArgs.opTensor, collectiveArgs.ipTensor
+        """algBW numerator (reference ``:860-897``): bytes of the OUTPUT tensor(s); of the input list for reduce_scatter
+        and of the input tensor for reduce_scatter_base / reduce_scatter_v; pair mode: of the pair's output"""
+        def nbytes(x):
+            if isinstance(x, (list, tuple)):
+                return sum(t.nelement() * t.element_size() for t in x)
+            return x.nelement() * x.element_size()
+
+        if pair:
+            return nbytes(collectiveArgs.opTensor_pair[pairIdx])
+        ip, op = collectiveArgs.ipTensor, collectiveArgs.opTensor
         if isinstance(op, (list, tuple)):
-            return sum(t.nelement() * t.element_size() for t in op)
-        if isinstance(ip, (list, tuple)):
-            return sum(t.nelement() * t.element_size() for t in ip)
-        return op.nelement() * op.element_size()
+            return nbytes(op)
+        if isinstance(ip, (list, tuple)) or collectiveArgs.collective in ("reduce_scatter_v", "reduce_scatter_base"):
+            return nbytes(ip)
+        return nbytes(op)
 
     def alloc_random(self, sizeArr, curRankDevice="cuda", dtype=torch.float32, scaleFactor=1.0):
         if dtype in (torch.int8, torch.uint8, torch.short, torch.int16, torch.int32, torch.long):
@@ -240,8 +417,10 @@ class MI355XBackend(backendFunctions):
     def alloc_batched_embedding_tables(self, rows, dim, curRankDevice, dtype, layout="bd"):
         from ...embedding_bag import BatchedEmbeddingBagMI355
 
+        # optimizer: what the reference builds its TBE ops with (comms_utils.py:2014)
         return BatchedEmbeddingBagMI355(rows, dim, dtype=dtype, device=curRankDevice, layout=layout,
-                                        init="uniform_dlrm", seed=int(np.random.randint(0, 2**31 - 1)))
+                                        init="uniform_dlrm", seed=int(np.random.randint(0, 2**31 - 1)),
+                                        optimizer="rowwise_adagrad")
 
     def alloc_empty(self, sizeArr, curRankDevice, dtype):
         # the reference's concrete backends take (size, device, dtype) although the ABC says (size, dtype, device)
@@ -293,6 +472,9 @@ class MI355XBackend(backendFunctions):
     def get_num_pgs(self):
         return self.num_pgs
 
+    def get_next_group(self):
+        return next(self.round_robin_group) if self.round_robin_group is not None else self.get_default_group()
+
     def tensor_list_to_numpy(self, tensorList):
         if isinstance(tensorList, list):
             tensorList = [t.cpu().detach().numpy() for t in tensorList]
@@ -334,14 +516,25 @@ class MI355XBackend(backendFunctions):
         if self._is_gpu():
             torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
 
+    def _pg_backend(self, backend: str) -> str:
+        """c10d process-group backend behind ``--backend rccl_xgmi``: RCCL ("nccl" IS RCCL on ROCm) for device
+        tensors; gloo when the driver was started with ``--device cpu`` (host tensors cannot travel over RCCL: this
+        is how the plug-in runs under the reference's unmodified drivers on a box without GPUs -- the committed
+        fixture tests/golden/ref_plugin_rows.json was made that way).  ``PARAM_AMD_PG_BACKEND`` overrides."""
+        forced = os.environ.get("PARAM_AMD_PG_BACKEND")
+        if forced:
+            return forced
+        if backend == BACKEND_NAME or backend in ("rccl", "rocm"):
+            return "nccl" if self._is_gpu() else "gloo"
+        return backend
+
     def initialize_backend(self, master_ip, master_port, backend="nccl", eager_mode=False) -> None:
         """TCPStore rendezvous + init_process_group, as the reference (``:1145-1200``); RCCL needs
         HSA_ENABLE_IPC_MODE_LEGACY=0 for dmabuf IPC (set if absent)."""
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         self.set_device(self.bootstrap_info.local_rank, self.bootstrap_info.global_rank)
         rank, world = self.bootstrap_info.global_rank, self.bootstrap_info.world_size
-        if backend == BACKEND_NAME or backend in ("rccl", "rocm"):
-            backend = "nccl"
+        backend = self._pg_backend(backend)
         if not dist.is_initialized():
             if self.tcp_store is None:
                 self.tcp_store = dist.TCPStore(master_ip, int(master_port), world, is_master=(rank == 0),
@@ -357,7 +550,7 @@ class MI355XBackend(backendFunctions):
             if len(ranks) == self.get_world_size() and not force_new_group:
                 groups[pg_id] = self.get_default_group()
             else:
-                groups[pg_id] = dist.new_group(ranks=ranks, backend="nccl" if backend == BACKEND_NAME else backend)
+                groups[pg_id] = dist.new_group(ranks=ranks, backend=self._pg_backend(backend))
         if groups:
             self.groups = groups
         self.num_pgs = len(self.groups)

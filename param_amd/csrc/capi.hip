@@ -283,7 +283,8 @@ int pm_embbag_check(const pm_embbag_batch* op, int32_t* d_error_count, pm_stream
     int rc = make_params(op, op ? op->weight_dtype : -1, p);
     if (rc != PM_OK) return rc;
     if (!d_error_count) return fail(PM_ERR_INVALID, "d_error_count is NULL");
-    hipError_t h = pm::launch_embbag_check(p, d_error_count, static_cast<hipStream_t>(stream));
+    hipError_t h = pm::launch_embbag_check(p, d_error_count, op->weight_dtype == PM_F32 ? 4 : 8, op->max_dim,
+                                           static_cast<hipStream_t>(stream));
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_check launch");
     return PM_OK;
 }

@@ -80,7 +80,8 @@ __device__ __forceinline__ void block_to_tile(const KParams& p, int& t, int& til
 }
 
 // Stage the tile's offsets (absolute, int64) and -- when the tile's index range fits --
-// its indices (narrowed to int32; rows < 2^31 is checked on the host) and per-sample
+// its indices (narrowed to int32: rows[t] < 2^31 is the caller's contract, verified by pm_embbag_check and
+// by the Python modules) and per-sample
 // weights into LDS with coalesced loads.  Returns true if indices were staged.
 // LDS layout: int64 s_off[bags_per_block + 1] | int32 s_idx[idx_cap] | float s_w[idx_cap]
 template <bool WEIGHTED>
@@ -120,7 +121,7 @@ hipError_t launch_embbag_fwd(const KParams& p, int weight_dtype, int max_dim, in
                              hipStream_t stream);
 hipError_t launch_embbag_fwd_split(const KParams& p, int weight_dtype, int max_dim, hipStream_t stream);
 hipError_t launch_embbag_bwd(const KParams& p, int dst_dtype, int max_dim, hipStream_t stream);
-hipError_t launch_embbag_check(const KParams& p, int32_t* d_err, hipStream_t stream);
+hipError_t launch_embbag_check(const KParams& p, int32_t* d_err, int vec, int max_dim, hipStream_t stream);
 hipError_t launch_fill_random(void* dst, int64_t count, int dtype, int dist, float lo, float hi,
                               uint64_t seed, hipStream_t stream);
 

@@ -7,10 +7,23 @@ namespace {
 // One thread per bag: offsets monotone within [0, N]; every index within [0, rows[t]).
 // torch raises on such inputs on the CPU path the reference runs
 // (train/compute/pt/pytorch_emb.py:40); the hot kernels do not check.
-__global__ void __launch_bounds__(kBlock) embbag_check_kernel(const KParams p, int32_t* err) {
+// Block 0 also validates what the kernels assume about the per-table DEVICE arrays, which the host side of the C ABI
+// cannot see: rows[t] in [1, 2^31) (staged indices are narrowed to int32), dims[t] a multiple of the 16-byte vector and
+// <= max_dim, out_offsets[t] 16-byte aligned, table base pointers 16-byte aligned.
+__global__ void __launch_bounds__(kBlock) embbag_check_kernel(const KParams p, int32_t* err, int vec, int max_dim) {
     const int64_t per_table = p.bag_count;
     const int64_t total = per_table * p.T;
     int bad = 0;
+    if (blockIdx.x == 0) {
+        for (int t = threadIdx.x; t < p.T; t += kBlock) {
+            const int64_t rows = p.rows[t];
+            const int d = p.dims[t];
+            bad += (rows < 1 || rows >= (1LL << 31)) ? 1 : 0;
+            bad += (d < 1 || d % vec != 0 || d > max_dim) ? 1 : 0;
+            bad += (p.out_offsets[t] % 4 != 0) ? 1 : 0;
+            bad += (reinterpret_cast<uintptr_t>(p.tables[t]) % 16 != 0) ? 1 : 0;
+        }
+    }
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total;
          i += static_cast<int64_t>(gridDim.x) * kBlock) {
         const int t = static_cast<int>(i / per_table);
@@ -98,14 +111,15 @@ __global__ void __launch_bounds__(kBlock) fill_random_kernel(void* dst, int64_t 
 
 }  // namespace
 
-hipError_t launch_embbag_check(const KParams& p, int32_t* d_err, hipStream_t stream) {
+hipError_t launch_embbag_check(const KParams& p, int32_t* d_err, int vec, int max_dim, hipStream_t stream) {
     hipError_t rc = hipMemsetAsync(d_err, 0, sizeof(int32_t), stream);
     if (rc != hipSuccess) return rc;
     const int64_t total = p.bag_count * p.T;
-    if (total == 0) return hipSuccess;
     int64_t blocks = (total + kBlock - 1) / kBlock;
+    if (blocks < 1) blocks = 1;   // the per-table checks run even for an empty batch slice
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(embbag_check_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, p, d_err);
+    hipLaunchKernelGGL(embbag_check_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, p, d_err, vec,
+                       max_dim);
     return hipGetLastError();
 }
 

@@ -297,3 +297,117 @@ def trace_replay(rank, world, port, outdir, golden_dir, blocking):
     with open(os.path.join(outdir, f"summary{rank}.json"), "w") as f:
         json.dump({"collLat": {k: len(v) for k, v in bench.collLat.items()}, "stdout": buf.getvalue(),
                    "total_us": bench.totalTraceLatency}, f)
+
+
+def plugin_table_collectives(rank, world, port):
+    """The rest of the reference ABC's collective table (all_gather ... scatter, point-to-point, the pair-mode twins and
+    the reference-driver call forms ``sayHello()`` with no arguments / list work handles in ``waitObj``): data checks."""
+    import contextlib
+    import io
+
+    from param_amd.comms.pt.pytorch_backend_utils import collectiveArgsHolder
+
+    _env(rank, world, port)
+    bf = _backend(rank, world, port)
+    try:
+        ca = collectiveArgsHolder()
+        ca.world_size, ca.global_rank, ca.group, ca.device = world, rank, bf.get_default_group(), bf.get_device()
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            bf.sayHello()                                # the reference drivers pass nothing (comms.py:1533)
+            bf.sayHello(rank, rank, world, "127.0.0.1")  # the ABC's declared form still works
+        if rank == 0:
+            assert buf.getvalue().count("Hello from Rank 1: [Rank   1]") == 2, buf.getvalue()
+        for name in ("all_gather", "all_gather_base", "reduce_scatter", "reduce_scatter_base", "broadcast", "gather", "scatter",
+                     "all_to_all", "all_to_allv", "all_to_all_single", "all_reduce", "reduce", "barrier", "wait", "send", "recv"):
+            assert name in bf.collectiveFunc, name
+        me = torch.arange(3.0) + 10 * rank
+        ca.asyncOp = False
+        # all_gather (what comms.py:951 / dlrm.py:1220 use for their reports)
+        ca.ipTensor, ca.opTensor = me.clone(), [torch.empty(3) for _ in range(world)]
+        ca.collective = "all_gather"
+        bf.collectiveFunc["all_gather"](ca)
+        assert [t.tolist() for t in ca.opTensor] == [[0.0, 1.0, 2.0], [10.0, 11.0, 12.0]]
+        assert bf.get_mem_size(ca) == 4 * 3 * world
+        ca.opTensor = torch.empty(3 * world)
+        bf.all_gather_base(ca)
+        assert ca.opTensor.tolist() == [0.0, 1.0, 2.0, 10.0, 11.0, 12.0]
+        # reduce_scatter (list) / reduce_scatter_base: get_mem_size counts the INPUT (reference :866-877)
+        ca.op = bf.get_reduce_op("sum")
+        ca.ipTensor, ca.opTensor = [torch.ones(2) * (rank + 1 + j) for j in range(world)], torch.empty(2)
+        ca.collective = "reduce_scatter"
+        bf.reduce_scatter(ca)
+        assert ca.opTensor.tolist() == [[3.0, 3.0], [5.0, 5.0]][rank] and bf.get_mem_size(ca) == 16
+        ca.ipTensor, ca.opTensor = torch.arange(4.0) * (rank + 1), torch.empty(2)
+        ca.collective = "reduce_scatter_base"
+        bf.reduce_scatter_base(ca)
+        assert ca.opTensor.tolist() == [[0.0, 3.0], [6.0, 9.0]][rank] and bf.get_mem_size(ca) == 16
+        # broadcast / gather / scatter
+        ca.collective, ca.srcOrDst = "broadcast", 1
+        ca.opTensor = me.clone()
+        bf.broadcast(ca)
+        assert ca.opTensor.tolist() == [10.0, 11.0, 12.0]
+        ca.collective, ca.srcOrDst = "gather", 0
+        ca.ipTensor, ca.opTensor = me.clone(), [torch.empty(3) for _ in range(world)]
+        bf.gather(ca)
+        if rank == 0:
+            assert ca.opTensor[1].tolist() == [10.0, 11.0, 12.0]
+        ca.collective = "scatter"
+        ca.ipTensor, ca.opTensor = [torch.full((2,), float(j)) for j in range(world)], torch.empty(2)
+        bf.scatter(ca)
+        assert ca.opTensor.tolist() == [float(rank)] * 2
+        # point to point, blocking and batched
+        ca.ipTensor, ca.opTensor = me.clone(), torch.empty(3)
+        ca.dst_rank = ca.src_rank = 1 - rank
+        if rank == 0:
+            bf.send(ca)
+            bf.recv(ca)
+        else:
+            bf.recv(ca)
+            bf.send(ca)
+        assert ca.opTensor.tolist() == (torch.arange(3.0) + 10 * (1 - rank)).tolist()
+        ca.p2pOps, ca.opTensor = [], torch.empty(3)
+        ca.collective = "isend"
+        bf.P2POp(ca)
+        ca.collective = "irecv"
+        bf.P2POp(ca)
+        bf.batch_isend_irecv(ca)
+        assert len(ca.waitObj) == 2 and ca.p2pOps == []
+        bf.complete_accel_ops(ca)
+        assert ca.opTensor.tolist() == (torch.arange(3.0) + 10 * (1 - rank)).tolist() and ca.waitObj == []
+        # pair mode (comms.py --pair): the twins' tensors are used, get_mem_size reads the pair's output
+        ca.collective = "all_to_allv"
+        ca.ipTensor_pair, ca.opTensor_pair = [torch.arange(4.0) + 100 * rank], [torch.empty(4)]
+        ca.ipTensor_split_pair, ca.opTensor_split_pair = [[2, 2]], [[2, 2]]
+        bf.all_to_allv(ca, pair=True, pairIdx=0)
+        assert ca.opTensor_pair[0].tolist() == [[0.0, 1.0, 100.0, 101.0], [2.0, 3.0, 102.0, 103.0]][rank]
+        assert bf.get_mem_size(ca, pair=True, pairIdx=0) == 16
+        # a list of work handles in waitObj / waitObjIds (what a pipelined call returns) is waited element-wise
+        ca.asyncOp = True
+        ca.ipTensor, ca.opTensor = torch.ones(2), torch.empty(2)
+        ca.ipTensor_split = ca.opTensor_split = [1, 1]
+        w1 = bf.all_to_allv(ca, retFlag=True)
+        ca.waitObj.clear()
+        ca.waitObj.append([w1])
+        bf.wait(ca)
+        assert ca.waitObj == []
+        bf.sync_barrier(ca)
+    finally:
+        bf.shutdown()
+
+
+def comms_sweep_plugin_fixture(rank, world, port, outdir, argv_json):
+    """this build's comms.py with the argument list of the reference-driver run recorded in ref_plugin_rows.json"""
+    import contextlib
+    import io
+    import json
+
+    from param_amd.comms.pt import comms
+
+    _env(rank, world, port)
+    argv = json.loads(argv_json)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        comms.main(["--master-ip", "127.0.0.1", "--master-port", str(port)] + argv)
+    with open(os.path.join(outdir, f"rank{rank}.txt"), "w") as f:
+        f.write(buf.getvalue())

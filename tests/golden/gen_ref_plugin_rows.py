@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Runs the REFERENCE's unmodified drivers with this build's plug-ins and writes tests/golden/ref_plugin_rows.json.
+Needs /root/reference (build container only); the fixture is data, nothing of the reference travels.
+
+1. ``train/comms/pt/comms.py --backend rccl_xgmi --device cpu`` on 2 gloo ranks with ``MI355XBackend`` registered in the
+   reference's ``customized_backend`` table (this is the command documented there).  The
+   deterministic columns of every COMMS-RES row (collective, dtype, bytes, elements per rank, column count) are stored,
+   after checking that they equal what the reference's OWN backend (``--backend gloo``) prints for the same arguments.
+   Blocking and non-blocking mode, the all-to-all family plus the collectives the driver itself needs (all_gather for
+   its latency report) and the rest of the ABC's table.
+2. ``train/comms/pt/dlrm.py`` with ``dlrm.PyTorchDistBackend`` bound to ``MI355XBackend`` (dlrm.py:1327 hard-codes its
+   backend class: that assignment is the one line a maintainer adds).  The embedding tables are a torch CPU stand-in
+   in THIS script only -- the product lookup has no CPU path -- so what is exercised is every collective of the DLRM
+   iteration through the plug-in: the ``--print-comms`` records must equal tests/golden/dlrm_np2 (made by the reference
+   with its own backend).
+3. ``train/compute/python``: the operator, its input iterator and data generator registered in the reference's
+   registries (param_amd/compute/python/reference_plugin.py); the reference's ``BenchmarkConfig`` resolves its example
+   config to them and the (id, arguments) stream of build and input configs is stored for the host test to replay
+   through this build's own iterator.
+"""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+COMMS_LAUNCH = f'''
+import runpy, sys
+sys.path.insert(0, {REPO!r})
+from param_amd.comms.pt import mi355_backend
+mi355_backend.register()                      # -> param_bench...pytorch_backend_utils.customized_backend["rccl_xgmi"]
+sys.argv[0] = "{REF}/train/comms/pt/comms.py"
+runpy.run_path(sys.argv[0], run_name="__main__")
+'''
+
+DLRM_LAUNCH = f'''
+import argparse, sys
+sys.path.insert(0, {REPO!r})
+import torch
+from param_amd.comms.pt import mi355_backend
+import dlrm
+from param_bench.train.comms.pt import comms_utils
+
+class _HostTables(mi355_backend.MI355XBackend):      # generator-only stand-in: the HIP lookup needs a GPU
+    def alloc_embedding_tables(self, n, m, curRankDevice, dtype):
+        return torch.nn.EmbeddingBag(n, m, mode="sum", sparse=False).to(curRankDevice)
+
+dlrm.PyTorchDistBackend = _HostTables               # dlrm.py:1327 hard-codes the class it instantiates
+mi355_backend.register()
+env = comms_utils.read_comms_env_vars()
+b = dlrm.commsDLRMBench()
+p = argparse.ArgumentParser()
+p.add_argument("--use-device-time", action="store_true", default=False)   # reference bug R1 (SURVEY.md)
+args = b.readArgs(p); b.checkArgs(args); b.initBench(args, env)
+bi = comms_utils.bootstrap_info_holder(args.master_ip, args.master_port, args.num_tpu_cores, env)
+b.runBench(bi, comms_utils.commsDlrmParamsHolder(args, env), args)
+'''
+
+SWEEPS = [
+    {"name": "blocking_a2a_family", "z": "1",
+     "collective": "all_to_allv,all_to_all_single,all_reduce"},
+    {"name": "nonblocking_rest_of_table", "z": "0",
+     "collective": "all_to_allv,all_gather,all_gather_base,reduce_scatter,reduce_scatter_base,broadcast,reduce,gather,scatter"},
+]
+
+
+def run2(work, script, argv, port, pythonpath, stdout=True):
+    env = dict(os.environ, PYTHONPATH=pythonpath, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2",
+               LOCAL_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, script, "--master-ip", "127.0.0.1", "--master-port", str(port)] + argv, cwd=work,
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True) for r in (0, 1)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    return outs[0][0]
+
+
+def rows_of(text):
+    rows = []
+    for ln in text.splitlines():
+        m = re.match(r"\tCOMMS-RES-(\w+)-(\w+)\s+(\d+)\s+(\d+)\s", ln)
+        if m:
+            rows.append({"collective": m.group(1), "dtype": m.group(2), "size": int(m.group(3)),
+                         "elements_per_rank": int(m.group(4)), "columns": len(ln.split())})
+    return rows
+
+
+def main():
+    work = tempfile.mkdtemp()
+    os.makedirs(os.path.join(work, "pb"))
+    os.symlink(REF, os.path.join(work, "pb", "param_bench"))
+    pb = os.path.join(work, "pb")
+    open(os.path.join(work, "comms_launch.py"), "w").write(COMMS_LAUNCH)
+    open(os.path.join(work, "dlrm_launch.py"), "w").write(DLRM_LAUNCH)
+    result = {"comms": [], "dlrm": {}, "compute_python": {}}
+    port = 29581
+
+    # 1. comms.py sweeps: plug-in vs the reference's own backend
+    for sw in SWEEPS:
+        common = ["--b", "64", "--e", "1024", "--f", "4", "--n", "3", "--w", "1", "--z", sw["z"], "--c", "1",
+                  "--collective", sw["collective"], "--device", "cpu"]
+        plug = run2(work, os.path.join(work, "comms_launch.py"), common + ["--backend", "rccl_xgmi"], port, pb)
+        own = run2(work, f"{REF}/train/comms/pt/comms.py", common + ["--backend", "gloo"], port + 1, pb)
+        port += 2
+        assert "Hello from Rank 1" in plug, "sayHello() under the reference driver"
+        r_plug, r_own = rows_of(plug), rows_of(own)
+        assert r_plug and r_plug == r_own, (r_plug, r_own)
+        result["comms"].append({"name": sw["name"], "args": common + ["--backend", "rccl_xgmi"], "rows": r_plug,
+                                "header": [ln for ln in plug.splitlines() if "COMMS-RES" in ln and "total-size" in ln][0]})
+        print(sw["name"], len(r_plug), "rows == reference backend's")
+
+    # 2. dlrm.py with the plug-in's collectives: --print-comms records == the reference's own (dlrm_np2 fixture)
+    flags = ["--backend", "rccl_xgmi", "--device", "cpu", "--mini-batch-size", "8", "--num-batches", "4", "--warmup-batches", "1",
+             "--arch-mlp-bot", "16-8", "--arch-mlp-top", "8-1", "--arch-sparse-feature-size", "8",
+             "--arch-embedding-size", "100-200-300-400", "--num-indices-per-lookup", "5", "--print-comms"]
+    run2(work, os.path.join(work, "dlrm_launch.py"), flags, port, f"{pb}:{REF}/train/comms/pt")
+    for r in (0, 1):
+        got = json.load(open(os.path.join(work, "dlrm_np2", f"rank{r}.json")))
+        exp = json.load(open(os.path.join(HERE, "dlrm_np2", f"rank{r}.json")))
+        assert got == exp, f"rank {r}: records differ from the reference backend's"
+        result["dlrm"][f"rank{r}_records"] = len(got)
+    result["dlrm"]["args"] = flags
+    result["dlrm"]["equal_to_reference_backend_records"] = True
+    print("dlrm.py print-comms records == dlrm_np2 fixture")
+
+    # 3. compute/python registries
+    sys.path.insert(0, pb)
+    sys.path.insert(0, REPO)
+    from param_amd.compute.python.reference_plugin import GENERATOR_NAME, ITERATOR_NAME, OP_NAME, register_in_reference
+    reg = register_in_reference()
+    from param_bench.train.compute.python.lib.config import BenchmarkConfig
+    from param_bench.train.compute.python.lib import pytorch as lib_pytorch
+    from param_bench.train.compute.python.lib.init_helper import load_modules
+    load_modules(lib_pytorch)          # registers "PyTorch:DefaultDataGenerator" (as run_benchmark.py:226 does)
+    cfg_text = json.dumps({OP_NAME: {
+        "build_iterator": "RangeConfigIterator", "input_iterator": ITERATOR_NAME,
+        "build_data_generator": "PyTorch:DefaultDataGenerator", "input_data_generator": GENERATOR_NAME,
+        "config": [{"build": [{"args": [
+            {"type": "int", "name": "num_tables", "value": [1, 2], "__range__": ["value"]},
+            {"type": "int", "name": "rows", "value": 2000}, {"type": "int", "name": "dim", "value": 64},
+            {"type": "int", "name": "pooling", "value": 0}, {"type": "bool", "name": "weighted", "value": False},
+            {"type": "str", "name": "weights_precision", "value": "fp32"}],
+            "kwargs": {"optimizer": {"type": "str", "value": "exact_row_wise_adagrad"}}}],
+            "input": [{"args": [{"type": "int", "name": "batch_size", "value": [4, 8, 4], "__range__": ["value"]},
+                                {"type": "int", "name": "pooling_factor", "value": [3, 5], "__list__": ["value"]}]}]}]}})
+    bc = BenchmarkConfig({"device": "cpu"})
+    bc.load_json(cfg_text)
+    assert len(bc.op_configs) == 1 and bc.op_configs[0].op is reg["operator"]
+    oc = bc.op_configs[0]
+    stream = []
+    import torch
+    for config in oc.info["config"]:
+        for build_id, build_config in oc.build_iterator(config, "build", "cpu"):
+            for input_id, input_config in oc.input_iterator({"build": build_config, "input": config["input"]}, "input", "cpu"):
+                (idx, off, psw), _ = oc.input_data_generator().get_data(input_config, "cpu", alpha=0.25)
+                stream.append({"build_id": build_id, "input_id": input_id,
+                               "build_args": [a["value"] for a in build_config["args"]],
+                               "input_args": [a["value"] for a in input_config["args"]],
+                               "indices_len": int(idx.numel()), "offsets_len": int(off.numel()),
+                               "indices_sum": int(idx.sum()), "offsets_last": int(off[-1]), "psw": psw is not None})
+    result["compute_python"] = {"config": json.loads(cfg_text), "stream": stream, "alpha": 0.25}
+    print("compute/python:", len(stream), "(build, input) configs through the reference's BenchmarkConfig")
+
+    json.dump(result, open(os.path.join(HERE, "ref_plugin_rows.json"), "w"), indent=1)
+    print("wrote ref_plugin_rows.json")
+
+
+if __name__ == "__main__":
+    main()

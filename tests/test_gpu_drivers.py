@@ -98,10 +98,28 @@ def test_backend_embedding_functions_single_rank(coracle):
         ca.num_emb_ops, ca.num_emb_tables_batched, ca.asyncOp, ca.direction = 2, 2, False, "forward"
         bf.emb_lookup(ca)
         assert ca.LookupOut.shape == (8, 128)
+        # the fused lookup -> all_to_all entry is an explicit opt-in (the reference needs extend_distributed for it):
+        # without it a batched-table holder changes nothing about a plain all_to_all call
+        ca.ipTensor, ca.opTensor = torch.arange(4.0, device=DEV), torch.empty(4, device=DEV)
+        bf.all_to_all(ca)
+        assert torch.equal(ca.opTensor, ca.ipTensor) and getattr(ca, "a2a_recv", None) is None
+        bf.fused_lookup_a2a = True
         bf.all_to_all(ca)                     # fused lookup -> all_to_all per op (1 rank: identity exchange)
         bf.complete_accel_ops(ca)
         for i in range(2):
             assert torch.equal(ca.a2a_recv[i], ca.emb[i].lookup(*ca.embRequests[i][:2]))
+        ca.asyncOp = True                     # non-blocking: the individual handles join waitObj, wait() takes them one by one
+        assert bf.all_to_all(ca) is None and len(ca.waitObj) == 2 and all(hasattr(w, "wait") for w in ca.waitObj)
+        bf.wait(ca)
+        assert len(ca.waitObj) == 1
+        bf.complete_accel_ops(ca)
+        assert ca.waitObj == []
+        ca.collective = "all_to_all"          # pooled into the collective: emb_lookup itself is skipped (reference :835-839)
+        ca.LookupOut = None
+        bf.emb_lookup(ca)
+        assert ca.LookupOut is None
+        ca.collective, ca.asyncOp = "", False
+        bf.fused_lookup_a2a = False
         before = ca.emb[0].table(0).clone()
         ca.direction, ca.grad_output = "backward", torch.ones(8, 128, device=DEV)
         bf.emb_lookup(ca)

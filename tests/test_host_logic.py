@@ -186,3 +186,26 @@ def test_range_config_iterator_matches_reference(golden_dir):
               {"args": [{"type": "int", "value": 64}, {"type": "int", "value": 7}]}]
     assert list(tbe_input_iterator(inputs)) == [("0_0", [512, 20]), ("0_1", [512, 50]), ("0_2", [1024, 20]),
                                                 ("0_3", [1024, 50]), ("0_0", [64, 7])]
+
+
+def test_compute_python_stream_equals_reference_registry_run(golden_dir):
+    """ref_plugin_rows.json["compute_python"]: the (build id, input id, arguments, request shape) stream the REFERENCE's
+    BenchmarkConfig produced from a ranged config with this build's operator / iterator / data generator registered in the
+    reference's registries (gen_ref_plugin_rows.py).  This build's own runner pieces produce the same stream."""
+    from param_amd.compute.python.config_iter import BUILD_ITERATORS, tbe_input_iterator
+    from param_amd.compute.python.split_table_batched_embeddings_ops import generate_batched_request
+
+    fx = json.load(open(os.path.join(golden_dir, "ref_plugin_rows.json")))["compute_python"]
+    (op_name, info), = fx["config"].items()
+    assert op_name == "SplitTableBatchedEmbeddingBagsCodegen"
+    mine = []
+    for config in info["config"]:
+        for build_id, build in BUILD_ITERATORS[info["build_iterator"]](config["build"]):
+            b = [a["value"] for a in build["args"]]
+            for input_id, (batch, pooling) in tbe_input_iterator(config["input"]):
+                idx, off, psw = generate_batched_request(b[0], b[1], batch, pooling, fx["alpha"], b[4], "cpu")
+                mine.append({"build_id": build_id, "input_id": input_id, "build_args": b,
+                             "input_args": [b[0], b[1], b[2], batch, pooling, b[4], b[5]],
+                             "indices_len": int(idx.numel()), "offsets_len": int(off.numel()), "indices_sum": int(idx.sum()),
+                             "offsets_last": int(off[-1]), "psw": psw is not None})
+    assert len(mine) == 8 and mine == fx["stream"]
