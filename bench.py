@@ -1,31 +1,47 @@
 #!/usr/bin/env python3
 """bench.py -- EmbeddingBag lookups/s (+ achieved HBM GB/s) on MI355X, 1..8 GPUs.
 
-Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1 under torch.distributed.run,
-one rank per GPU).  W untimed warm-up steps, then exactly K steps bracketed by barrier +
-``torch.cuda.synchronize()``, MAX over ranks, rank 0 prints ONE JSON line.
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1 under torch.distributed.run, one rank per GPU).
+W untimed warm-up steps, then exactly K steps bracketed by barrier + ``torch.cuda.synchronize()``, MAX over ranks,
+rank 0 prints ONE JSON line.
 
 A *step* is one pass of the hot path over one synthetic batch:
-  N == 1 : one batched EmbeddingBag forward launch over all local tables (BASELINE.json
-           configs[1]: 64 tables x 10M rows x 128 dim, fp32, Zipf indices -- 64 fp32 tables are
-           327.68 GB > 288 GB HBM, so one GPU runs the largest table count that fits, 48).
-  N  > 1 : the 64 tables are sharded table-wise (64/N per GPU); every rank looks up the GLOBAL
-           batch (N x 8192 bags) for its tables and the pooled embeddings go back to
-           batch-parallel layout with ONE RCCL all-to-all per table group, issued per group so
-           that it overlaps the next group's lookup (reference dlrm.py:858-878 /
-           pytorch_dist_backend.py:214-234).  Per-GPU work is fixed as N grows ("weak").
+  N == 1 : one batched EmbeddingBag forward launch over all local tables (BASELINE.json configs[1]: 64 tables x 10M rows x
+           128 dim, fp32, Zipf indices -- 64 fp32 tables are 327.68 GB > 288 GB HBM, so one GPU runs the largest table
+           count that fits, 48).
+  N  > 1 : the tables are sharded table-wise with the reference's partition (dlrm.py:390-398; 64 -> 64/N each, the 26
+           tables of configs[3]/[4] -> [4,4,3,3,3,3,3,3] at N = 8); every rank looks up the GLOBAL batch (N x 8192 bags)
+           for its tables and the pooled embeddings go back to batch-parallel layout with ONE RCCL all-to-all on the
+           process group's stream, two steps in flight (the exchange of step k runs under the lookup of step k+1).
+           Per-GPU work is fixed as N grows ("weak").
 
-``value`` = lookups of all ranks / wall time, inputs resident in HBM.  ``roofline`` is the
-forward kernel's ALGORITHMIC bytes (546 B/lookup at D=128 fp32 L=20) over its
-average launch duration measured with HIP events on the launch stream.  ``cpu_baseline`` times
-the reference's CPU engine (torch.nn.EmbeddingBag, pytorch_emb.py:37-45 protocol) and the
-1-core C oracle on a bounded sample on the box's host cores (rank 0, N == 1 only).
+``value`` = lookups of all ranks / wall time of the K timed steps, inputs resident in HBM.
+
+``roofline`` (dominant kernel = the forward lookup): ``frac`` comes from the launch whose ALGORITHMIC bytes ARE memory
+bytes -- the same kernel on the same tables under uniform indices (the roofline-defining run):
+546 B/lookup at D = 128 fp32 L = 20 over its average launch duration (HIP events on the launch stream) over 8 TB/s.  The
+Zipf launch that ``value`` times is served partly by L2, so its algorithmic rate is reported beside it as
+``roofline.zipf.alg_frac`` (may exceed 1) together with the HBM-side fraction from the committed rocprofv3 counter
+profile, labelled with the profile's file name -- counters are never collected inside this run, so ``traffic`` is null
+unless ``--traffic-from-profile`` is given, and then ``traffic_from_profile`` says where the number comes from.
+
+Also timed in the default N == 1 run (BASELINE configs[2]): the deterministic scatter-add backward (key sort + apply,
+apply alone) and the whole fwd + bwd step, under Zipf and under uniform indices.  ``cpu_baseline`` times the reference's
+CPU engine (torch.nn.EmbeddingBag, pytorch_emb.py:37-45 protocol) and the 1-core C oracle on a bounded sample on the
+box's host cores (rank 0, N == 1 only).
+
+N > 1 additionally reports the exchange alone (algBW / busBW with the reference's definitions), the lookup alone, the
+overlap efficiency max(lookup, exchange) / step, and a fwd + bwd training step with BOTH exchanges (pooled embeddings out,
+gradients back: dlrm.py:858-878 and :204-214) pipelined three batches deep.  ``--lookup-cus`` runs the compute stream on
+a CU-masked HIP stream so RCCL's kernels have CUs of their own (the lookup saturates the memory system with 192 of 256).
 """
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -49,21 +65,26 @@ def parse():
     p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--workload", choices=["uniform-tables", "criteo"], default="uniform-tables",
-                   help="criteo: the 26 MLPerf DLRM-v2 tables with per-table multi-hot pooling (BASELINE.json configs[4]), N=1 only")
-    p.add_argument("--tables", type=int, default=64, help="logical table count of the workload")
+                   help="criteo: the 26 MLPerf DLRM-v2 tables with per-table multi-hot pooling (BASELINE.json configs[4])")
+    p.add_argument("--tables", type=int, default=64, help="logical table count of the workload (26 = BASELINE configs[3])")
     p.add_argument("--rows", type=int, default=10_000_000)
     p.add_argument("--dim", type=int, default=128)
     p.add_argument("--batch", type=int, default=8192, help="bags per table per rank")
     p.add_argument("--pooling", type=int, default=20)
     p.add_argument("--alpha", type=float, default=1.05, help="Zipf exponent of the headline run (0 = uniform)")
     p.add_argument("--dtype", choices=sorted(_DT), default="fp32")
-    p.add_argument("--a2a-groups", type=int, default=1, help="N>1: table groups pipelined against the all-to-all inside a step")
-    p.add_argument("--pipeline-depth", type=int, default=2,
-                   help="N>1: steps in flight; 2 = step k's exchange completes under step k+1's lookups (double-buffered)")
+    p.add_argument("--layout", choices=["bd", "tbd"], default="bd",
+                   help="N == 1 output layout: bd = [B, sum D] (TBE / all-to-all send layout), tbd = [T, B, D] (dlrm.py's stack)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--dist-debug", action="store_true", help="run the N>1 (pipeline + RCCL) code path even at world size 1")
-    p.add_argument("--no-uniform", action="store_true", help="skip the extra uniform-index (pure HBM) measurement")
-    p.add_argument("--bwd", action="store_true", help="also time the scatter-add backward (extra field)")
+    p.add_argument("--dist-debug", action="store_true", help="run the N>1 (exchange + RCCL) code path even at world size 1")
+    p.add_argument("--no-uniform", action="store_true", help="skip the uniform-index (roofline-defining) measurement")
+    p.add_argument("--no-bwd", action="store_true", help="skip the backward / fwd+bwd measurements")
+    p.add_argument("--bwd", action="store_true", help="(default now; kept for old command lines)")
+    p.add_argument("--atomic", action="store_true", help="also time the atomic backward kernel (slow: ~15 ms per step)")
+    p.add_argument("--lookup-cus", type=int, default=0,
+                   help="N>1: run lookup / backward on a HIP stream masked to this many CUs (0 = all 256), leaving the rest to RCCL")
+    p.add_argument("--traffic-from-profile", action="store_true",
+                   help="fill roofline.traffic from profiles/pmc_traffic.json (a committed rocprofv3 --pmc result, not this run)")
     p.add_argument("--unroll", type=int, default=0)
     p.add_argument("--bags-per-block", type=int, default=0)
     p.add_argument("--xcd-affine", type=int, default=-1)
@@ -72,8 +93,8 @@ def parse():
 
 
 def time_steps(fn, steps, warmup, barrier):
-    """W warm-ups, then K steps between (barrier + device sync); HIP events on the launch stream
-    give the average device time per step."""
+    """W warm-ups, then K steps between (barrier + device sync); HIP events on the launch stream (torch's current stream:
+    every kernel of the step is launched on it) give the average device time per step."""
     for _ in range(warmup):
         fn()
     barrier()
@@ -90,34 +111,77 @@ def time_steps(fn, steps, warmup, barrier):
     return wall, ev0.elapsed_time(ev1) * 1e-3 / steps
 
 
-def cpu_baseline(table0: torch.Tensor, idx0: torch.Tensor, B: int, L: int, budget_s: float = 12.0):
-    """Reference CPU engine on a bounded sample: ONE table of the workload (same rows/dim/indices
-    as table 0 on the GPU), measure_cpu protocol of pytorch_emb.py:37-45."""
+def masked_stream(n_cus: int, dev):
+    """HIP stream restricted to the first ``n_cus`` CUs (hipExtStreamCreateWithCUMask), wrapped for torch"""
+    hip = ctypes.CDLL("libamdhip64.so")
+    words = (ctypes.c_uint32 * 8)()
+    for i in range(n_cus):
+        words[i // 32] |= 1 << (i % 32)
+    s = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(s), ctypes.c_uint32(8), words)
+    if rc != 0:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed: {rc}")
+    return torch.cuda.ExternalStream(s.value, device=dev)
+
+
+# ---- CPU baseline ------------------------------------------------------------------------------------------------
+def _one_cpu_per_core():
+    """first hardware thread of every physical core this process may run on, grouped by socket"""
+    allowed = sorted(os.sched_getaffinity(0))
+    seen, by_pkg = set(), {}
+    for c in allowed:
+        base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+        try:
+            sib = open(base + "thread_siblings_list").read().strip()
+            pkg = int(open(base + "physical_package_id").read())
+        except OSError:
+            sib, pkg = str(c), 0
+        if sib in seen:
+            continue
+        seen.add(sib)
+        by_pkg.setdefault(pkg, []).append(c)
+    return by_pkg
+
+
+def cpu_baseline(table0: torch.Tensor, idx0: torch.Tensor, B: int, L: int, budget_s: float = 16.0):
+    """Reference CPU engine on a bounded sample: ONE table of the workload (same rows / dim / indices as table 0 on the
+    GPU), measure_cpu protocol of pytorch_emb.py:37-45.  Per mode: threads pinned (one per physical core, by socket),
+    3 discarded warm-up steps, then 3 repeats of a fixed step count; the mode's figure is the MEDIAN repeat, ``value`` is the
+    best mode (named in ``sample``)."""
     from param_amd.compute.pt.pytorch_emb import measure_cpu
 
     W = table0.float().cpu()
     idx = idx0.cpu()
     off = torch.arange(B, dtype=torch.int64) * L
     emb = torch.nn.EmbeddingBag(W.shape[0], W.shape[1], mode="sum", _weight=W)
-    res = {}
-    nthreads = torch.get_num_threads()
     lookups = B * L
-
-    def run(tag, threads, no_grad, budget):
-        torch.set_num_threads(threads)
-        ctx = torch.no_grad() if no_grad else torch.enable_grad()
-        with ctx:
-            t1, _ = measure_cpu(1, 1, emb, idx, off)
-            steps = max(2, min(200, int(budget / max(t1, 1e-4))))
-            el, _ = measure_cpu(1, steps, emb, idx, off)
-        res[tag] = {"lookups_per_s": lookups * steps / el, "s_per_step": el / steps, "threads": threads, "steps": steps}
-
-    with torch.no_grad():  # discarded: first touch of the table pages + thread-pool spin-up
-        measure_cpu(1, 3, emb, idx, off)
-    run("all_threads_no_grad", nthreads, True, budget_s * 0.4)
-    run("all_threads_grad_on_param_default", nthreads, False, budget_s * 0.2)
-    run("one_thread_no_grad", 1, True, budget_s * 0.2)
-    torch.set_num_threads(nthreads)
+    saved_aff = os.sched_getaffinity(0)
+    saved_threads = torch.get_num_threads()
+    by_pkg = _one_cpu_per_core()
+    all_cores = sorted(c for v in by_pkg.values() for c in v)
+    one_socket = sorted(by_pkg[min(by_pkg)])
+    modes = [("all_cores_no_grad", all_cores, True), ("all_cores_grad_on_param_default", all_cores, False),
+             ("one_socket_no_grad", one_socket, True), ("one_thread_no_grad", all_cores[:1], True)]
+    per_mode = budget_s / len(modes)
+    res = {}
+    try:
+        for tag, cpus, no_grad in modes:
+            os.sched_setaffinity(0, set(cpus))
+            torch.set_num_threads(len(cpus))
+            ctx = torch.no_grad() if no_grad else torch.enable_grad()
+            with ctx:
+                t3, _ = measure_cpu(0, 3, emb, idx, off)                      # warm-ups: pool spin-up, first touch, caches
+                steps = max(3, min(300, int(per_mode / 4 / max(t3 / 3, 1e-5))))
+                reps = []
+                for _ in range(3):
+                    el, _ = measure_cpu(0, steps, emb, idx, off)
+                    reps.append(el / steps)
+            med = statistics.median(reps)
+            res[tag] = {"lookups_per_s": lookups / med, "s_per_step": med, "threads": len(cpus), "steps": steps,
+                        "repeats_s_per_step": reps, "spread": (max(reps) - min(reps)) / med}
+    finally:
+        os.sched_setaffinity(0, saved_aff)
+        torch.set_num_threads(saved_threads)
     # 1-core C oracle ("port") on a smaller slice of the same request
     try:
         from oracle.embbag_oracle import COracle
@@ -125,26 +189,29 @@ def cpu_baseline(table0: torch.Tensor, idx0: torch.Tensor, B: int, L: int, budge
         nb = min(B, 2048)
         orc = COracle()
         Wn, In, On = W.numpy(), idx[: nb * L].numpy(), off[:nb].numpy()
+        orc.fwd(Wn, In, On)
         t0 = time.perf_counter()
         orc.fwd(Wn, In, On)
         res["c_oracle_1core"] = {"lookups_per_s": nb * L / (time.perf_counter() - t0), "bags": nb}
     except Exception as exc:  # the checker is optional for the baseline leg
         res["c_oracle_1core"] = {"error": str(exc)}
-    best = res["all_threads_no_grad"]
+    best_tag = max((t for t, _, _ in modes), key=lambda t: res[t]["lookups_per_s"])
+    best = res[best_tag]
     return {
-        "value": best["lookups_per_s"], "unit": "lookups/s", "cores": nthreads, "kind": "port",
-        "sample": (f"torch.nn.EmbeddingBag(sum) on host, 1 table {W.shape[0]}x{W.shape[1]} fp32, batch {B}, "
-                   f"pool {L}, same indices as GPU table 0, {best['steps']} steps after 1 warm-up, "
-                   f"{nthreads} threads, no_grad (reference engine + its measure_cpu protocol)"),
-        "host_cpu_count": os.cpu_count(), "modes": res,
+        "value": best["lookups_per_s"], "unit": "lookups/s", "cores": best["threads"], "kind": "port",
+        "sample": (f"torch.nn.EmbeddingBag(sum) on host (the engine the reference calls, its measure_cpu protocol), 1 table "
+                   f"{W.shape[0]}x{W.shape[1]} fp32, batch {B}, pool {L}, same indices as GPU table 0; best of 4 modes = "
+                   f"{best_tag}: {best['threads']} pinned threads, median of 3 x {best['steps']} steps after 3 warm-ups"),
+        "best_mode": best_tag, "host_cpu_count": os.cpu_count(), "physical_cores": len(all_cores),
+        "sockets": len(by_pkg), "modes": res,
     }
 
 
+# ---- main --------------------------------------------------------------------------------------------------------------
 def main():
     a = parse()
-    # stdout must carry exactly ONE JSON line: RCCL prints a version banner to the C-level stdout and
-    # torch may warn there too, so fd 1 is pointed at stderr for the whole run and the JSON line goes
-    # to a private duplicate of the original stdout.
+    # stdout must carry exactly ONE JSON line: RCCL prints a version banner to the C-level stdout and torch may warn there
+    # too, so fd 1 is pointed at stderr for the whole run and the JSON line goes to a private duplicate of the original.
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
@@ -170,86 +237,133 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def rank_max(*vals):
+        if dist is None:
+            return list(vals)
+        t = torch.tensor(vals, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.tolist()
+
+    def rank_sum(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.item()
+
     param_amd.load_library()  # fail loudly before allocating anything
     param_amd.set_tuning(a.unroll, a.bags_per_block, a.xcd_affine, a.nt_loads)
     dtype = _DT[a.dtype]
     esize = torch.empty(0, dtype=dtype).element_size()
     D, R, L, B_local = a.dim, a.rows, a.pooling, a.batch
 
-    # ---- shard the tables -------------------------------------------------------------------
-    free, total = torch.cuda.mem_get_info()
-    table_bytes = R * D * esize
-    if world == 1:
-        fit = int((free - (40 << 30)) // table_bytes)  # headroom for outputs, gradients, sort scratch
-        T_loc = min(a.tables, fit)
-        if T_loc >= 8:
-            T_loc = T_loc // 8 * 8  # keep the XCD-affine mapping (table t -> XCD t % 8)
-    else:
-        assert a.tables % world == 0, "table count must divide over ranks"
-        T_loc = a.tables // world
-    assert T_loc >= 1, "not enough HBM for one table"
-    B_glob = B_local * world  # table-wise sharding: every rank serves the global batch for its tables
-    rows_list, pool_list = [R] * T_loc, [L] * T_loc
+    # ---- the workload's tables, and this rank's shard ---------------------------------------------------------
+    from param_amd.comms.pt.pipeline import ShardedEmbeddingExchange, table_split
+
     if a.workload == "criteo":
         from param_amd.compute.pt import dataset as ds
 
-        assert not multi, "--workload criteo is a single-GPU configuration of bench.py"
-        rows_list, pool_list, D = list(ds.criteo_v2_rows), list(ds.criteo_v2_multi_hot), ds.criteo_v2_dim
-        T_loc, a.tables = len(rows_list), len(rows_list)
+        all_rows, all_pool, D = list(ds.criteo_v2_rows), list(ds.criteo_v2_multi_hot), ds.criteo_v2_dim
+        a.tables = len(all_rows)
+    else:
+        all_rows, all_pool = [R] * a.tables, [L] * a.tables
+    free, total = torch.cuda.mem_get_info()
+    if world == 1:
+        if a.workload == "criteo":
+            T_loc = a.tables
+        else:
+            fit = int((free - (40 << 30)) // (R * D * esize))  # headroom for outputs, gradients, sort scratch
+            T_loc = min(a.tables, fit)
+            if T_loc >= 8:
+                T_loc = T_loc // 8 * 8  # keep the XCD-affine mapping (table t -> XCD t % 8)
+        split = [T_loc]
+    else:
+        split = table_split(a.tables, world)          # reference partition (dlrm.py:390-398); uneven when T % W != 0
+        T_loc = split[rank]
+    assert T_loc >= 1, "not enough HBM for one table / more ranks than tables"
+    first = sum(split[:rank])
+    rows_list, pool_list = all_rows[first:first + T_loc], all_pool[first:first + T_loc]
+    widths = [s * D for s in split]
+    B_glob = B_local * world  # table-wise sharding: every rank serves the global batch for its tables
+    table_bytes = R * D * esize
 
-    model = param_amd.BatchedEmbeddingBagMI355(rows_list, D, dtype=dtype, device=dev, init="normal",
+    model = param_amd.BatchedEmbeddingBagMI355(rows_list, D, dtype=dtype, device=dev, init="normal", layout=a.layout if not multi else "bd",
                                                seed=1000 + rank, fused_update=False)
-    groups = 1 if not multi else max(1, min(a.a2a_groups, T_loc))
-    while T_loc % groups:
-        groups -= 1
-    Tg = T_loc // groups
 
     def make_request(alpha, seed):
-        return tbe_request(rows_list, B_glob, pool_list if a.workload == "criteo" else L, alpha=alpha, device=dev,
-                           seed=seed + 17 * rank)
+        return tbe_request(rows_list, B_glob, pool_list, alpha=alpha, device=dev, seed=seed + 17 * rank)
 
     idx, off = make_request(a.alpha, 1)
     lookups_step_rank = B_glob * sum(pool_list)
+    lookups_step_all = rank_sum(lookups_step_rank)
     # SURVEY 8d per-unit figures summed over tables: per lookup D*e + 8 read, per bag 8 read + D*4 written
     alg_bytes = sum(algorithmic_bytes(1, B_glob, Lt, D, esize) for Lt in pool_list)
+    bwd_bytes = lookups_step_rank * (2 * D * esize + 8) + T_loc * B_glob * (D * 4 + 8)
+    n_sub = max(5, a.steps // 2)   # steps of the secondary measurements
 
-    # ---- the step ---------------------------------------------------------------------------
+    compute_stream = None
+    if multi and a.lookup_cus > 0:
+        compute_stream = masked_stream(a.lookup_cus, dev)
+        torch.cuda.set_stream(compute_stream)      # lookups, backward and the c10d stream hand-offs all key on it
+
+    # ---- the step ---------------------------------------------------------------------------------------------
+    out_shape = (B_glob, T_loc * D) if (multi or a.layout == "bd") else (T_loc, B_glob, D)
     if not multi:
-        out = torch.empty((B_glob, T_loc * D), dtype=torch.float32, device=dev)
+        out = torch.empty(out_shape, dtype=torch.float32, device=dev)
 
         def step(i=idx, o=off):
             model.lookup(i, o, out=out, batch=B_glob)
+
+        def lookup_only(i=idx, o=off):
+            step(i, o)
     else:
-        from param_amd.comms.pt.pipeline import LookupAllToAll, split_request_by_group
-        from param_amd.embedding_bag import _TableSet, _fwd
+        def hip_lookup(i, o, out_t):
+            model.lookup(i, o, out=out_t, batch=B_glob)
 
-        tsets = [_TableSet([model.table(g * Tg + t) for t in range(Tg)], "bd") for g in range(groups)]
+        def hip_backward(g, i, o):
+            model.scatter_add_(g, i, o, alpha=-1e-6, batch=B_glob)   # key sort + deterministic apply
 
-        def hip_lookup(g, ig, og, out_g):  # the HIP batched forward of table group g
-            _fwd(tsets[g], ig, og, B_glob, out=out_g)
+        ex = ShardedEmbeddingExchange(hip_lookup, hip_backward, world, rank, B_local, widths, dev)
+        fwd_pending = [None, None]
+        kstep = [0]
 
-        # lookup(g) -> RCCL all_to_all(g) on the process group's own stream, under lookup(g+1)
-        pipe = LookupAllToAll(hip_lookup, world, B_local, [Tg * D] * groups, dev, depth=a.pipeline_depth)
+        def step(i=idx, o=off):
+            # two steps in flight: slot s's previous exchange (step k-2) must be done before its send buffer is rewritten
+            s = kstep[0] % 2
+            if fwd_pending[s] is not None:
+                fwd_pending[s].wait()
+            hip_lookup(i, o, ex.pooled[s])
+            fwd_pending[s] = ex.fwd_a2a(s)
+            kstep[0] += 1
 
-        def split_request(i, o):
-            return split_request_by_group(i, o, T_loc, groups, B_glob)
+        def flush():
+            for s in (0, 1):
+                if fwd_pending[s] is not None:
+                    fwd_pending[s].wait()
+                    fwd_pending[s] = None
 
-        reqs = split_request(idx, off)
-
-        def step(rq=None):
-            pipe.step(reqs if rq is None else rq)
+        def lookup_only(i=idx, o=off):
+            hip_lookup(i, o, ex.pooled[0])
 
     wall, dev_s = time_steps(step, a.steps, a.warmup, barrier)   # the closing device sync covers exchanges still in flight
     if multi:
-        pipe.flush()
-    if dist is not None:
-        t = torch.tensor([wall, dev_s], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, dev_s = t.tolist()
+        flush()
+    wall, dev_s = rank_max(wall, dev_s)
 
+    wl = (f"batched EmbeddingBag(sum) fwd, {a.tables} tables x {R} rows x {D} dim {a.dtype}, batch {B_local}/rank, pool {L}, "
+          if a.workload != "criteo" else
+          f"batched EmbeddingBag(sum) fwd, MLPerf DLRM-v2 Criteo tables (26 tables, {sum(all_rows)} rows, dim {D}, {a.dtype}), "
+          f"batch {B_local}/rank, multi-hot pooling {sum(all_pool)} lookups/sample, ")
+    wl += f"Zipf alpha={a.alpha} (reference pmf, per-bag dedupe)"
+    if world == 1 and T_loc < a.tables:
+        wl += (f"; 1 GPU holds {T_loc} of {a.tables} tables ({T_loc * table_bytes / 1e9:.1f} GB): "
+               f"{a.tables} x {table_bytes / 1e9:.2f} GB exceeds 288 GB HBM")
+    if world > 1:
+        wl += (f"; table-wise sharded {split} tables/GPU (dlrm.py:390-398), global batch {B_glob}, one pooled all-to-all per "
+               f"step on the RCCL stream, 2 steps in flight (exchange of step k under the lookup of step k+1)")
     result = {
         "metric": "EmbeddingBag lookups/s + achieved HBM GB/s; all-to-all bus-BW at 1/2/4/8 GPU",
-        "value": lookups_step_rank * world * a.steps / wall,
+        "value": lookups_step_all * a.steps / wall,
         "unit": "lookups/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": wall / a.steps * 1e3,
@@ -257,132 +371,158 @@ def main():
         "dtype": {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}[a.dtype],
         "data": "synthetic",
         "config": {
-            "workload": ((f"batched EmbeddingBag(sum) fwd, {a.tables} tables x {R} rows x {D} dim {a.dtype}, "
-                          f"batch {B_local}/rank, pool {L}, " if a.workload != "criteo" else
-                          f"batched EmbeddingBag(sum) fwd, MLPerf DLRM-v2 Criteo tables (26 tables, {sum(rows_list)} rows, "
-                          f"dim {D}, {a.dtype}), batch {B_local}, multi-hot pooling {sum(pool_list)} lookups/sample, ")
-                         + f"Zipf alpha={a.alpha} (reference pmf, per-bag dedupe)"
-                         + (f"; 1 GPU holds {T_loc} of {a.tables} tables ({T_loc * table_bytes / 1e9:.1f} GB): "
-                            f"{a.tables} x {table_bytes / 1e9:.2f} GB exceeds 288 GB HBM" if world == 1 and T_loc < a.tables else "")
-                         + (f"; table-wise sharded {T_loc}/GPU, global batch {B_glob}, pooled all-to-all in "
-                            f"{groups} table group(s), {a.pipeline_depth} step(s) in flight (exchange of step k under the "
-                            f"lookups of step k+1)" if world > 1 else "")),
-            "tables_total": a.tables if world > 1 else T_loc, "tables_per_gpu": T_loc,
+            "workload": wl,
+            "tables_total": a.tables if world > 1 else T_loc, "tables_per_gpu": split if world > 1 else T_loc,
             "rows": R if a.workload != "criteo" else "criteo_v2 (3 .. 40M rows, 204.2 M total)", "dim": D,
-            "batch_per_rank": B_local, "global_batch": B_glob, "pooling": L, "alpha": a.alpha,
-            "index_dtype": "int64", "parallelism": "1gpu" if world == 1 else f"table-wise x{world} + all-to-all",
-            "lookups_per_step": lookups_step_rank * world,
+            "batch_per_rank": B_local, "global_batch": B_glob, "pooling": L if a.workload != "criteo" else "criteo_v2 multi-hot",
+            "alpha": a.alpha, "index_dtype": "int64", "output_layout": "[B, sum D]" if (multi or a.layout == "bd") else "[T, B, D]",
+            "parallelism": "1gpu" if world == 1 else f"table-wise x{world} + all-to-all",
+            "lookups_per_step": lookups_step_all,
         },
     }
 
-    # roofline of the dominant kernel (forward lookup): algorithmic bytes / avg launch duration
+    # ---- roofline of the dominant kernel (forward lookup) ---------------------------------------------------
     if not multi:
-        kern_s = dev_s
+        zipf_s = dev_s
     else:  # time the lookups alone (no a2a) for the kernel roofline
-        _, kern_s = time_steps(lambda: pipe.lookups_only(reqs), max(5, a.steps // 2), 2, barrier)
-        if dist is not None:
-            t = torch.tensor([kern_s], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            kern_s = t.item()
-    ach = alg_bytes / kern_s / 1e9
-    traffic = None
+        _, zipf_s = time_steps(lookup_only, n_sub, 2, barrier)
+        zipf_s, = rank_max(zipf_s)
+    uni_s = None
+    if not a.no_uniform and a.alpha != 0.0:
+        ui, uo = make_request(0.0, 2)
+        _, uni_s = time_steps(lambda: lookup_only(ui, uo), n_sub, 2, barrier)
+        uni_s, = rank_max(uni_s)
+    elif a.alpha == 0.0:
+        ui, uo, uni_s = idx, off, zipf_s
+    zipf_alg = alg_bytes / zipf_s / 1e9
+    prof = {}
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    key = f"T{T_loc}_R{R}_D{D}_B{B_local}_L{L}_a{a.alpha}_{a.dtype}" if a.workload != "criteo" else "criteo"
     if world == 1 and os.path.exists(pmc_path):
         try:
-            pm = json.load(open(pmc_path))
-            key = f"T{T_loc}_R{R}_D{D}_B{B_local}_L{L}_a{a.alpha}_{a.dtype}" if a.workload != "criteo" else "criteo"
-            traffic = pm.get(key, {}).get("hbm_bytes_per_launch")
+            prof = json.load(open(pmc_path)).get(key, {})
         except Exception:
-            traffic = None
-    result["roofline"] = {
-        "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-        "traffic": traffic, "kernel": "embbag_fwd_kernel", "algorithmic_bytes_per_launch": alg_bytes,
-        "bytes_per_lookup": alg_bytes / lookups_step_rank, "avg_launch_s": kern_s,
-        "lookups_per_s_kernel": lookups_step_rank / kern_s,
-    }
+            prof = {}
+    roof = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s", "kernel": "embbag_fwd_kernel",
+            "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_lookup": alg_bytes / lookups_step_rank}
+    if uni_s is not None:
+        roof.update({
+            "achieved": alg_bytes / uni_s / 1e9, "frac": alg_bytes / uni_s / 1e9 / HBM_PEAK_GBPS,
+            "run": "uniform indices (alpha = 0): no reuse possible, algorithmic bytes == HBM bytes (the roofline-defining run); "
+                   "same kernel, tables and shape as the Zipf launch `value` times",
+            "avg_launch_s": uni_s, "lookups_per_s_kernel": lookups_step_rank / uni_s})
+    else:
+        roof.update({"achieved": None, "frac": None, "run": "uniform run skipped (--no-uniform): no roofline fraction reported"})
+    roof["zipf"] = {
+        "avg_launch_s": zipf_s, "lookups_per_s_kernel": lookups_step_rank / zipf_s, "algorithmic_GBps": zipf_alg,
+        "alg_frac": zipf_alg / HBM_PEAK_GBPS,
+        "note": "hot rows are served by L2, so algorithmic bytes exceed HBM bytes: alg_frac is a cache-assisted rate, not a roofline fraction",
+        "hbm_side_frac": (prof["hbm_bytes_per_launch"] / zipf_s / 1e9 / HBM_PEAK_GBPS) if prof.get("hbm_bytes_per_launch") else None,
+        "hbm_side_frac_source": ("profiles/pmc_traffic.json[%s] (rocprofv3 --pmc bytes of a committed profile) / this run's launch time" % key)
+        if prof.get("hbm_bytes_per_launch") else None}
+    roof["traffic"] = None   # PMC counters are not collected inside a bench run (separate rocprofv3 --pmc passes: profiles/)
+    if a.traffic_from_profile and world == 1 and os.path.exists(pmc_path):
+        ukey = f"T{T_loc}_R{R}_D{D}_B{B_local}_L{L}_a0.0_{a.dtype}"
+        uprof = json.load(open(pmc_path)).get(ukey, {})
+        if uprof.get("hbm_bytes_per_launch"):
+            roof["traffic"] = uprof["hbm_bytes_per_launch"]
+            roof["traffic_from_profile"] = f"profiles/pmc_traffic.json[{ukey}] <- {uprof.get('source')}"
+    result["roofline"] = roof
+    if uni_s is not None:   # kept for readers of round-1 lines
+        result["uniform"] = {"lookups_per_s": lookups_step_all / uni_s,
+                             "achieved_GBps": alg_bytes / uni_s / 1e9, "frac": alg_bytes / uni_s / 1e9 / HBM_PEAK_GBPS,
+                             "avg_launch_s": uni_s}
 
+    # ---- N > 1: the exchange alone, overlap, and the fwd + bwd training step ------------------------------------
     if multi:
-        a2a_bytes = world * B_local * T_loc * D * 4  # output tensor bytes per rank (reference memSize)
-        _, a2a_s = time_steps(pipe.all_to_all_only, max(5, a.steps // 2), 2, barrier)
-        t = torch.tensor([a2a_s], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        a2a_s = t.item()
+        a2a_bytes = ex.bytes_per_rank()  # output tensor bytes per rank (reference memSize)
+
+        def a2a_only():
+            ex.fwd_a2a(0).wait()
+
+        _, a2a_s = time_steps(a2a_only, n_sub, 2, barrier)
+        a2a_s, = rank_max(a2a_s)
         alg_bw = a2a_bytes / a2a_s / 1e9
         result["all_to_all"] = {
             "bytes_per_rank": a2a_bytes, "avg_s": a2a_s, "algbw_GBps": alg_bw,
-            "busbw_GBps": alg_bw * (world - 1) / world,  # pytorch_backend_utils.py:221-234
-            "xgmi_bound_GBps": (world - 1) * 153.0, "overlap_step_s": dev_s, "lookup_only_s": kern_s,
-        }
+            "busbw_GBps": alg_bw * (world - 1) / max(world, 1),  # pytorch_backend_utils.py:221-234
+            "xgmi_bound_GBps": (world - 1) * 153.0}
+        result["overlap"] = {"step_s": dev_s, "lookup_only_s": zipf_s, "all_to_all_only_s": a2a_s,
+                             "overlap_eff": max(zipf_s, a2a_s) / dev_s, "serial_s": zipf_s + a2a_s,
+                             "lookup_cus": a.lookup_cus or 256,
+                             "definition": "max(lookup, exchange) / pipelined step: 1.0 = the shorter of the two is fully hidden"}
+        if not a.no_bwd:
+            def bwd_a2a_only():
+                ex.bwd_a2a(0).wait()
 
-    # extra: uniform indices = no cache help, the pure-HBM run (SURVEY.md 8d "roofline-defining run")
-    if not a.no_uniform and a.alpha != 0.0:
-        ui, uo = make_request(0.0, 2)
-        if not multi:
-            _, us = time_steps(lambda: step(ui, uo), max(5, a.steps // 2), 2, barrier)
-        else:
-            ur = split_request(ui, uo)
-            _, us = time_steps(lambda: pipe.lookups_only(ur), max(5, a.steps // 2), 2, barrier)
-        if dist is not None:
-            t = torch.tensor([us], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            us = t.item()
-        result["uniform"] = {"lookups_per_s": lookups_step_rank * world / us, "achieved_GBps": alg_bytes / us / 1e9,
-                             "frac": alg_bytes / us / 1e9 / HBM_PEAK_GBPS, "avg_launch_s": us}
-        del ui, uo
+            def compute_only():
+                hip_lookup(idx, off, ex.pooled[0])
+                hip_backward(ex.grad[0], idx, off)
 
-    if a.bwd and world == 1:
-        grad = torch.randn((B_glob, T_loc * D), dtype=torch.float32, device=dev)
-        bwd_bytes = lookups_step_rank * (2 * D * esize + 8) + T_loc * B_glob * (D * 4 + 8)
-        n_b = max(5, a.steps // 2)
-        _, bs = time_steps(lambda: model.scatter_add_(grad, idx, off, alpha=-1e-6, batch=B_glob), n_b, 2, barrier)
-        model.sort_indices(idx, off, batch=B_glob)
-        _, ba = time_steps(lambda: model.scatter_add_(grad, idx, off, alpha=-1e-6, batch=B_glob, presorted=True),
-                           n_b, 2, barrier)
-        _, bt = time_steps(lambda: model.scatter_add_(grad, idx, off, alpha=-1e-6, batch=B_glob, method="atomic"),
-                           3, 1, barrier)
-        result["bwd_scatter_add"] = {
-            "method": "sorted (stable radix sort of (table,row) keys + one read-modify-write per touched row, no atomics)",
-            "lookups_per_s": lookups_step_rank / bs, "achieved_GBps": bwd_bytes / bs / 1e9,
-            "frac": bwd_bytes / bs / 1e9 / HBM_PEAK_GBPS, "avg_s_sort_plus_apply": bs, "avg_s_apply_only": ba,
-            "apply_only_GBps": bwd_bytes / ba / 1e9, "apply_only_frac": bwd_bytes / ba / 1e9 / HBM_PEAK_GBPS,
-            "bytes_per_lookup": bwd_bytes / lookups_step_rank,
-            "atomic_kernel_s": bt, "atomic_kernel_frac": bwd_bytes / bt / 1e9 / HBM_PEAK_GBPS}
+            for _ in range(3):
+                ex.step(idx, off)
+            ex.drain()
+            _, fb = time_steps(lambda: ex.step(idx, off), n_sub, 2, barrier)
+            ex.drain()
+            _, fs = time_steps(lambda: ex.step_serial(idx, off), max(3, n_sub // 2), 1, barrier)
+            _, cs = time_steps(compute_only, n_sub, 2, barrier)
+            _, bs = time_steps(bwd_a2a_only, n_sub, 2, barrier)
+            fb, fs, cs, bs = rank_max(fb, fs, cs, bs)
+            result["fwd_bwd_step"] = {
+                "what": "lookup -> pooled all-to-all -> gradient all-to-all -> key sort + deterministic scatter-add, 3 batches in "
+                        "flight: compute stream runs lookup(k) + backward(k-2), RCCL stream runs fwd_a2a(k) + bwd_a2a(k-1)",
+                "avg_s_pipelined": fb, "avg_s_serial": fs, "compute_only_s": cs, "exchanges_only_s": a2a_s + bs,
+                "bwd_all_to_all_s": bs, "overlap_eff": max(cs, a2a_s + bs) / fb,
+                "lookups_per_s": lookups_step_all / fb, "bytes_per_lookup": (alg_bytes + bwd_bytes) / lookups_step_rank,
+                "algorithmic_GBps_per_gpu": (alg_bytes + bwd_bytes) / fb / 1e9}
+
+    # ---- N == 1: backward and the fwd + bwd step (BASELINE configs[2]) ---------------------------------------------
+    if not multi and not a.no_bwd:
+        grad = torch.randn(out_shape, dtype=torch.float32, device=dev)
+
+        def bwd_block(i, o, tag, uniform):
+            _, bs = time_steps(lambda: model.scatter_add_(grad, i, o, alpha=-1e-6, batch=B_glob), n_sub, 2, barrier)
+            model.sort_indices(i, o, batch=B_glob)
+            _, ba = time_steps(lambda: model.scatter_add_(grad, i, o, alpha=-1e-6, batch=B_glob, presorted=True),
+                               n_sub, 2, barrier)
+            r = {"indices": tag,
+                 "method": "sorted (stable (table,row) key sort + one read-modify-write per touched row, no atomics)",
+                 "lookups_per_s": lookups_step_rank / bs, "avg_s_sort_plus_apply": bs, "avg_s_apply_only": ba,
+                 "avg_s_sort": bs - ba, "algorithmic_GBps": bwd_bytes / bs / 1e9,
+                 ("frac" if uniform else "alg_frac"): bwd_bytes / bs / 1e9 / HBM_PEAK_GBPS,
+                 ("apply_only_frac" if uniform else "apply_only_alg_frac"): bwd_bytes / ba / 1e9 / HBM_PEAK_GBPS,
+                 "bytes_per_lookup": bwd_bytes / lookups_step_rank}
+            if a.atomic:
+                _, bt = time_steps(lambda: model.scatter_add_(grad, i, o, alpha=-1e-6, batch=B_glob, method="atomic"), 3, 1, barrier)
+                r["atomic_kernel_s"] = bt
+            return r
+
+        out_fb = torch.empty(out_shape, dtype=torch.float32, device=dev)
+
+        def fwd_bwd_block(i, o, uniform):
+            def fwd_bwd():
+                model.lookup(i, o, out=out_fb, batch=B_glob)
+                model.scatter_add_(grad, i, o, alpha=-1e-6, batch=B_glob)
+            _, fb = time_steps(fwd_bwd, n_sub, 2, barrier)
+            fb_bytes = alg_bytes + bwd_bytes
+            return {"avg_s": fb, "lookups_per_s": lookups_step_rank / fb, "algorithmic_GBps": fb_bytes / fb / 1e9,
+                    ("frac" if uniform else "alg_frac"): fb_bytes / fb / 1e9 / HBM_PEAK_GBPS,
+                    "bytes_per_lookup": fb_bytes / lookups_step_rank}
+
+        result["bwd_scatter_add"] = bwd_block(idx, off, f"zipf alpha={a.alpha}", a.alpha == 0.0)
+        result["fwd_bwd_step"] = fwd_bwd_block(idx, off, a.alpha == 0.0)
+        if uni_s is not None and a.alpha != 0.0:
+            result["bwd_scatter_add"]["uniform"] = bwd_block(ui, uo, "uniform", True)
+            result["fwd_bwd_step"]["uniform"] = fwd_bwd_block(ui, uo, True)
         # the optimizer the reference configures for its TBE ops (EXACT_ROWWISE_ADAGRAD): same kernels, fused epilogue,
         # + 4 B of state read-modify-write per touched row
         try:
             model.learning_rate = 1e-6
-            _, ag = time_steps(lambda: model.adagrad_step_(grad, idx, off, batch=B_glob, presorted=True), n_b, 2, barrier)
-            result["bwd_rowwise_adagrad"] = {"avg_s_apply_only": ag, "apply_only_GBps": bwd_bytes / ag / 1e9,
-                                             "apply_only_frac": bwd_bytes / ag / 1e9 / HBM_PEAK_GBPS,
-                                             "avg_s_sort_plus_apply": ag + (bs - ba)}
+            model.sort_indices(idx, off, batch=B_glob)
+            _, ag = time_steps(lambda: model.adagrad_step_(grad, idx, off, batch=B_glob, presorted=True), n_sub, 2, barrier)
+            result["bwd_rowwise_adagrad"] = {"avg_s_apply_only": ag, "apply_only_alg_frac": bwd_bytes / ag / 1e9 / HBM_PEAK_GBPS}
         except Exception as exc:  # wide rows (> 64 lanes x vector) have no fused Adagrad
             result["bwd_rowwise_adagrad"] = {"error": str(exc)}
-        # BASELINE configs[2]: one fwd + bwd training step.  The key sort needs only the request, so it runs on a
-        # second HIP stream UNDER the forward lookup; the apply kernels wait for both.
-        side = torch.cuda.Stream(device=dev)
-        ev_sorted = torch.cuda.Event()
-        out_fb = torch.empty((B_glob, T_loc * D), dtype=torch.float32, device=dev)
-
-        def fwd_bwd_step():
-            main = torch.cuda.current_stream()
-            side.wait_stream(main)                       # the previous step's apply must be done with the scratch
-            with torch.cuda.stream(side):
-                model.sort_indices(idx, off, batch=B_glob)
-                ev_sorted.record(side)
-            model.lookup(idx, off, out=out_fb, batch=B_glob)
-            main.wait_event(ev_sorted)
-            model.scatter_add_(grad, idx, off, alpha=-1e-6, batch=B_glob, presorted=True)
-
-        def fwd_bwd_serial():
-            model.lookup(idx, off, out=out_fb, batch=B_glob)
-            model.scatter_add_(grad, idx, off, alpha=-1e-6, batch=B_glob)
-
-        _, fb = time_steps(fwd_bwd_step, n_b, 2, barrier)
-        _, fs = time_steps(fwd_bwd_serial, n_b, 2, barrier)
-        fb_bytes = alg_bytes + bwd_bytes
-        result["fwd_bwd_step"] = {"avg_s_sort_overlapped": fb, "avg_s_serial": fs, "lookups_per_s": lookups_step_rank / fb,
-                                  "algorithmic_GBps": fb_bytes / fb / 1e9, "frac": fb_bytes / fb / 1e9 / HBM_PEAK_GBPS,
-                                  "bytes_per_lookup": fb_bytes / lookups_step_rank}
         del grad, out_fb
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

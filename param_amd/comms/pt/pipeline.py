@@ -102,3 +102,119 @@ class LookupAllToAll:
     def bytes_per_rank(self) -> int:
         """output-tensor bytes per rank: the reference's ``memSize`` for algBW (pytorch_dist_backend.py:860-897)"""
         return sum(r.numel() * r.element_size() for r in self.recv)
+
+
+def table_split(num_tables: int, world: int) -> List[int]:
+    """tables per rank, the reference's contiguous partition (dlrm.py:390-398): the first ``T mod W`` ranks hold one
+    more -- 26 tables over 8 ranks -> [4, 4, 3, 3, 3, 3, 3, 3]"""
+    k, m = divmod(num_tables, world)
+    return [k + 1 if r < m else k for r in range(world)]
+
+
+class ShardedEmbeddingExchange:
+    """Training-step form of the sparse path for ANY table count (uneven shards, mixed dims): forward lookup ->
+    pooled all-to-all (dlrm.py:858-878 ``fwd_a2a``), and the way back: gradient all-to-all (``bwd_a2a``, dlrm.py:204-214:
+    the same exchange with send / receive splits swapped) -> fused backward on the owner.
+
+    Rank r owns the tables ``[sum(split[:r]), sum(split[:r+1]))`` whose dims add up to ``widths[r]`` and serves the GLOBAL
+    batch (``world * B_local`` bags) for them.  Layouts (fp32, contiguous):
+      pooled   [world * B_local, widths[me]]            lookup output = forward send buffer; rows [j*B_local, ...) go to rank j
+      recv     flat: block i = [B_local, widths[i]]     my samples' pooled embeddings of rank i's tables (forward receive)
+      grad_in  flat, same blocks as recv                d(loss)/d(recv): backward send buffer, block i goes back to rank i
+      grad     [world * B_local, widths[me]]            backward receive = the lookup-layout gradient the backward kernel reads
+    Forward: equal send splits (``B_local * widths[me]``), receive split i = ``B_local * widths[i]``; backward: swapped.
+
+    Three batches in flight (``step``): the compute stream runs lookup(k) and backward(k-2), the process group's stream
+    runs fwd_a2a(k) and bwd_a2a(k-1) -- every collective has a whole lookup + backward to hide under, and the tables a
+    lookup reads are two updates stale (pipelined-training semantics; the arithmetic of each piece is unchanged).
+    ``lookup(indices, offsets, out)`` and ``backward(grad, indices, offsets)`` are injected: bench.py passes the HIP
+    kernels, the gloo tests a torch stand-in.  ``make_grad(recv, grad_in)`` stands for the dense part of the model (the
+    reference's benchmark has none either: it sends a gradient of the received shape back, dlrm.py:1268-1281); default:
+    the received embeddings themselves."""
+
+    def __init__(self, lookup: Callable, backward: Callable, world: int, rank: int, local_batch: int,
+                 widths: Sequence[int], device, group=None, make_grad: Callable = None, slots: int = 3):
+        self.lookup, self.backward, self.make_grad = lookup, backward, make_grad
+        self.world, self.rank, self.local_batch, self.pg = world, rank, local_batch, group
+        self.widths = [int(w) for w in widths]
+        assert len(self.widths) == world
+        wme, n = self.widths[rank], world * local_batch
+        self.fwd_recv_splits = [local_batch * w for w in self.widths]
+        self.fwd_send_splits = [local_batch * wme] * world
+        total = sum(self.fwd_recv_splits)
+        self.slots = slots
+        mk = lambda *shape: [torch.empty(shape, dtype=torch.float32, device=device) for _ in range(slots)]  # noqa: E731
+        self.pooled, self.recv = mk(n, wme), mk(total)
+        self.grad_in, self.grad = (mk(total) if make_grad is not None else self.recv), mk(n, wme)
+        self._req = [None] * slots
+        self._fwd_work = [None] * slots
+        self._bwd_work = [None] * slots
+        self._k = 0
+
+    # -- pieces (also timed on their own by bench.py) ---------------------------------------------
+    def fwd_a2a(self, slot: int, async_op: bool = True):
+        return dist.all_to_all_single(self.recv[slot], self.pooled[slot].view(-1), self.fwd_recv_splits, self.fwd_send_splits,
+                                      group=self.pg, async_op=async_op)
+
+    def bwd_a2a(self, slot: int, async_op: bool = True):
+        return dist.all_to_all_single(self.grad[slot].view(-1), self.grad_in[slot], self.fwd_send_splits, self.fwd_recv_splits,
+                                      group=self.pg, async_op=async_op)
+
+    def recv_block(self, slot: int, src: int) -> torch.Tensor:
+        """[B_local, widths[src]] view of what rank ``src`` sent me in the forward exchange"""
+        o = sum(self.fwd_recv_splits[:src])
+        return self.recv[slot][o:o + self.fwd_recv_splits[src]].view(self.local_batch, self.widths[src])
+
+    def bytes_per_rank(self) -> int:
+        """output-tensor bytes of ONE exchange per rank (the reference's ``memSize``); forward and backward are equal in
+        total over the ranks, not per rank, when the shards are uneven"""
+        return self.recv[0].numel() * 4
+
+    # -- the pipelined step ---------------------------------------------------------------------------
+    def step(self, indices, offsets) -> None:
+        k, s = self._k, self._k % self.slots
+        # slot s was last used by batch k - slots, whose backward ran at step k - slots + 2 on this stream: free.
+        self.lookup(indices, offsets, self.pooled[s])
+        self._req[s] = (indices, offsets)
+        self._fwd_work[s] = self.fwd_a2a(s)                      # on the pg stream, after the lookup; under what follows
+        if k >= 1:                                               # batch k-1: its pooled embeddings have arrived -> gradient back
+            p = (k - 1) % self.slots
+            self._fwd_work[p].wait()
+            if self.make_grad is not None:
+                self.make_grad(self.recv[p], self.grad_in[p])
+            self._bwd_work[p] = self.bwd_a2a(p)
+        if k >= 2:                                               # batch k-2: its gradient is home -> fused backward
+            q = (k - 2) % self.slots
+            self._bwd_work[q].wait()
+            self.backward(self.grad[q], *self._req[q])
+        self._k += 1
+
+    def drain(self) -> None:
+        """finish the batches still in flight (the last two): their gradient exchange and backward"""
+        k = self._k
+        for b in (k - 1, k - 2):
+            if b < 0:
+                continue
+            p = b % self.slots
+            if b == k - 1:
+                self._fwd_work[p].wait()
+                if self.make_grad is not None:
+                    self.make_grad(self.recv[p], self.grad_in[p])
+                self._bwd_work[p] = self.bwd_a2a(p)
+        for b in (k - 2, k - 1):
+            if b < 0:
+                continue
+            q = b % self.slots
+            self._bwd_work[q].wait()
+            self.backward(self.grad[q], *self._req[q])
+        self._k = 0
+
+    def step_serial(self, indices, offsets) -> None:
+        """the same batch with nothing overlapped: lookup, exchange, gradient exchange, backward, each waited for
+        (what the reference does: barrier after every region, dlrm.py:119-123,1196-1290)"""
+        self.lookup(indices, offsets, self.pooled[0])
+        self.fwd_a2a(0).wait()
+        if self.make_grad is not None:
+            self.make_grad(self.recv[0], self.grad_in[0])
+        self.bwd_a2a(0).wait()
+        self.backward(self.grad[0], indices, offsets)

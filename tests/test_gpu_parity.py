@@ -452,6 +452,22 @@ def test_fill_random_statistics_and_determinism():
 
 
 # ----------------------------------------------------------------------------- full size
+_FULL = {}
+
+
+def _full_size_model():
+    """the benchmark's tables (10 M x 128 fp32, as many as fit: 48 on a 288 GB MI355X), built once per test process"""
+    from param_amd import BatchedEmbeddingBagMI355
+
+    if "m" not in _FULL:
+        free, _total = torch.cuda.mem_get_info()
+        R, D = 10_000_000, 128
+        T = int(min(48, (free - (16 << 30)) // (R * D * 4)) // 8 * 8)
+        assert T >= 8, f"only {free / 2**30:.0f} GiB free"
+        _FULL["m"] = BatchedEmbeddingBagMI355([R] * T, D, device=DEV, init="normal", seed=1, fused_update=False)
+    return _FULL["m"]
+
+
 def test_full_size_properties_and_live_torch_oracle():
     """BASELINE.json configs[1] geometry at the largest table count that fits (fp32), checked
     through size-independent properties and against torch-ROCm's own embedding_bag as a live
@@ -459,11 +475,9 @@ def test_full_size_properties_and_live_torch_oracle():
     from param_amd import BatchedEmbeddingBagMI355
     from param_amd.indices import tbe_request
 
-    free, _total = torch.cuda.mem_get_info()
     R, D, B, L = 10_000_000, 128, 8192, 20
-    T = int(min(48, (free - (12 << 30)) // (R * D * 4)) // 8 * 8)
-    assert T >= 8, f"only {free / 2**30:.0f} GiB free"
-    m = BatchedEmbeddingBagMI355([R] * T, D, device=DEV, init="normal", seed=1, fused_update=False)
+    m = _full_size_model()
+    T = len(m.rows)
     idx, off = tbe_request([R] * T, B, L, alpha=0.0, device=DEV, seed=3)
     m.check(idx, off)
     out = m.lookup(idx, off)
@@ -501,6 +515,69 @@ def test_full_size_properties_and_live_torch_oracle():
     hit[idx[:B * L]] = True
     untouched = (~hit[:1000]).nonzero().squeeze(1)
     assert torch.equal(t0[untouched], probe[untouched])
+
+
+def test_full_size_zipf_headline_workload():
+    """The HEADLINE workload of bench.py at full size -- 48 x 10 M x 128 fp32, B = 8192, L = 20, Zipf(1.05) indices (hot rows =
+    low ids, per-bag dedupe) -- which the alpha = 0 test above does not exercise: the forward against torch-ROCm's own
+    embedding_bag on 3 tables including table 0 (whose head rows are hit thousands of times per step, from L2), and the
+    sorted backward of the WHOLE request against an fp64 accumulation on a slice of table 0 that holds the hottest rows
+    (chunk-partial path), mid-frequency rows (exact re-walk path) and rows looked up once."""
+    from param_amd.indices import tbe_request
+
+    R, D, B, L = 10_000_000, 128, 8192, 20
+    m = _full_size_model()
+    T = len(m.rows)
+    idx, off = tbe_request([R] * T, B, L, alpha=1.05, device=DEV, seed=1)
+    m.check(idx, off)
+    counts0 = torch.bincount(idx[:B * L], minlength=R)
+    assert int(counts0.max()) > 2000 and int((counts0 == 1).sum()) > 20000      # skewed: a hot head and a long tail
+    out = m.lookup(idx, off)
+    for t in (0, T // 2, T - 1):
+        sl = slice(t * B * L, (t + 1) * B * L)
+        ref = torch.nn.functional.embedding_bag(idx[sl], m.table(t), off[t * B:(t + 1) * B] - t * B * L, mode="sum")
+        mag = torch.nn.functional.embedding_bag(idx[sl], m.table(t).abs(), off[t * B:(t + 1) * B] - t * B * L, mode="sum")
+        assert ((out[:, t * D:(t + 1) * D] - ref).abs() <= 1e-5 * mag + 1e-30).all(), t
+    # checksum of checksums on table 0: sum of all pooled outputs == sum over lookups of row sums (fp64)
+    rows_sum = m.table(0)[idx[:B * L]].double().sum()
+    assert abs(out[:, :D].double().sum().item() - rows_sum.item()) <= 1e-6 * B * L * D
+    # tuning variants agree bit for bit on the skewed request too (XCD-affine mapping on / off)
+    import param_amd
+
+    for unroll, xcd in [(4, 0), (2, 1)]:
+        param_amd.set_tuning(unroll=unroll, xcd_affine=xcd)
+        assert torch.equal(m.lookup(idx, off), out)
+    param_amd.set_tuning()
+
+    # sorted backward of the whole 7.86 M-lookup request; checked on table 0's rows in a slice
+    i0 = idx[:B * L]
+    hot = torch.argsort(counts0, descending=True)[:48]                             # > 256 lookups each: chunk partials
+    mid = (((counts0 >= 2) & (counts0 <= 256)).nonzero().squeeze(1))[:2000]         # exact in-tile / re-walk paths
+    once = ((counts0 == 1).nonzero().squeeze(1))[:2000]
+    never = ((counts0 == 0).nonzero().squeeze(1))[:2000]
+    sel = torch.unique(torch.cat([hot, mid, once, never]))                         # sorted
+    before = m.table(0)[sel].clone()
+    grad = torch.randn(B, T * D, device=DEV)
+    alpha = -0.25
+    m.scatter_add_(grad, idx, off, alpha=alpha)
+    after = m.table(0)[sel]
+    pos = torch.isin(i0, sel).nonzero().squeeze(1)                                  # lookups of table 0 that hit a selected row
+    slot = torch.searchsorted(sel, i0[pos])
+    bag = pos // L
+    g0 = grad[:, :D].double()
+    G = torch.zeros(sel.numel(), D, dtype=torch.float64, device=DEV).index_add_(0, slot, g0[bag])
+    Gabs = torch.zeros(sel.numel(), D, dtype=torch.float64, device=DEV).index_add_(0, slot, g0[bag].abs())
+    exp = before.double() + alpha * G
+    err = (after.double() - exp).abs()
+    assert (err <= 1e-5 * (abs(alpha) * Gabs + before.double().abs()) + 1e-30).all(), float(err.max())
+    sel_counts = counts0[sel]
+    untouched = sel_counts == 0
+    assert torch.equal(after[untouched], before[untouched])                         # rows never looked up keep their bits
+    assert int((sel_counts > 256).sum()) >= 40 and int((sel_counts == 1).sum()) >= 1000
+    # a second application with the opposite sign brings every selected row back (to rounding)
+    m.scatter_add_(grad, idx, off, alpha=-alpha)
+    back = m.table(0)[sel]
+    assert ((back - before).abs().double() <= 4e-5 * (abs(alpha) * Gabs + before.double().abs()) + 1e-30).all()
 
 
 def test_fused_rowwise_adagrad_vs_oracle(coracle):
