@@ -45,7 +45,13 @@ import statistics
 import sys
 import time
 
-import torch
+# Host-side OpenMP threads (the CPU baseline only) are bound to cores, one place per physical core, BEFORE the OpenMP
+# runtime loads with torch: unbound threads migrate inside the affinity mask and the 84 MB of rows a step touches move
+# between "resident in the cores' L3 slices" and "streamed from DRAM" (64 vs 300 us per step in the same run).
+os.environ.setdefault("OMP_PLACES", "cores")
+os.environ.setdefault("OMP_PROC_BIND", "close")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -73,8 +79,10 @@ def parse():
     p.add_argument("--pooling", type=int, default=20)
     p.add_argument("--alpha", type=float, default=1.05, help="Zipf exponent of the headline run (0 = uniform)")
     p.add_argument("--dtype", choices=sorted(_DT), default="fp32")
-    p.add_argument("--layout", choices=["bd", "tbd"], default="bd",
-                   help="N == 1 output layout: bd = [B, sum D] (TBE / all-to-all send layout), tbd = [T, B, D] (dlrm.py's stack)")
+    p.add_argument("--layout", choices=["bd", "tbd"], default="tbd",
+                   help="N == 1 output layout of the timed step: tbd = [T, B, D] (one [B, D] block per table: what the reference's "
+                        "pytorch_emb.py / dlrm.py apply_emb produce, dlrm.py:380-387), bd = [B, sum D] (fbgemm TBE's, the "
+                        "all-to-all send layout); the other one is timed too and reported as `other_layout`")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--dist-debug", action="store_true", help="run the N>1 (exchange + RCCL) code path even at world size 1")
     p.add_argument("--no-uniform", action="store_true", help="skip the uniform-index (roofline-defining) measurement")
@@ -145,9 +153,10 @@ def _one_cpu_per_core():
 
 def cpu_baseline(table0: torch.Tensor, idx0: torch.Tensor, B: int, L: int, budget_s: float = 16.0):
     """Reference CPU engine on a bounded sample: ONE table of the workload (same rows / dim / indices as table 0 on the
-    GPU), measure_cpu protocol of pytorch_emb.py:37-45.  Per mode: threads pinned (one per physical core, by socket),
-    3 discarded warm-up steps, then 3 repeats of a fixed step count; the mode's figure is the MEDIAN repeat, ``value`` is the
-    best mode (named in ``sample``)."""
+    GPU), measure_cpu protocol of pytorch_emb.py:37-45.  OpenMP threads are bound one per physical core (OMP_PLACES=cores,
+    OMP_PROC_BIND=close, set at the top of this file), so n threads occupy the first n cores.  Per mode: 3 discarded
+    warm-up steps, then 5 repeats of a fixed step count; the mode's figure is the MEDIAN repeat, ``value`` is the best mode
+    (named in ``sample``)."""
     from param_amd.compute.pt.pytorch_emb import measure_cpu
 
     W = table0.float().cpu()
@@ -155,32 +164,30 @@ def cpu_baseline(table0: torch.Tensor, idx0: torch.Tensor, B: int, L: int, budge
     off = torch.arange(B, dtype=torch.int64) * L
     emb = torch.nn.EmbeddingBag(W.shape[0], W.shape[1], mode="sum", _weight=W)
     lookups = B * L
-    saved_aff = os.sched_getaffinity(0)
     saved_threads = torch.get_num_threads()
     by_pkg = _one_cpu_per_core()
-    all_cores = sorted(c for v in by_pkg.values() for c in v)
-    one_socket = sorted(by_pkg[min(by_pkg)])
-    modes = [("all_cores_no_grad", all_cores, True), ("all_cores_grad_on_param_default", all_cores, False),
-             ("one_socket_no_grad", one_socket, True), ("one_thread_no_grad", all_cores[:1], True)]
+    n_all = sum(len(v) for v in by_pkg.values())
+    n_socket = len(by_pkg[min(by_pkg)])
+    modes = [("one_socket_no_grad", n_socket, True), ("all_cores_no_grad", n_all, True),
+             ("all_cores_grad_on_param_default", n_all, False), ("quarter_socket_no_grad", max(1, n_socket // 4), True),
+             ("one_thread_no_grad", 1, True)]
     per_mode = budget_s / len(modes)
     res = {}
     try:
-        for tag, cpus, no_grad in modes:
-            os.sched_setaffinity(0, set(cpus))
-            torch.set_num_threads(len(cpus))
+        for tag, nthr, no_grad in modes:
+            torch.set_num_threads(nthr)
             ctx = torch.no_grad() if no_grad else torch.enable_grad()
             with ctx:
                 t3, _ = measure_cpu(0, 3, emb, idx, off)                      # warm-ups: pool spin-up, first touch, caches
-                steps = max(3, min(300, int(per_mode / 4 / max(t3 / 3, 1e-5))))
+                steps = max(3, min(300, int(per_mode / 6 / max(t3 / 3, 1e-5))))
                 reps = []
-                for _ in range(3):
+                for _ in range(5):
                     el, _ = measure_cpu(0, steps, emb, idx, off)
                     reps.append(el / steps)
             med = statistics.median(reps)
-            res[tag] = {"lookups_per_s": lookups / med, "s_per_step": med, "threads": len(cpus), "steps": steps,
+            res[tag] = {"lookups_per_s": lookups / med, "s_per_step": med, "threads": nthr, "steps": steps,
                         "repeats_s_per_step": reps, "spread": (max(reps) - min(reps)) / med}
     finally:
-        os.sched_setaffinity(0, saved_aff)
         torch.set_num_threads(saved_threads)
     # 1-core C oracle ("port") on a smaller slice of the same request
     try:
@@ -200,10 +207,10 @@ def cpu_baseline(table0: torch.Tensor, idx0: torch.Tensor, B: int, L: int, budge
     return {
         "value": best["lookups_per_s"], "unit": "lookups/s", "cores": best["threads"], "kind": "port",
         "sample": (f"torch.nn.EmbeddingBag(sum) on host (the engine the reference calls, its measure_cpu protocol), 1 table "
-                   f"{W.shape[0]}x{W.shape[1]} fp32, batch {B}, pool {L}, same indices as GPU table 0; best of 4 modes = "
-                   f"{best_tag}: {best['threads']} pinned threads, median of 3 x {best['steps']} steps after 3 warm-ups"),
-        "best_mode": best_tag, "host_cpu_count": os.cpu_count(), "physical_cores": len(all_cores),
-        "sockets": len(by_pkg), "modes": res,
+                   f"{W.shape[0]}x{W.shape[1]} fp32, batch {B}, pool {L}, same indices as GPU table 0; best of {len(modes)} modes = "
+                   f"{best_tag}: {best['threads']} core-bound threads, median of 5 x {best['steps']} steps after 3 warm-ups"),
+        "best_mode": best_tag, "host_cpu_count": os.cpu_count(), "physical_cores": n_all,
+        "sockets": len(by_pkg), "omp": {k: os.environ.get(k) for k in ("OMP_PLACES", "OMP_PROC_BIND")}, "modes": res,
     }
 
 
@@ -432,6 +439,22 @@ def main():
         result["uniform"] = {"lookups_per_s": lookups_step_all / uni_s,
                              "achieved_GBps": alg_bytes / uni_s / 1e9, "frac": alg_bytes / uni_s / 1e9 / HBM_PEAK_GBPS,
                              "avg_launch_s": uni_s}
+
+    # ---- N == 1: the same launches writing the other output layout ---------------------------------------------------
+    if not multi and len(set(model.dims)) == 1:
+        from param_amd.embedding_bag import _TableSet, _fwd
+
+        other = "bd" if a.layout == "tbd" else "tbd"
+        ts_o = _TableSet([model.table(t) for t in range(T_loc)], other)
+        out_o = torch.empty((B_glob, T_loc * D) if other == "bd" else (T_loc, B_glob, D), dtype=torch.float32, device=dev)
+        _, oz = time_steps(lambda: _fwd(ts_o, idx, off, B_glob, out=out_o), n_sub, 2, barrier)
+        rec = {"output_layout": "[B, sum D]" if other == "bd" else "[T, B, D]", "zipf_avg_launch_s": oz,
+               "zipf_lookups_per_s": lookups_step_rank / oz}
+        if uni_s is not None:
+            _, ou = time_steps(lambda: _fwd(ts_o, ui, uo, B_glob, out=out_o), n_sub, 2, barrier)
+            rec.update({"uniform_avg_launch_s": ou, "uniform_frac": alg_bytes / ou / 1e9 / HBM_PEAK_GBPS})
+        result["other_layout"] = rec
+        del out_o, ts_o
 
     # ---- N > 1: the exchange alone, overlap, and the fwd + bwd training step ------------------------------------
     if multi:
