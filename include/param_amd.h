@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PM_ABI_VERSION 2
+#define PM_ABI_VERSION 3
 
 typedef void* pm_stream_t;
 
@@ -239,6 +239,34 @@ int pm_fill_random(void* dst, int64_t count, int32_t dtype, int32_t dist, float 
  * num_tables%8==0 (keeps each table's hot rows in one L2), -1 = default.
  */
 int pm_set_tuning(int32_t unroll, int32_t bags_per_block, int32_t xcd_affine, int32_t nt_loads);
+
+/*
+ * Tuning knobs of the sorted backward (process-wide; -1 = default, which the environment can set:
+ * PARAM_AMD_SORT=rocprim, PARAM_AMD_SORT_ORDER=table, PARAM_AMD_BWD_XCD=1):
+ *   sort_impl   0: the build's own radix sort (pm_radix_sort_pairs), 1: rocPRIM's radix_sort_pairs (kept as
+ *               the measured alternative)
+ *   order       0: pairs ordered by (row, table, position) -- only the row bits are sorted, the request being
+ *               table-major already; 1: (table, row, position) -- one more radix pass
+ *   xcd_affine  1 (with order 1): the apply kernel's tiles of table t run on XCD t % 8, so one table's gradient
+ *               rows stay in one L2.  Placement and pass count change speed only; every setting gives the same
+ *               result for rows looked up at most 256 times (longer runs: same value up to fp32 association).
+ * A request sorted under one setting must be applied under the same setting.
+ */
+int pm_set_backward_tuning(int32_t sort_impl, int32_t order, int32_t xcd_affine, int32_t reserved);
+
+/*
+ * Stable LSD radix sort of (key, uint32 value) pairs by key bits [begin_bit, end_bit) -- the sort the sorted
+ * backward runs on its (table,row) keys (replaces the sort inside aten::_embedding_bag_dense_backward /
+ * fbgemm's TBE backward at the call sites of pm_embbag_bwd_sorted).  key_bytes: 4 or 8.  The pairs start in
+ * (keys_a, vals_a); 8-bit passes alternate between the a and b buffers and *result_in_b says where the sorted
+ * pairs ended up.  n_max <= 2^32 - 1 elements; if d_count is not NULL the number of elements is read from that
+ * device uint32 when the kernels run (clamped to n_max), so a producer kernel can decide it without a host
+ * round trip.  scratch: pm_radix_sort_scratch_bytes(n_max) bytes of device memory.
+ */
+int64_t pm_radix_sort_scratch_bytes(int64_t n_max);
+int pm_radix_sort_pairs(void* keys_a, void* keys_b, uint32_t* vals_a, uint32_t* vals_b, int64_t n_max,
+                        const uint32_t* d_count, int32_t key_bytes, int32_t begin_bit, int32_t end_bit,
+                        void* scratch, int64_t scratch_bytes, int32_t* result_in_b, pm_stream_t stream);
 
 
 #ifdef __cplusplus

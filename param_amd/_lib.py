@@ -13,7 +13,7 @@ import threading
 
 PM_F32, PM_BF16, PM_F16, PM_I32, PM_I64 = 0, 1, 2, 10, 11
 PM_OK, PM_ERR_INVALID, PM_ERR_UNSUPPORTED, PM_ERR_HIP, PM_ERR_INDEX = 0, -1, -2, -3, -4
-PM_ABI_VERSION = 2
+PM_ABI_VERSION = 3
 PM_WD_NONE, PM_WD_L2, PM_WD_DECOUPLE = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -37,6 +37,9 @@ EXPORTED_SYMBOLS = (
     "pm_embbag_check",
     "pm_fill_random",
     "pm_set_tuning",
+    "pm_set_backward_tuning",
+    "pm_radix_sort_scratch_bytes",
+    "pm_radix_sort_pairs",
 )
 
 
@@ -137,6 +140,12 @@ def load() -> ctypes.CDLL:
         L.pm_fill_random.argtypes = [vp, i64, i32, i32, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, vp]
         L.pm_set_tuning.restype = ctypes.c_int
         L.pm_set_tuning.argtypes = [i32, i32, i32, i32]
+        L.pm_set_backward_tuning.restype = ctypes.c_int
+        L.pm_set_backward_tuning.argtypes = [i32, i32, i32, i32]
+        L.pm_radix_sort_scratch_bytes.restype = ctypes.c_int64
+        L.pm_radix_sort_scratch_bytes.argtypes = [i64]
+        L.pm_radix_sort_pairs.restype = ctypes.c_int
+        L.pm_radix_sort_pairs.argtypes = [vp, vp, vp, vp, i64, vp, i32, i32, i32, vp, i64, ctypes.POINTER(ctypes.c_int32), vp]
         if L.pm_abi_version() != PM_ABI_VERSION:
             raise ImportError(f"{LIB_PATH}: ABI version {L.pm_abi_version()} != {PM_ABI_VERSION}")
         _lib = L
@@ -150,3 +159,9 @@ def check(rc: int) -> None:
 
 def set_tuning(unroll: int = 0, bags_per_block: int = 0, xcd_affine: int = -1, nt_loads: int = -1) -> None:
     check(load().pm_set_tuning(unroll, bags_per_block, xcd_affine, nt_loads))
+
+
+def set_backward_tuning(sort_impl: int = -1, order: int = -1, xcd_affine: int = -1) -> None:
+    """sorted-backward knobs (``pm_set_backward_tuning``): sort_impl 0 own / 1 rocPRIM, order 0 (row, table) / 1 (table,
+    row), xcd_affine 0 / 1; -1 = default.  Sort and apply of one request must run under the same setting."""
+    check(load().pm_set_backward_tuning(sort_impl, order, xcd_affine, 0))

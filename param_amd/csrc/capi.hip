@@ -132,6 +132,40 @@ int pm_set_tuning(int32_t unroll, int32_t bags_per_block, int32_t xcd_affine, in
     return PM_OK;
 }
 
+int pm_set_backward_tuning(int32_t sort_impl, int32_t order, int32_t xcd_affine, int32_t reserved) {
+    (void)reserved;
+    if (sort_impl < -1 || sort_impl > 1 || order < -1 || order > 1 || xcd_affine < -1 || xcd_affine > 1)
+        return fail(PM_ERR_INVALID, "sort_impl / order / xcd_affine must be -1, 0 or 1");
+    pm::set_backward_tuning(sort_impl, order, xcd_affine);
+    return PM_OK;
+}
+
+int64_t pm_radix_sort_scratch_bytes(int64_t n_max) {
+    if (n_max < 0 || n_max > 0xffffffffLL) return fail(PM_ERR_INVALID, "n_max must be in [0, 2^32)");
+    return static_cast<int64_t>(pm::rs_scratch_bytes(static_cast<size_t>(n_max)));
+}
+
+int pm_radix_sort_pairs(void* keys_a, void* keys_b, uint32_t* vals_a, uint32_t* vals_b, int64_t n_max,
+                        const uint32_t* d_count, int32_t key_bytes, int32_t begin_bit, int32_t end_bit, void* scratch,
+                        int64_t scratch_bytes, int32_t* result_in_b, pm_stream_t stream) {
+    if (n_max < 0 || n_max > 0xffffffffLL) return fail(PM_ERR_INVALID, "n_max must be in [0, 2^32)");
+    if (key_bytes != 4 && key_bytes != 8) return fail(PM_ERR_INVALID, "key_bytes must be 4 or 8");
+    if (begin_bit < 0 || end_bit < begin_bit || end_bit > key_bytes * 8) return fail(PM_ERR_INVALID, "bad bit range");
+    if (!result_in_b) return fail(PM_ERR_INVALID, "result_in_b is NULL");
+    *result_in_b = pm::rs_num_passes(begin_bit, end_bit) % 2;
+    if (n_max == 0) return PM_OK;
+    if (!keys_a || !keys_b || !vals_a || !vals_b) return fail(PM_ERR_INVALID, "key / value buffers are NULL");
+    if (!scratch || scratch_bytes < static_cast<int64_t>(pm::rs_scratch_bytes(static_cast<size_t>(n_max))))
+        return fail(PM_ERR_INVALID, "scratch too small: need " + std::to_string(pm::rs_scratch_bytes(static_cast<size_t>(n_max))) + " bytes");
+    hipError_t h = key_bytes == 4
+        ? pm::rs_sort_pairs<uint32_t>(static_cast<uint32_t*>(keys_a), static_cast<uint32_t*>(keys_b), vals_a, vals_b,
+                                      static_cast<size_t>(n_max), d_count, begin_bit, end_bit, scratch, static_cast<hipStream_t>(stream))
+        : pm::rs_sort_pairs<uint64_t>(static_cast<uint64_t*>(keys_a), static_cast<uint64_t*>(keys_b), vals_a, vals_b,
+                                      static_cast<size_t>(n_max), d_count, begin_bit, end_bit, scratch, static_cast<hipStream_t>(stream));
+    if (h != hipSuccess) return hip_fail(h, "pm_radix_sort_pairs");
+    return PM_OK;
+}
+
 int pm_embbag_fwd(const pm_embbag_batch* op, float* out, pm_stream_t stream) {
     pm::KParams p;
     int rc = make_params(op, op ? op->weight_dtype : -1, p);

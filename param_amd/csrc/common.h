@@ -131,6 +131,15 @@ hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, void* w
 hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, int max_dim, const void* workspace,
                             float* const* momentum, const pm_rowwise_adagrad* opt, hipStream_t stream);
 
+// own stable LSD radix sort of (key, uint32) pairs (radix_sort.hip); element count optionally read from device memory
+size_t rs_scratch_bytes(size_t n_max);
+int rs_num_passes(int begin_bit, int end_bit);   // result lands in the b buffers iff odd
+template <typename K>
+hipError_t rs_sort_pairs(K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n_max, const uint32_t* d_count,
+                         int begin_bit, int end_bit, void* scratch, hipStream_t stream);
+
+void set_backward_tuning(int sort_impl, int order, int xcd);   // -1 = default (environment)
+
 // DLRM input redistribution (dlrm_regroup.hip)
 hipError_t launch_dlrm_regroup(const int64_t* lengths, const int64_t* indices, int W, int F, int64_t B,
                                int64_t* out_indices, int64_t* out_offsets, int64_t* scratch, hipStream_t stream);

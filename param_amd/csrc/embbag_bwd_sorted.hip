@@ -6,8 +6,11 @@
 // the atomic kernel (embbag_bwd.hip) tops out at ~77 G atomic-dwords/s = 0.6 G lookups/s at
 // D=128 (profiles/, sweep r1a), 6-8 % of the HBM roofline.  This path instead
 //   1. builds one (table,row) key and one bag value per lookup          (build_keys_kernel)
-//   2. sorts the pairs by key with a stable LSD radix sort               (rocPRIM device primitive;
-//      only bits [0, bits(T)+bits(max_rows)) are sorted)
+//   2. sorts the pairs with a stable LSD radix sort by the ROW bits only (radix_sort.hip: own kernels, 3 passes of 8 bits
+//      for 10 M-row tables).  The request is table-major, so after a stable sort by row the lookups of one (table, row)
+//      are still contiguous and in lookup order -- the order is (row, table, position), which is all step 3 needs: it
+//      finds runs by key equality.  (Sorting the table bits too would be a fourth pass for nothing.)  rocPRIM's
+//      radix_sort_pairs stays compiled in as the measured alternative: PARAM_AMD_SORT=rocprim.
 //   3. streams the sorted pairs: every run of equal keys is owned by ONE lane group, which
 //      reads the destination row once, adds the run's gradient rows in sorted (= original
 //      index) order in fp32 registers and writes the row back once      (bwd_sorted_kernel)
@@ -22,6 +25,10 @@
 //
 // Step 1+2 depend only on the indices, not on the gradient: pm_embbag_sort_indices() can run
 // on a side stream under the forward pass; pm_embbag_bwd_sorted() is step 3.
+#include <atomic>
+#include <cstdlib>
+#include <string>
+
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
@@ -61,6 +68,7 @@ struct SortedParams {
     int32_t sr;              // 1: stochastic rounding of the updated row (16-bit tables)
     uint64_t sr_seed;
     int32_t exact_run;       // crossing runs up to this length are re-walked exactly in the fix-up
+    int32_t xcd_tpt;         // > 0: XCD-affine tile mapping of the main kernel, tiles per table (table-major order only)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -247,11 +255,32 @@ hipError_t rocprim_temp_bytes(int64_t n, int kbits_sort, size_t& bytes) {
                                      static_cast<unsigned>(kbits_sort), hipStream_t(0));
 }
 
+// Backward tuning knobs (pm_set_backward_tuning; defaults from the environment, read once):
+//   sort_impl  0 own radix sort (radix_sort.hip), 1 rocPRIM radix_sort_pairs          PARAM_AMD_SORT=rocprim
+//   order      0 (row, table, position): row bits sorted only, 1 (table, row, position) PARAM_AMD_SORT_ORDER=table
+//   xcd        1: XCD-affine tile mapping of the apply kernel (needs order 1)          PARAM_AMD_BWD_XCD=1
+std::atomic<int> g_sort_impl{-1}, g_sort_order{-1}, g_bwd_xcd{-1};
+int env_is(const char* name, const char* value) {
+    const char* e = getenv(name);
+    return (e && std::string(e) == value) ? 1 : 0;
+}
+int knob(std::atomic<int>& k, int env_default) {
+    int v = k.load();
+    if (v < 0) {
+        v = env_default;
+        k.store(v);
+    }
+    return v;
+}
+bool use_rocprim_sort() { return knob(g_sort_impl, env_is("PARAM_AMD_SORT", "rocprim")) == 1; }
+
 hipError_t ws_layout(void* base, int64_t n, int key_bytes, int kbits_sort, bool weighted, int max_dim, SortWs& ws) {
     size_t tb = 0;
     hipError_t rc = key_bytes == 4 ? rocprim_temp_bytes<uint32_t>(n, kbits_sort, tb)
                                    : rocprim_temp_bytes<uint64_t>(n, kbits_sort, tb);
     if (rc != hipSuccess) return rc;
+    const size_t own = rs_scratch_bytes(static_cast<size_t>(n));
+    if (own > tb) tb = own;
     char* p = reinterpret_cast<char*>(base);
     size_t off = 0;
     auto take = [&](size_t bytes) { char* q = p ? p + off : nullptr; off += align256(bytes); return q; };
@@ -275,6 +304,16 @@ inline int bits_for(int64_t n_values) {  // bits needed to represent 0 .. n_valu
     return b;
 }
 
+// Key bits the sort has to order.  Whole-batch requests: the row bits only (table-major input + stable sort keep every
+// (table, row) run contiguous).  Batch slices carry padding keys (bit kbits) that must end up last: all bits.
+// PARAM_AMD_SORT_ORDER=table sorts the table bits too (a fourth pass for 48 x 10 M-row tables): (table, row, position)
+// order, which the XCD-affine tile mapping of the apply kernel needs.
+bool table_major_order() { return knob(g_sort_order, env_is("PARAM_AMD_SORT_ORDER", "table")) == 1; }
+inline int sort_bits(int rbits, int kbits, bool sliced) { return sliced ? kbits + 1 : (table_major_order() ? kbits : rbits); }
+inline bool sorted_in_b(int rbits, int kbits, bool sliced) {
+    return use_rocprim_sort() || (rs_num_passes(0, sort_bits(rbits, kbits, sliced)) % 2 == 1);
+}
+
 template <typename K>
 hipError_t sort_impl(const KParams& p, bool weighted, int rbits, int kbits, int64_t slice_begin, int64_t slice_end,
                      bool sliced, SortWs& ws, hipStream_t stream) {
@@ -296,16 +335,21 @@ hipError_t sort_impl(const KParams& p, bool weighted, int rbits, int kbits, int6
     hipError_t rc = hipGetLastError();
     if (rc != hipSuccess) return rc;
     size_t tb = ws.temp_bytes;
-    // stable LSD radix sort over the used key bits only; sorted pairs land in keys_b / vals_b
-    return rocprim::radix_sort_pairs(ws.temp, tb, ka, kb, ws.vals_a, ws.vals_b, static_cast<size_t>(p.N), 0u,
-                                     static_cast<unsigned>(kbits + (sliced ? 1 : 0)), stream);
+    // stable LSD radix sort; bits: see sort_bits().  rocPRIM leaves the result in keys_b / vals_b, the own sort in the b
+    // buffers iff its pass count is odd (sorted_in_b()).
+    const int end_bit = sort_bits(rbits, kbits, sliced);
+    if (use_rocprim_sort())
+        return rocprim::radix_sort_pairs(ws.temp, tb, ka, kb, ws.vals_a, ws.vals_b, static_cast<size_t>(p.N), 0u,
+                                         static_cast<unsigned>(end_bit), stream);
+    return rs_sort_pairs<K>(ka, kb, ws.vals_a, ws.vals_b, static_cast<size_t>(p.N), nullptr, 0, end_bit, ws.temp, stream);
 }
 
 template <typename DST, typename K, int G>
 hipError_t launch_apply_w(const SortedParams& sp, hipStream_t stream) {
     constexpr int NG = kBlock / G;
     constexpr int C = kSortTile / NG;
-    const int64_t grid = (sp.n + kSortTile - 1) / kSortTile;
+    int64_t grid = (sp.n + kSortTile - 1) / kSortTile;
+    if (sp.xcd_tpt > 0) grid = static_cast<int64_t>(kXcds) * ((sp.T + kXcds - 1) / kXcds) * sp.xcd_tpt;
     const int64_t n_chunks = (sp.n + C - 1) / C;       // every chunk below this index wrote its record
     const int64_t fgrid = (n_chunks + NG - 1) / NG;
     const dim3 g1(static_cast<unsigned>(grid)), g2(static_cast<unsigned>(fgrid)), blk(kBlock);
@@ -362,6 +406,12 @@ static SortedGeom sorted_geom(const KParams& p, int64_t max_rows) {
     return g;
 }
 
+void set_backward_tuning(int sort_impl, int order, int xcd) {
+    g_sort_impl.store(sort_impl);
+    g_sort_order.store(order);
+    g_bwd_xcd.store(xcd);
+}
+
 hipError_t sorted_workspace_bytes(const KParams& p, int64_t max_rows, int max_dim, size_t& bytes) {
     const SortedGeom g = sorted_geom(p, max_rows);
     SortWs ws;
@@ -391,8 +441,9 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
     sp.recs = ws.recs;
     sp.partials = ws.partials;
     sp.T = p.T;
-    sp.keys = ws.keys_b;
-    sp.vals = ws.vals_b;
+    const bool in_b = sorted_in_b(g.rbits, g.kbits, g.sliced);
+    sp.keys = in_b ? ws.keys_b : ws.keys_a;
+    sp.vals = in_b ? ws.vals_b : ws.vals_a;
     sp.bag_of = ws.bag_of;
     sp.dst = const_cast<void* const*>(p.tables);
     sp.dims = p.dims;
@@ -414,6 +465,13 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
     sp.sr = (opt && opt->stochastic_rounding && dst_dtype != PM_F32) ? 1 : 0;
     sp.sr_seed = opt ? opt->seed : 0;
     sp.exact_run = kExactRun;
+    sp.xcd_tpt = 0;
+    {   // XCD-affine tiles: table-major order, whole batch, lookups dividing evenly over the tables (fixed pooling)
+        const int want = knob(g_bwd_xcd, env_is("PARAM_AMD_BWD_XCD", "1"));
+        const int64_t per_table = p.T > 0 ? p.N / p.T : 0;
+        if (want && table_major_order() && !g.sliced && p.T > 1 && per_table * p.T == p.N && per_table % kSortTile == 0)
+            sp.xcd_tpt = static_cast<int32_t>(per_table / kSortTile);
+    }
     if (sp.n == 0) return hipSuccess;
     return g.key_bytes == 4 ? launch_apply_k<uint32_t>(sp, dst_dtype, max_dim, stream)
                             : launch_apply_k<uint64_t>(sp, dst_dtype, max_dim, stream);

@@ -1,0 +1,138 @@
+"""The build's own radix sort (param_amd/csrc/radix_sort.hip, C ABI pm_radix_sort_pairs) against numpy's stable argsort,
+and the sorted backward under every sort / order / XCD-mapping setting against the CPU oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu_and_lib():
+    import param_amd
+
+    assert torch.cuda.is_available(), "gpu-marked tests need a ROCm device"
+    param_amd.load_library()
+    yield
+    param_amd.set_backward_tuning()
+
+
+def _sort(keys: np.ndarray, begin: int, end: int, count=None):
+    """runs pm_radix_sort_pairs with values = original positions; returns (keys_out, vals_out) of the first `count`"""
+    from param_amd import _lib
+
+    L = _lib.load()
+    n = keys.size
+    kb = keys.dtype.itemsize
+    ka = torch.from_numpy(keys.view(np.int32 if kb == 4 else np.int64).copy()).to(DEV)
+    kbuf = torch.full_like(ka, -1)
+    va = torch.arange(n, dtype=torch.int32, device=DEV)
+    vb = torch.full_like(va, -1)
+    need = L.pm_radix_sort_scratch_bytes(n)
+    assert need > 0
+    scratch = torch.empty(need, dtype=torch.uint8, device=DEV)
+    dcount = None if count is None else torch.tensor([count], dtype=torch.int32, device=DEV)
+    in_b = ctypes.c_int32(-1)
+    _lib.check(L.pm_radix_sort_pairs(ka.data_ptr(), kbuf.data_ptr(), va.data_ptr(), vb.data_ptr(), n,
+                                     None if dcount is None else dcount.data_ptr(), kb, begin, end, scratch.data_ptr(), need,
+                                     ctypes.byref(in_b), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert in_b.value == (((end - begin) + 7) // 8) % 2
+    ko, vo = (kbuf, vb) if in_b.value else (ka, va)
+    m = n if count is None else min(count, n)
+    return ko.cpu().numpy().view(keys.dtype)[:m], vo.cpu().numpy().view(np.uint32)[:m]
+
+
+def _expect(keys, begin, end, count=None):
+    m = keys.size if count is None else min(count, keys.size)
+    k = keys[:m]
+    if end == begin:
+        return k, np.arange(m, dtype=np.uint32)
+    digit = (k.astype(np.uint64) >> np.uint64(begin)) & np.uint64((1 << (end - begin)) - 1)
+    perm = np.argsort(digit, kind="stable")
+    return k[perm], perm.astype(np.uint32)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 4095, 4096, 4097, 100_003, 3_000_017])
+def test_radix_sort_matches_stable_argsort_u32(n):
+    rng = np.random.default_rng(n)
+    keys = rng.integers(0, 1 << 30, n, dtype=np.uint32)
+    for begin, end in [(0, 24), (0, 30), (3, 17), (0, 1), (0, 0), (0, 32)]:
+        ko, vo = _sort(keys, begin, end)
+        ek, ev = _expect(keys, begin, end)
+        assert np.array_equal(vo, ev), (n, begin, end)           # the permutation itself: stability included
+        assert np.array_equal(ko, ek), (n, begin, end)
+
+
+def test_radix_sort_skewed_equal_and_u64_keys():
+    rng = np.random.default_rng(5)
+    n = 1_200_001
+    # Zipf-like: most keys in a few values (whole waves / tiles of one digit), a long tail
+    z = np.minimum(rng.zipf(1.2, n), 1 << 23).astype(np.uint32)
+    tables = np.repeat(np.arange(8, dtype=np.uint32), (n + 7) // 8)[:n]           # table-major, like the backward's keys
+    keys = (tables << np.uint32(24)) | z
+    for begin, end in [(0, 24), (0, 27)]:
+        ko, vo = _sort(keys, begin, end)
+        ek, ev = _expect(keys, begin, end)
+        assert np.array_equal(vo, ev) and np.array_equal(ko, ek), (begin, end)
+    same = np.full(70_000, 0x00ABCDEF, dtype=np.uint32)
+    ko, vo = _sort(same, 0, 24)
+    assert np.array_equal(vo, np.arange(same.size, dtype=np.uint32))              # all equal: nothing moves
+    k64 = rng.integers(0, 1 << 62, 300_007, dtype=np.uint64)
+    for begin, end in [(0, 41), (20, 64), (0, 64)]:
+        ko, vo = _sort(k64, begin, end)
+        ek, ev = _expect(k64, begin, end)
+        assert np.array_equal(vo, ev) and np.array_equal(ko, ek), (begin, end)
+
+
+def test_radix_sort_device_side_count():
+    """the element count read from device memory: only the first `count` pairs are sorted, whatever n_max is"""
+    rng = np.random.default_rng(9)
+    keys = rng.integers(0, 1 << 24, 100_003, dtype=np.uint32)
+    for count in (0, 1, 4096, 70_001, 100_003, 1 << 30):
+        ko, vo = _sort(keys, 0, 24, count=count)
+        ek, ev = _expect(keys, 0, 24, count=count)
+        assert np.array_equal(vo, ev) and np.array_equal(ko, ek), count
+
+
+@pytest.mark.parametrize("sort_impl,order,xcd", [(0, 0, 0), (0, 1, 0), (0, 1, 1), (1, 0, 0), (1, 1, 1)])
+def test_sorted_backward_under_every_tuning(coracle, sort_impl, order, xcd):
+    """8 tables x 1024 bags x 16 lookups (per-table lookups = 16 tiles of 1024: the XCD-affine mapping engages), Zipf
+    duplicates incl. rows past the exact-run limit: every (own | rocPRIM) x (row | table order) x XCD-mapping setting
+    gives the oracle's bits on rows looked up <= 256 times and 1e-5 of an fp64 sum on the hot rows."""
+    import param_amd
+    from param_amd import BatchedEmbeddingBagMI355
+    from param_amd.indices import zipf_indices
+
+    param_amd.set_backward_tuning(sort_impl, order, xcd)
+    try:
+        T, R, D, B, L = 8, 30000, 128, 1024, 16
+        m = BatchedEmbeddingBagMI355([R] * T, D, device=DEV, init="normal", seed=3, fused_update=False)
+        g = torch.Generator().manual_seed(11)
+        idx = torch.cat([zipf_indices(1.15, R, B * L, 1, dedupe=False, generator=g) for _ in range(T)])
+        idx[:600] = 5                                    # > 256 lookups of one row in table 0
+        off = torch.arange(T * B + 1) * L
+        grad = torch.randn(B, T * D, generator=g)
+        W0 = [m.table(t).cpu().numpy().copy() for t in range(T)]
+        m.scatter_add_(grad.to(DEV), idx.to(DEV), off.to(DEV), alpha=-0.1)
+        ih, gh = idx.numpy(), grad.numpy()
+        for t in range(T):
+            s, e = t * B * L, (t + 1) * B * L
+            gt = np.ascontiguousarray(gh[:, t * D:(t + 1) * D])
+            exp = coracle.bwd_f32(W0[t].copy(), ih[s:e], np.arange(B, dtype=np.int64) * L, gt, None, alpha=-0.1)
+            got = m.table(t).cpu().numpy()
+            cnt = np.bincount(ih[s:e], minlength=R)
+            cold = cnt <= 256
+            assert np.array_equal(got[cold], exp[cold]), (t, sort_impl, order, xcd)
+            truth = W0[t].astype(np.float64)
+            np.add.at(truth, ih[s:e], -0.1 * gt.astype(np.float64)[np.repeat(np.arange(B), L)])
+            mag = np.abs(W0[t]).astype(np.float64)
+            np.add.at(mag, ih[s:e], 0.1 * np.abs(gt).astype(np.float64)[np.repeat(np.arange(B), L)])
+            assert (np.abs(got - truth) <= 1e-5 * mag + 1e-30).all(), (t, sort_impl, order, xcd)
+            if t == 0:
+                assert (~cold).sum() >= 1
+    finally:
+        param_amd.set_backward_tuning()
