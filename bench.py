@@ -541,7 +541,7 @@ def main():
         # + 4 B of state read-modify-write per touched row
         try:
             model.learning_rate = 1e-6
-            model.sort_indices(idx, off, batch=B_glob)
+            model.sort_indices(idx, off, batch=B_glob, for_adagrad=True)
             _, ag = time_steps(lambda: model.adagrad_step_(grad, idx, off, batch=B_glob, presorted=True), n_sub, 2, barrier)
             result["bwd_rowwise_adagrad"] = {"avg_s_apply_only": ag, "apply_only_alg_frac": bwd_bytes / ag / 1e9 / HBM_PEAK_GBPS}
         except Exception as exc:  # wide rows (> 64 lanes x vector) have no fused Adagrad

@@ -83,6 +83,11 @@ typedef struct pm_embbag_batch {
     const void* indices;          /* device [N] */
     const void* offsets;          /* device [T*B] or [T*B+1] */
     const float* per_sample_weights; /* device [N] or NULL */
+    int64_t fixed_pooling;        /* L > 0: the caller GUARANTEES every bag has exactly L lookups (offsets[i] == i * L,
+                                     num_indices == T * B * L) -- what every benchmark request of the reference looks like;
+                                     0: bags may be ragged.  A hint that changes speed only: the sorted backward then knows
+                                     where each table's lookups start without reading device memory (per-table sort segments,
+                                     XCD-affine and two-phase apply).  pm_embbag_check verifies it; the kernels do not. */
 } pm_embbag_batch;
 
 /* ABI / build identification. */
@@ -151,6 +156,16 @@ int pm_embbag_bwd(const pm_embbag_batch* op, const float* grad, void* const* dst
 int64_t pm_embbag_bwd_sorted_workspace(const pm_embbag_batch* op, int64_t max_rows);
 int pm_embbag_sort_indices(const pm_embbag_batch* op, int64_t max_rows, void* workspace,
                            int64_t workspace_bytes, pm_stream_t stream);
+/*
+ * The same with the number of BAG PHASES the apply may use: phases = 2 lets pm_embbag_bwd_sorted apply the lower and the
+ * upper half of the bags in two launches (each re-reads only half a table's gradient rows, which then stay in the L2 of the
+ * XCD serving that table) when the request has fixed pooling and its sizes allow; the result is unchanged (a row's
+ * lookups are still added in lookup order).  The fused row-wise Adagrad needs every row's lookups in one run: sort with
+ * phases = 1 (what pm_embbag_sort_indices does) for pm_embbag_bwd_sorted_adagrad*, which otherwise return PM_ERR_INVALID.
+ * The library remembers, per workspace, how the last sort was laid out; the apply call must follow on the same workspace.
+ */
+int pm_embbag_sort_indices_ex(const pm_embbag_batch* op, int64_t max_rows, int32_t phases, void* workspace,
+                              int64_t workspace_bytes, pm_stream_t stream);
 int pm_embbag_bwd_sorted(const pm_embbag_batch* op, const float* grad, void* const* dst_tables,
                          int32_t dst_dtype, float alpha, int64_t max_rows, const void* workspace,
                          int64_t workspace_bytes, pm_stream_t stream);
@@ -241,18 +256,21 @@ int pm_fill_random(void* dst, int64_t count, int32_t dtype, int32_t dist, float 
 int pm_set_tuning(int32_t unroll, int32_t bags_per_block, int32_t xcd_affine, int32_t nt_loads);
 
 /*
- * Tuning knobs of the sorted backward (process-wide; -1 = default, which the environment can set:
- * PARAM_AMD_SORT=rocprim, PARAM_AMD_SORT_ORDER=table, PARAM_AMD_BWD_XCD=1):
- *   sort_impl   0: the build's own radix sort (pm_radix_sort_pairs), 1: rocPRIM's radix_sort_pairs (kept as
- *               the measured alternative)
- *   order       0: pairs ordered by (row, table, position) -- only the row bits are sorted, the request being
- *               table-major already; 1: (table, row, position) -- one more radix pass
- *   xcd_affine  1 (with order 1): the apply kernel's tiles of table t run on XCD t % 8, so one table's gradient
- *               rows stay in one L2.  Placement and pass count change speed only; every setting gives the same
- *               result for rows looked up at most 256 times (longer runs: same value up to fp32 association).
- * A request sorted under one setting must be applied under the same setting.
+ * Tuning knobs of the sorted backward (process-wide; -1 = default, which the environment can change:
+ * PARAM_AMD_SORT=rocprim, PARAM_AMD_SORT_ORDER=row, PARAM_AMD_BWD_XCD=0, PARAM_AMD_BWD_PHASES=1):
+ *   sort_impl   0 (default): the build's own radix sort (pm_radix_sort_pairs), 1: rocPRIM's radix_sort_pairs (kept
+ *               as the measured alternative)
+ *   order       1 (default): pairs ordered by (table, [bag phase,] row, position); 0: (row, table, position) -- only
+ *               the row bits are sorted, the request being table-major already (one radix pass fewer, a slower apply)
+ *   xcd_affine  1 (default; needs order 1 and a fixed-pooling request): the apply kernel's tiles of table t run on
+ *               XCD t % 8, so one table's gradient rows are fetched into one L2
+ *   max_phases  2 (default): pm_embbag_sort_indices_ex(phases = 2) may lay a fixed-pooling request out for the
+ *               two-phase apply; 1: never.
+ * Placement, pass count and phases change speed only; every setting gives the same result for rows looked up at
+ * most 256 times (longer runs: same value up to fp32 association).
+ * Settings are read when a request is SORTED; its apply follows what the sort recorded.
  */
-int pm_set_backward_tuning(int32_t sort_impl, int32_t order, int32_t xcd_affine, int32_t reserved);
+int pm_set_backward_tuning(int32_t sort_impl, int32_t order, int32_t xcd_affine, int32_t max_phases);
 
 /*
  * Stable LSD radix sort of (key, uint32 value) pairs by key bits [begin_bit, end_bit) -- the sort the sorted
@@ -261,12 +279,14 @@ int pm_set_backward_tuning(int32_t sort_impl, int32_t order, int32_t xcd_affine,
  * (keys_a, vals_a); 8-bit passes alternate between the a and b buffers and *result_in_b says where the sorted
  * pairs ended up.  n_max <= 2^32 - 1 elements; if d_count is not NULL the number of elements is read from that
  * device uint32 when the kernels run (clamped to n_max), so a producer kernel can decide it without a host
- * round trip.  scratch: pm_radix_sort_scratch_bytes(n_max) bytes of device memory.
+ * round trip.  segment_len > 0 (a multiple of 4096 dividing n_max, d_count NULL): the array is a sequence of segments of
+ * that many pairs, each sorted on its own.  scratch: pm_radix_sort_scratch_bytes(n_max) bytes of device memory.
  */
 int64_t pm_radix_sort_scratch_bytes(int64_t n_max);
 int pm_radix_sort_pairs(void* keys_a, void* keys_b, uint32_t* vals_a, uint32_t* vals_b, int64_t n_max,
                         const uint32_t* d_count, int32_t key_bytes, int32_t begin_bit, int32_t end_bit,
-                        void* scratch, int64_t scratch_bytes, int32_t* result_in_b, pm_stream_t stream);
+                        int64_t segment_len, void* scratch, int64_t scratch_bytes, int32_t* result_in_b,
+                        pm_stream_t stream);
 
 
 #ifdef __cplusplus

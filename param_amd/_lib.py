@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = (
     "pm_embbag_bwd",
     "pm_embbag_bwd_sorted_workspace",
     "pm_embbag_sort_indices",
+    "pm_embbag_sort_indices_ex",
     "pm_embbag_bwd_sorted",
     "pm_embbag_bwd_sorted_adagrad",
     "pm_embbag_bwd_sorted_adagrad_ex",
@@ -77,6 +78,7 @@ class pm_embbag_batch(ctypes.Structure):
         ("indices", ctypes.c_void_p),
         ("offsets", ctypes.c_void_p),
         ("per_sample_weights", ctypes.c_void_p),
+        ("fixed_pooling", ctypes.c_int64),
     ]
 
 
@@ -123,6 +125,8 @@ def load() -> ctypes.CDLL:
         L.pm_embbag_bwd_sorted_workspace.argtypes = [ctypes.POINTER(pm_embbag_batch), i64]
         L.pm_embbag_sort_indices.restype = ctypes.c_int
         L.pm_embbag_sort_indices.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, vp, i64, vp]
+        L.pm_embbag_sort_indices_ex.restype = ctypes.c_int
+        L.pm_embbag_sort_indices_ex.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, i32, vp, i64, vp]
         L.pm_embbag_bwd_sorted.restype = ctypes.c_int
         L.pm_embbag_bwd_sorted.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, ctypes.c_float, i64, vp,
                                            i64, vp]
@@ -145,7 +149,7 @@ def load() -> ctypes.CDLL:
         L.pm_radix_sort_scratch_bytes.restype = ctypes.c_int64
         L.pm_radix_sort_scratch_bytes.argtypes = [i64]
         L.pm_radix_sort_pairs.restype = ctypes.c_int
-        L.pm_radix_sort_pairs.argtypes = [vp, vp, vp, vp, i64, vp, i32, i32, i32, vp, i64, ctypes.POINTER(ctypes.c_int32), vp]
+        L.pm_radix_sort_pairs.argtypes = [vp, vp, vp, vp, i64, vp, i32, i32, i32, i64, vp, i64, ctypes.POINTER(ctypes.c_int32), vp]
         if L.pm_abi_version() != PM_ABI_VERSION:
             raise ImportError(f"{LIB_PATH}: ABI version {L.pm_abi_version()} != {PM_ABI_VERSION}")
         _lib = L
@@ -161,7 +165,7 @@ def set_tuning(unroll: int = 0, bags_per_block: int = 0, xcd_affine: int = -1, n
     check(load().pm_set_tuning(unroll, bags_per_block, xcd_affine, nt_loads))
 
 
-def set_backward_tuning(sort_impl: int = -1, order: int = -1, xcd_affine: int = -1) -> None:
-    """sorted-backward knobs (``pm_set_backward_tuning``): sort_impl 0 own / 1 rocPRIM, order 0 (row, table) / 1 (table,
-    row), xcd_affine 0 / 1; -1 = default.  Sort and apply of one request must run under the same setting."""
-    check(load().pm_set_backward_tuning(sort_impl, order, xcd_affine, 0))
+def set_backward_tuning(sort_impl: int = -1, order: int = -1, xcd_affine: int = -1, max_phases: int = -1) -> None:
+    """sorted-backward knobs (``pm_set_backward_tuning``): sort_impl 0 own / 1 rocPRIM, order 1 (table, row) / 0 (row,
+    table), xcd_affine 1 / 0, max_phases 2 / 1; -1 = default.  Read when a request is sorted; its apply follows the sort."""
+    check(load().pm_set_backward_tuning(sort_impl, order, xcd_affine, max_phases))

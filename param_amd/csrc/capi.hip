@@ -44,6 +44,9 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p) {
         return fail(PM_ERR_UNSUPPORTED, "every dims[t] (and max_dim) must be a multiple of " +
                                             std::to_string(vec) + " for this element type");
     if (op->out_stride % 4 != 0) return fail(PM_ERR_UNSUPPORTED, "out_stride must be a multiple of 4 elements");
+    if (op->fixed_pooling < 0 ||
+        (op->fixed_pooling > 0 && op->fixed_pooling * op->batch * static_cast<int64_t>(op->num_tables) != op->num_indices))
+        return fail(PM_ERR_INVALID, "fixed_pooling must be 0 or num_indices / (num_tables * batch)");
 
     const int G = pm::group_lanes(op->max_dim, vec);
     const int NG = pm::kBlock / G;
@@ -132,11 +135,11 @@ int pm_set_tuning(int32_t unroll, int32_t bags_per_block, int32_t xcd_affine, in
     return PM_OK;
 }
 
-int pm_set_backward_tuning(int32_t sort_impl, int32_t order, int32_t xcd_affine, int32_t reserved) {
-    (void)reserved;
+int pm_set_backward_tuning(int32_t sort_impl, int32_t order, int32_t xcd_affine, int32_t max_phases) {
     if (sort_impl < -1 || sort_impl > 1 || order < -1 || order > 1 || xcd_affine < -1 || xcd_affine > 1)
         return fail(PM_ERR_INVALID, "sort_impl / order / xcd_affine must be -1, 0 or 1");
-    pm::set_backward_tuning(sort_impl, order, xcd_affine);
+    if (max_phases != -1 && max_phases != 1 && max_phases != 2) return fail(PM_ERR_INVALID, "max_phases must be -1, 1 or 2");
+    pm::set_backward_tuning(sort_impl, order, xcd_affine, max_phases);
     return PM_OK;
 }
 
@@ -146,12 +149,14 @@ int64_t pm_radix_sort_scratch_bytes(int64_t n_max) {
 }
 
 int pm_radix_sort_pairs(void* keys_a, void* keys_b, uint32_t* vals_a, uint32_t* vals_b, int64_t n_max,
-                        const uint32_t* d_count, int32_t key_bytes, int32_t begin_bit, int32_t end_bit, void* scratch,
-                        int64_t scratch_bytes, int32_t* result_in_b, pm_stream_t stream) {
+                        const uint32_t* d_count, int32_t key_bytes, int32_t begin_bit, int32_t end_bit, int64_t segment_len,
+                        void* scratch, int64_t scratch_bytes, int32_t* result_in_b, pm_stream_t stream) {
     if (n_max < 0 || n_max > 0xffffffffLL) return fail(PM_ERR_INVALID, "n_max must be in [0, 2^32)");
     if (key_bytes != 4 && key_bytes != 8) return fail(PM_ERR_INVALID, "key_bytes must be 4 or 8");
     if (begin_bit < 0 || end_bit < begin_bit || end_bit > key_bytes * 8) return fail(PM_ERR_INVALID, "bad bit range");
     if (!result_in_b) return fail(PM_ERR_INVALID, "result_in_b is NULL");
+    if (segment_len < 0 || (segment_len > 0 && (segment_len % 4096 != 0 || n_max % segment_len != 0 || d_count)))
+        return fail(PM_ERR_INVALID, "segment_len must be 0 or a multiple of 4096 dividing n_max (and d_count NULL)");
     *result_in_b = pm::rs_num_passes(begin_bit, end_bit) % 2;
     if (n_max == 0) return PM_OK;
     if (!keys_a || !keys_b || !vals_a || !vals_b) return fail(PM_ERR_INVALID, "key / value buffers are NULL");
@@ -159,9 +164,11 @@ int pm_radix_sort_pairs(void* keys_a, void* keys_b, uint32_t* vals_a, uint32_t* 
         return fail(PM_ERR_INVALID, "scratch too small: need " + std::to_string(pm::rs_scratch_bytes(static_cast<size_t>(n_max))) + " bytes");
     hipError_t h = key_bytes == 4
         ? pm::rs_sort_pairs<uint32_t>(static_cast<uint32_t*>(keys_a), static_cast<uint32_t*>(keys_b), vals_a, vals_b,
-                                      static_cast<size_t>(n_max), d_count, begin_bit, end_bit, scratch, static_cast<hipStream_t>(stream))
+                                      static_cast<size_t>(n_max), d_count, begin_bit, end_bit, scratch, static_cast<hipStream_t>(stream),
+                                      static_cast<size_t>(segment_len))
         : pm::rs_sort_pairs<uint64_t>(static_cast<uint64_t*>(keys_a), static_cast<uint64_t*>(keys_b), vals_a, vals_b,
-                                      static_cast<size_t>(n_max), d_count, begin_bit, end_bit, scratch, static_cast<hipStream_t>(stream));
+                                      static_cast<size_t>(n_max), d_count, begin_bit, end_bit, scratch, static_cast<hipStream_t>(stream),
+                                      static_cast<size_t>(segment_len));
     if (h != hipSuccess) return hip_fail(h, "pm_radix_sort_pairs");
     return PM_OK;
 }
@@ -227,6 +234,12 @@ int64_t pm_embbag_bwd_sorted_workspace(const pm_embbag_batch* op, int64_t max_ro
 
 int pm_embbag_sort_indices(const pm_embbag_batch* op, int64_t max_rows, void* workspace, int64_t workspace_bytes,
                            pm_stream_t stream) {
+    return pm_embbag_sort_indices_ex(op, max_rows, 1, workspace, workspace_bytes, stream);
+}
+
+int pm_embbag_sort_indices_ex(const pm_embbag_batch* op, int64_t max_rows, int32_t phases, void* workspace,
+                              int64_t workspace_bytes, pm_stream_t stream) {
+    if (phases != 1 && phases != 2) return fail(PM_ERR_INVALID, "phases must be 1 or 2");
     pm::KParams p;
     int rc = make_params(op, op ? op->weight_dtype : -1, p);
     if (rc != PM_OK) return rc;
@@ -237,7 +250,7 @@ int pm_embbag_sort_indices(const pm_embbag_batch* op, int64_t max_rows, void* wo
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_sort_indices");
     if (!workspace || workspace_bytes < static_cast<int64_t>(need))
         return fail(PM_ERR_INVALID, "workspace too small: need " + std::to_string(need) + " bytes");
-    h = pm::sort_indices(p, max_rows, op->max_dim, workspace, static_cast<hipStream_t>(stream));
+    h = pm::sort_indices(p, max_rows, op->max_dim, op->fixed_pooling, phases, workspace, static_cast<hipStream_t>(stream));
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_sort_indices");
     return PM_OK;
 }
@@ -256,6 +269,8 @@ int pm_embbag_bwd_sorted(const pm_embbag_batch* op, const float* grad, void* con
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_bwd_sorted");
     if (!workspace || workspace_bytes < static_cast<int64_t>(need))
         return fail(PM_ERR_INVALID, "workspace too small: need " + std::to_string(need) + " bytes");
+    if (pm::bwd_sorted_plan_check(p, max_rows, workspace, false) != 0)
+        return fail(PM_ERR_INVALID, "pm_embbag_sort_indices has not been called for this request on this workspace");
     p.io = const_cast<float*>(grad);
     p.tables = const_cast<const void* const*>(dst_tables);
     p.alpha = alpha;
@@ -285,6 +300,14 @@ int pm_embbag_bwd_sorted_adagrad_ex(const pm_embbag_batch* op, const float* grad
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_bwd_sorted_adagrad");
     if (!workspace || workspace_bytes < static_cast<int64_t>(need))
         return fail(PM_ERR_INVALID, "workspace too small: need " + std::to_string(need) + " bytes");
+    {
+        const int pc = pm::bwd_sorted_plan_check(p, max_rows, workspace, true);
+        if (pc == 2)
+            return fail(PM_ERR_INVALID, "the request was sorted for a two-phase scatter-add apply; row-wise Adagrad needs "
+                                        "pm_embbag_sort_indices (phases = 1)");
+        if (pc != 0)
+            return fail(PM_ERR_INVALID, "pm_embbag_sort_indices has not been called for this request on this workspace");
+    }
     p.io = const_cast<float*>(grad);
     p.tables = const_cast<const void* const*>(tables);
     p.alpha = 1.0f;
@@ -317,7 +340,7 @@ int pm_embbag_check(const pm_embbag_batch* op, int32_t* d_error_count, pm_stream
     int rc = make_params(op, op ? op->weight_dtype : -1, p);
     if (rc != PM_OK) return rc;
     if (!d_error_count) return fail(PM_ERR_INVALID, "d_error_count is NULL");
-    hipError_t h = pm::launch_embbag_check(p, d_error_count, op->weight_dtype == PM_F32 ? 4 : 8, op->max_dim,
+    hipError_t h = pm::launch_embbag_check(p, d_error_count, op->weight_dtype == PM_F32 ? 4 : 8, op->max_dim, op->fixed_pooling,
                                            static_cast<hipStream_t>(stream));
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_check launch");
     return PM_OK;

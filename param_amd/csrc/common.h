@@ -121,13 +121,16 @@ hipError_t launch_embbag_fwd(const KParams& p, int weight_dtype, int max_dim, in
                              hipStream_t stream);
 hipError_t launch_embbag_fwd_split(const KParams& p, int weight_dtype, int max_dim, hipStream_t stream);
 hipError_t launch_embbag_bwd(const KParams& p, int dst_dtype, int max_dim, hipStream_t stream);
-hipError_t launch_embbag_check(const KParams& p, int32_t* d_err, int vec, int max_dim, hipStream_t stream);
+hipError_t launch_embbag_check(const KParams& p, int32_t* d_err, int vec, int max_dim, int64_t fixed_pooling,
+                               hipStream_t stream);
 hipError_t launch_fill_random(void* dst, int64_t count, int dtype, int dist, float lo, float hi,
                               uint64_t seed, hipStream_t stream);
 
 // sort-based deterministic backward (embbag_bwd_sorted.hip)
 hipError_t sorted_workspace_bytes(const KParams& p, int64_t max_rows, int max_dim, size_t& bytes);
-hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, void* workspace, hipStream_t stream);
+hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, int64_t fixed_pooling, int phases, void* workspace,
+                        hipStream_t stream);
+int bwd_sorted_plan_check(const KParams& p, int64_t max_rows, const void* workspace, bool adagrad);
 hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, int max_dim, const void* workspace,
                             float* const* momentum, const pm_rowwise_adagrad* opt, hipStream_t stream);
 
@@ -136,9 +139,9 @@ size_t rs_scratch_bytes(size_t n_max);
 int rs_num_passes(int begin_bit, int end_bit);   // result lands in the b buffers iff odd
 template <typename K>
 hipError_t rs_sort_pairs(K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n_max, const uint32_t* d_count,
-                         int begin_bit, int end_bit, void* scratch, hipStream_t stream);
+                         int begin_bit, int end_bit, void* scratch, hipStream_t stream, size_t seg_len = 0);
 
-void set_backward_tuning(int sort_impl, int order, int xcd);   // -1 = default (environment)
+void set_backward_tuning(int sort_impl, int order, int xcd, int max_phases);   // -1 = default (environment)
 
 // DLRM input redistribution (dlrm_regroup.hip)
 hipError_t launch_dlrm_regroup(const int64_t* lengths, const int64_t* indices, int W, int F, int64_t B,

@@ -27,7 +27,9 @@
 // on a side stream under the forward pass; pm_embbag_bwd_sorted() is step 3.
 #include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -68,15 +70,19 @@ struct SortedParams {
     int32_t sr;              // 1: stochastic rounding of the updated row (16-bit tables)
     uint64_t sr_seed;
     int32_t exact_run;       // crossing runs up to this length are re-walked exactly in the fix-up
-    int32_t xcd_tpt;         // > 0: XCD-affine tile mapping of the main kernel, tiles per table (table-major order only)
+    int32_t tshift;          // table id = key >> tshift (rbits + phase bits)
+    int32_t seg_tiles;       // > 0: the sorted array is T * H equal segments of this many tiles (fixed pooling)
+    int32_t H;               // bag phases (1 or 2): segments are (table, phase), one apply launch per phase
+    int32_t phase;           // phase this launch applies
+    int32_t xcd;             // 1: XCD-affine block -> tile mapping (needs seg_tiles)
 };
 
 // ---------------------------------------------------------------------------------------------
 // step 1: keys / values, same tiling and LDS offset staging as the forward
 template <typename K, bool WEIGHTED>
 __global__ void __launch_bounds__(kBlock) build_keys_kernel(const KParams p, K* keys, uint32_t* vals,
-                                                            uint32_t* bag_of, int rbits, int kbits,
-                                                            int64_t slice_begin, int64_t slice_end) {
+                                                            uint32_t* bag_of, int rbits, int tshift, int kbits,
+                                                            int64_t phase_bags, int64_t slice_begin, int64_t slice_end) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int t, tile;
     block_to_tile(p, t, tile);
@@ -101,7 +107,10 @@ __global__ void __launch_bounds__(kBlock) build_keys_kernel(const KParams p, K* 
         const int64_t bag = bag0 + lo;
         const K row = static_cast<K>(load_index(p.indices, j, p.idx64));
         const bool in_slice = bag >= slice_begin && bag < slice_end;
-        keys[j] = in_slice ? ((static_cast<K>(t) << rbits) | row) : pad;
+        // (table, bag phase, row): phase = which run of phase_bags consecutive bags the lookup belongs to (0 everywhere when
+        // the apply runs in one phase); the phase sits between table and row so that a (table, phase) segment sorts by row
+        const K phase = phase_bags > 0 ? static_cast<K>(bag / phase_bags) : static_cast<K>(0);
+        keys[j] = in_slice ? ((static_cast<K>(t) << tshift) | (phase << rbits) | row) : pad;
         if (WEIGHTED) {
             vals[j] = static_cast<uint32_t>(j);
             bag_of[j] = static_cast<uint32_t>(bag);
@@ -255,11 +264,12 @@ hipError_t rocprim_temp_bytes(int64_t n, int kbits_sort, size_t& bytes) {
                                      static_cast<unsigned>(kbits_sort), hipStream_t(0));
 }
 
-// Backward tuning knobs (pm_set_backward_tuning; defaults from the environment, read once):
-//   sort_impl  0 own radix sort (radix_sort.hip), 1 rocPRIM radix_sort_pairs          PARAM_AMD_SORT=rocprim
-//   order      0 (row, table, position): row bits sorted only, 1 (table, row, position) PARAM_AMD_SORT_ORDER=table
-//   xcd        1: XCD-affine tile mapping of the apply kernel (needs order 1)          PARAM_AMD_BWD_XCD=1
-std::atomic<int> g_sort_impl{-1}, g_sort_order{-1}, g_bwd_xcd{-1};
+// Backward tuning knobs (pm_set_backward_tuning; -1 = default, which the environment can override once):
+//   sort_impl  0 own radix sort (radix_sort.hip), 1 rocPRIM radix_sort_pairs              PARAM_AMD_SORT=rocprim
+//   order      1 (table, [phase,] row, position) -- default --, 0 (row, table, position):   PARAM_AMD_SORT_ORDER=row
+//              only the row bits are sorted (one pass fewer; the apply kernel then runs 5 % slower and cannot be XCD-affine)
+//   xcd        1 (default): XCD-affine tile mapping of the apply kernel where the layout allows  PARAM_AMD_BWD_XCD=0
+std::atomic<int> g_sort_impl{-1}, g_sort_order{-1}, g_bwd_xcd{-1}, g_max_phases{-1};
 int env_is(const char* name, const char* value) {
     const char* e = getenv(name);
     return (e && std::string(e) == value) ? 1 : 0;
@@ -273,10 +283,14 @@ int knob(std::atomic<int>& k, int env_default) {
     return v;
 }
 bool use_rocprim_sort() { return knob(g_sort_impl, env_is("PARAM_AMD_SORT", "rocprim")) == 1; }
+bool table_major_order() { return knob(g_sort_order, env_is("PARAM_AMD_SORT_ORDER", "row") ? 0 : 1) == 1; }
+bool want_xcd() { return knob(g_bwd_xcd, env_is("PARAM_AMD_BWD_XCD", "0") ? 0 : 1) == 1; }
+//   max_phases 2 (default): a phases = 2 sort may lay the request out for the two-phase apply; 1: never  PARAM_AMD_BWD_PHASES=1
+int max_phases() { return knob(g_max_phases, env_is("PARAM_AMD_BWD_PHASES", "1") ? 1 : 2); }
 
 hipError_t ws_layout(void* base, int64_t n, int key_bytes, int kbits_sort, bool weighted, int max_dim, SortWs& ws) {
     size_t tb = 0;
-    hipError_t rc = key_bytes == 4 ? rocprim_temp_bytes<uint32_t>(n, kbits_sort, tb)
+    hipError_t rc = key_bytes == 4 ? rocprim_temp_bytes<uint32_t>(n, kbits_sort > 32 ? 32 : kbits_sort, tb)
                                    : rocprim_temp_bytes<uint64_t>(n, kbits_sort, tb);
     if (rc != hipSuccess) return rc;
     const size_t own = rs_scratch_bytes(static_cast<size_t>(n));
@@ -304,19 +318,60 @@ inline int bits_for(int64_t n_values) {  // bits needed to represent 0 .. n_valu
     return b;
 }
 
-// Key bits the sort has to order.  Whole-batch requests: the row bits only (table-major input + stable sort keep every
-// (table, row) run contiguous).  Batch slices carry padding keys (bit kbits) that must end up last: all bits.
-// PARAM_AMD_SORT_ORDER=table sorts the table bits too (a fourth pass for 48 x 10 M-row tables): (table, row, position)
-// order, which the XCD-affine tile mapping of the apply kernel needs.
-bool table_major_order() { return knob(g_sort_order, env_is("PARAM_AMD_SORT_ORDER", "table")) == 1; }
-inline int sort_bits(int rbits, int kbits, bool sliced) { return sliced ? kbits + 1 : (table_major_order() ? kbits : rbits); }
-inline bool sorted_in_b(int rbits, int kbits, bool sliced) {
-    return use_rocprim_sort() || (rs_num_passes(0, sort_bits(rbits, kbits, sliced)) % 2 == 1);
+// Everything the sort and the apply have to agree on, derived in ONE place from the request, the knobs and the number
+// of bag phases asked for.  pm_embbag_sort_indices records the plan it sorted under (keyed by the workspace); the apply
+// entry points use that record.
+//
+// key = (table << tshift) | (phase << rbits) | row, padding keys (batch slices only) = 1 << kbits.
+//   fixed pooling (every bag L lookups, op->fixed_pooling = L) and a whole-batch request make the table-major request a
+//   sequence of T * H equal segments of seg_len = (B / H) * L lookups, H = bag phases.  If seg_len is a multiple of the
+//   sort tile the own sort orders every segment on its own by the ROW bits only (3 passes of 8 bits for 10 M rows: the
+//   table and phase bits need no pass); if it is a multiple of the apply tile the apply kernel can run XCD-affine and
+//   in H launches.  Everything else (ragged bags, slices, odd sizes) sorts all key bits globally and applies in one launch.
+struct SortPlan {
+    int key_bytes, rbits, hbits, tshift, kbits;
+    bool sliced, weighted, rocprim, segmented, in_b, xcd;
+    int H;
+    int64_t n, seg_len, phase_bags;
+    int sort_end_bit;
+    int32_t seg_tiles;   // apply tiles (kSortTile) per segment, 0 = no segment structure
+    int32_t T;
+};
+
+SortPlan make_plan(const KParams& p, int64_t max_rows, int64_t fixed_pooling, int phases) {
+    SortPlan g;
+    g.T = p.T;
+    g.n = p.N;
+    g.rbits = bits_for(max_rows);
+    g.sliced = !(p.bag_begin == 0 && p.bag_count == p.B);
+    g.weighted = p.psw != nullptr;
+    g.rocprim = use_rocprim_sort();
+    const bool fixed = fixed_pooling > 0 && !g.sliced && p.T >= 1 && p.B > 0 &&
+                       fixed_pooling * p.B * static_cast<int64_t>(p.T) == p.N;
+    g.H = 1;
+    if (phases == 2 && max_phases() >= 2 && fixed && table_major_order() && p.B % 2 == 0 && ((p.B / 2) * fixed_pooling) % kSortTile == 0) g.H = 2;
+    g.hbits = g.H == 2 ? 1 : 0;
+    g.tshift = g.rbits + g.hbits;
+    g.kbits = g.tshift + bits_for(p.T);
+    g.key_bytes = (g.kbits + 1 <= 32) ? 4 : 8;
+    g.phase_bags = g.H == 2 ? p.B / 2 : 0;
+    g.seg_len = fixed ? (p.B / g.H) * fixed_pooling : 0;
+    g.seg_tiles = (fixed && table_major_order() && g.seg_len % kSortTile == 0) ? static_cast<int32_t>(g.seg_len / kSortTile) : 0;
+    // (one workgroup walks a segment's tile counts: beyond a few thousand tiles per segment the global scan is the faster one)
+    g.segmented = fixed && table_major_order() && !g.rocprim && g.seg_len > 0 && g.seg_len % 4096 == 0 && g.seg_len / 4096 <= 4096;
+    g.xcd = want_xcd() && g.seg_tiles > 0 && p.T > 1;
+    if (g.sliced) g.sort_end_bit = g.kbits + 1;                  // padding keys must end up last
+    else if (g.segmented) g.sort_end_bit = g.rbits;              // per (table, phase) segment: rows only
+    else g.sort_end_bit = table_major_order() ? g.kbits : g.rbits;
+    g.in_b = g.rocprim || (rs_num_passes(0, g.sort_end_bit) % 2 == 1);
+    return g;
 }
 
+std::mutex g_plan_mutex;
+std::unordered_map<const void*, SortPlan> g_plans;   // workspace -> the plan of the last sort issued on it
+
 template <typename K>
-hipError_t sort_impl(const KParams& p, bool weighted, int rbits, int kbits, int64_t slice_begin, int64_t slice_end,
-                     bool sliced, SortWs& ws, hipStream_t stream) {
+hipError_t sort_impl(const KParams& p, const SortPlan& g, SortWs& ws, hipStream_t stream) {
     KParams q = p;
     q.bag_begin = 0;
     q.bag_count = p.B;
@@ -326,30 +381,32 @@ hipError_t sort_impl(const KParams& p, bool weighted, int rbits, int kbits, int6
     const size_t lds = static_cast<size_t>(q.bags_per_block + 2) * sizeof(int64_t);
     K* ka = reinterpret_cast<K*>(ws.keys_a);
     K* kb = reinterpret_cast<K*>(ws.keys_b);
-    if (weighted)
+    const int64_t s0 = p.bag_begin, s1 = p.bag_begin + p.bag_count;
+    if (g.weighted)
         hipLaunchKernelGGL((build_keys_kernel<K, true>), dim3(grid), dim3(kBlock), lds, stream, q, ka, ws.vals_a,
-                           ws.bag_of, rbits, kbits, slice_begin, slice_end);
+                           ws.bag_of, g.rbits, g.tshift, g.kbits, g.phase_bags, s0, s1);
     else
         hipLaunchKernelGGL((build_keys_kernel<K, false>), dim3(grid), dim3(kBlock), lds, stream, q, ka, ws.vals_a,
-                           ws.bag_of, rbits, kbits, slice_begin, slice_end);
+                           ws.bag_of, g.rbits, g.tshift, g.kbits, g.phase_bags, s0, s1);
     hipError_t rc = hipGetLastError();
     if (rc != hipSuccess) return rc;
     size_t tb = ws.temp_bytes;
-    // stable LSD radix sort; bits: see sort_bits().  rocPRIM leaves the result in keys_b / vals_b, the own sort in the b
-    // buffers iff its pass count is odd (sorted_in_b()).
-    const int end_bit = sort_bits(rbits, kbits, sliced);
-    if (use_rocprim_sort())
+    // stable LSD radix sort.  rocPRIM leaves the result in keys_b / vals_b, the own sort in the b buffers iff its pass
+    // count is odd (plan.in_b).
+    if (g.rocprim)
         return rocprim::radix_sort_pairs(ws.temp, tb, ka, kb, ws.vals_a, ws.vals_b, static_cast<size_t>(p.N), 0u,
-                                         static_cast<unsigned>(end_bit), stream);
-    return rs_sort_pairs<K>(ka, kb, ws.vals_a, ws.vals_b, static_cast<size_t>(p.N), nullptr, 0, end_bit, ws.temp, stream);
+                                         static_cast<unsigned>(g.sort_end_bit), stream);
+    return rs_sort_pairs<K>(ka, kb, ws.vals_a, ws.vals_b, static_cast<size_t>(p.N), nullptr, 0, g.sort_end_bit, ws.temp, stream,
+                            g.segmented ? static_cast<size_t>(g.seg_len) : 0);
 }
 
 template <typename DST, typename K, int G>
-hipError_t launch_apply_w(const SortedParams& sp, hipStream_t stream) {
+hipError_t launch_apply_w(SortedParams sp, hipStream_t stream) {
     constexpr int NG = kBlock / G;
     constexpr int C = kSortTile / NG;
     int64_t grid = (sp.n + kSortTile - 1) / kSortTile;
-    if (sp.xcd_tpt > 0) grid = static_cast<int64_t>(kXcds) * ((sp.T + kXcds - 1) / kXcds) * sp.xcd_tpt;
+    if (sp.seg_tiles > 0)
+        grid = (sp.xcd ? static_cast<int64_t>(kXcds) * ((sp.T + kXcds - 1) / kXcds) : static_cast<int64_t>(sp.T)) * sp.seg_tiles;
     const int64_t n_chunks = (sp.n + C - 1) / C;       // every chunk below this index wrote its record
     const int64_t fgrid = (n_chunks + NG - 1) / NG;
     const dim3 g1(static_cast<unsigned>(grid)), g2(static_cast<unsigned>(fgrid)), blk(kBlock);
@@ -359,11 +416,15 @@ hipError_t launch_apply_w(const SortedParams& sp, hipStream_t stream) {
                            static_cast<size_t>(sp.T) * ((OPT_) == 1 ? 28 : 20), stream, sp);                  \
         hipLaunchKernelGGL((bwd_sorted_fixup_kernel<DST, K, G, W_, OPT_>), g2, blk, 0, stream, sp, n_chunks); \
     } while (0)
-    if (sp.mom) {  // row-wise Adagrad: one column pass with all G lanes (cross-lane reduction)
-        if (sp.max_dim > G * DST::kVec) return hipErrorInvalidValue;
-        if (sp.psw) PM_LAUNCH_SORTED(true, 1); else PM_LAUNCH_SORTED(false, 1);
-    } else {
-        if (sp.psw) PM_LAUNCH_SORTED(true, 0); else PM_LAUNCH_SORTED(false, 0);
+    // one (main, fix-up) pair per bag phase, in stream order: phase 0 has updated a row before phase 1 touches it
+    for (int ph = 0; ph < sp.H; ++ph) {
+        sp.phase = ph;
+        if (sp.mom) {  // row-wise Adagrad: one column pass with all G lanes (cross-lane reduction)
+            if (sp.max_dim > G * DST::kVec || sp.H != 1) return hipErrorInvalidValue;
+            if (sp.psw) PM_LAUNCH_SORTED(true, 1); else PM_LAUNCH_SORTED(false, 1);
+        } else {
+            if (sp.psw) PM_LAUNCH_SORTED(true, 0); else PM_LAUNCH_SORTED(false, 0);
+        }
     }
 #undef PM_LAUNCH_SORTED
     return hipGetLastError();
@@ -388,62 +449,76 @@ hipError_t launch_apply_k(const SortedParams& sp, int dst_dtype, int max_dim, hi
     }
 }
 
+// the workspace is sized for the widest key the request can get (two phases), whatever plan is used later
+int ws_key_bytes(const KParams& p, int64_t max_rows) { return (bits_for(max_rows) + 1 + bits_for(p.T) + 1 <= 32) ? 4 : 8; }
+int ws_kbits_sort(const KParams& p, int64_t max_rows) { return bits_for(max_rows) + 1 + bits_for(p.T) + 1; }
+
 }  // namespace
 
 // ---- entry points used by capi.hip -----------------------------------------------------------
-struct SortedGeom {
-    int key_bytes, rbits, kbits;
-    bool sliced, weighted;
-};
-
-static SortedGeom sorted_geom(const KParams& p, int64_t max_rows) {
-    SortedGeom g;
-    g.rbits = bits_for(max_rows);
-    g.kbits = g.rbits + bits_for(p.T);
-    g.sliced = !(p.bag_begin == 0 && p.bag_count == p.B);
-    g.weighted = p.psw != nullptr;
-    g.key_bytes = (g.kbits + 1 <= 32) ? 4 : 8;
-    return g;
-}
-
-void set_backward_tuning(int sort_impl, int order, int xcd) {
+void set_backward_tuning(int sort_impl, int order, int xcd, int max_phases_) {
     g_sort_impl.store(sort_impl);
     g_sort_order.store(order);
     g_bwd_xcd.store(xcd);
+    g_max_phases.store(max_phases_);
 }
 
 hipError_t sorted_workspace_bytes(const KParams& p, int64_t max_rows, int max_dim, size_t& bytes) {
-    const SortedGeom g = sorted_geom(p, max_rows);
     SortWs ws;
-    hipError_t rc = ws_layout(nullptr, p.N, g.key_bytes, g.kbits + 1, g.weighted, max_dim, ws);
+    hipError_t rc = ws_layout(nullptr, p.N, ws_key_bytes(p, max_rows), ws_kbits_sort(p, max_rows), p.psw != nullptr, max_dim, ws);
     bytes = ws.total;
     return rc;
 }
 
-hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, void* workspace, hipStream_t stream) {
-    const SortedGeom g = sorted_geom(p, max_rows);
+hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, int64_t fixed_pooling, int phases, void* workspace,
+                        hipStream_t stream) {
+    const SortPlan g = make_plan(p, max_rows, fixed_pooling, phases);
     SortWs ws;
-    hipError_t rc = ws_layout(workspace, p.N, g.key_bytes, g.kbits + 1, g.weighted, max_dim, ws);
+    hipError_t rc = ws_layout(workspace, p.N, ws_key_bytes(p, max_rows), ws_kbits_sort(p, max_rows), g.weighted, max_dim, ws);
     if (rc != hipSuccess) return rc;
-    return g.key_bytes == 4
-               ? sort_impl<uint32_t>(p, g.weighted, g.rbits, g.kbits, p.bag_begin, p.bag_begin + p.bag_count, g.sliced, ws, stream)
-               : sort_impl<uint64_t>(p, g.weighted, g.rbits, g.kbits, p.bag_begin, p.bag_begin + p.bag_count, g.sliced, ws, stream);
+    {
+        std::lock_guard<std::mutex> lock(g_plan_mutex);
+        g_plans[workspace] = g;
+    }
+    // the key type follows the PLAN (a one-phase plan of a request whose two-phase key would need 33 bits still sorts
+    // 4-byte keys); the buffers were sized for the wider of the two
+    return g.key_bytes == 4 ? sort_impl<uint32_t>(p, g, ws, stream) : sort_impl<uint64_t>(p, g, ws, stream);
+}
+
+// 0: ok, 1: no sort was recorded for this workspace / it was for another request, 2: sorted in two bag phases but the
+// apply (row-wise Adagrad) needs every row's lookups in ONE run
+int bwd_sorted_plan_check(const KParams& p, int64_t max_rows, const void* workspace, bool adagrad) {
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    auto it = g_plans.find(workspace);
+    if (it == g_plans.end()) return 1;
+    const SortPlan& g = it->second;
+    if (g.n != p.N || g.T != p.T || g.rbits != bits_for(max_rows) || g.weighted != (p.psw != nullptr) ||
+        g.sliced != !(p.bag_begin == 0 && p.bag_count == p.B))
+        return 1;
+    if (adagrad && g.H != 1) return 2;
+    return 0;
 }
 
 hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, int max_dim, const void* workspace,
                             float* const* momentum, const pm_rowwise_adagrad* opt, hipStream_t stream) {
-    const SortedGeom g = sorted_geom(p, max_rows);
+    SortPlan g;
+    {
+        std::lock_guard<std::mutex> lock(g_plan_mutex);
+        auto it = g_plans.find(workspace);
+        if (it == g_plans.end()) return hipErrorInvalidValue;
+        g = it->second;
+    }
     SortWs ws;
-    hipError_t rc = ws_layout(const_cast<void*>(workspace), p.N, g.key_bytes, g.kbits + 1, g.weighted, max_dim, ws);
+    hipError_t rc = ws_layout(const_cast<void*>(workspace), p.N, ws_key_bytes(p, max_rows), ws_kbits_sort(p, max_rows), g.weighted,
+                              max_dim, ws);
     if (rc != hipSuccess) return rc;
     if (p.T > kMaxTablesLds) return hipErrorInvalidValue;
     SortedParams sp;
     sp.recs = ws.recs;
     sp.partials = ws.partials;
     sp.T = p.T;
-    const bool in_b = sorted_in_b(g.rbits, g.kbits, g.sliced);
-    sp.keys = in_b ? ws.keys_b : ws.keys_a;
-    sp.vals = in_b ? ws.vals_b : ws.vals_a;
+    sp.keys = g.in_b ? ws.keys_b : ws.keys_a;
+    sp.vals = g.in_b ? ws.vals_b : ws.vals_a;
     sp.bag_of = ws.bag_of;
     sp.dst = const_cast<void* const*>(p.tables);
     sp.dims = p.dims;
@@ -454,6 +529,7 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
     sp.n = p.N;
     sp.rbits = g.rbits;
     sp.kbits = g.kbits;
+    sp.tshift = g.tshift;
     sp.max_dim = max_dim;
     sp.nt_rows = p.nt_loads;
     sp.alpha = p.alpha;
@@ -465,13 +541,10 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
     sp.sr = (opt && opt->stochastic_rounding && dst_dtype != PM_F32) ? 1 : 0;
     sp.sr_seed = opt ? opt->seed : 0;
     sp.exact_run = kExactRun;
-    sp.xcd_tpt = 0;
-    {   // XCD-affine tiles: table-major order, whole batch, lookups dividing evenly over the tables (fixed pooling)
-        const int want = knob(g_bwd_xcd, env_is("PARAM_AMD_BWD_XCD", "1"));
-        const int64_t per_table = p.T > 0 ? p.N / p.T : 0;
-        if (want && table_major_order() && !g.sliced && p.T > 1 && per_table * p.T == p.N && per_table % kSortTile == 0)
-            sp.xcd_tpt = static_cast<int32_t>(per_table / kSortTile);
-    }
+    sp.seg_tiles = (g.xcd || g.H > 1) ? g.seg_tiles : 0;
+    sp.H = g.H;
+    sp.phase = 0;
+    sp.xcd = g.xcd ? 1 : 0;
     if (sp.n == 0) return hipSuccess;
     return g.key_bytes == 4 ? launch_apply_k<uint32_t>(sp, dst_dtype, max_dim, stream)
                             : launch_apply_k<uint64_t>(sp, dst_dtype, max_dim, stream);

@@ -5,6 +5,7 @@
 //
 //   rs_hist_kernel     per 4096-element tile: how many keys carry each digit value             -> bh[tile][256]
 //   rs_scan_kernel     per digit: exclusive prefix of the tile counts over tiles (in place)     -> bh, total[256]
+//                      (rs_scan_seg_kernel: per segment, when the array is a sequence of independently sorted segments)
 //   rs_scatter_kernel  per tile: stable rank of every element among the tile's elements of the same digit (wave-level
 //                      match by eight ballots, per-wave running counters in LDS, waves own consecutive quarters of the
 //                      tile), tile reordered by digit in LDS, then written out so that elements of one digit leave as
@@ -62,9 +63,17 @@ __global__ void __launch_bounds__(kRsThreads) rs_hist_kernel(const K* keys, cons
         const uint64_t i = tile0 + static_cast<uint64_t>(k) * kRsThreads + threadIdx.x;
         const bool valid = i < n;
         const uint32_t d = valid ? static_cast<uint32_t>(keys[i] >> shift) & mask : 0u;
-        // one LDS atomic per distinct digit of the wave (a Zipf head makes most of a tile's top digits equal)
-        const uint64_t m = match_digit(d, valid);
-        if (valid && (m & ((1ull << lane) - 1ull)) == 0) atomicAdd(&h[d], static_cast<uint32_t>(__popcll(m)));
+        // A wave whose 64 keys share the digit (the top digits of a Zipf head, of small tables, of any nearly sorted
+        // input) adds once; otherwise one LDS atomic per lane -- distinct digits do not conflict, and the eight-ballot
+        // match that would merge the equal ones costs more than the conflicts of a mixed wave (24.8 -> ~10 us per pass).
+        const uint64_t vmask = __ballot(valid);
+        const uint32_t first = __builtin_amdgcn_readfirstlane(d);
+        const bool uniform = __ballot(valid && d != first) == 0 && (vmask & 1ull);
+        if (uniform) {
+            if (lane == 0) atomicAdd(&h[first], static_cast<uint32_t>(__popcll(vmask)));
+        } else if (valid) {
+            atomicAdd(&h[d], 1u);
+        }
     }
     __syncthreads();
     bh[static_cast<uint64_t>(blockIdx.x) * kRsRadix + threadIdx.x] = h[threadIdx.x];
@@ -105,6 +114,25 @@ __global__ void __launch_bounds__(kScanThreads) rs_scan_kernel(uint32_t* bh, uin
     }
 }
 
+// Segmented form (every segment = seg_tiles whole tiles, sorted independently): one workgroup per segment, thread = digit,
+// rows of the segment walked in order (each row is one coalesced 1 KB read), eight per round trip.
+__global__ void __launch_bounds__(kRsRadix) rs_scan_seg_kernel(uint32_t* bh, uint32_t* total, uint32_t seg_tiles) {
+    const int d = threadIdx.x;
+    const uint64_t r0 = static_cast<uint64_t>(blockIdx.x) * seg_tiles;
+    uint32_t run = 0;
+    for (uint32_t r = 0; r < seg_tiles; r += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (r + u < seg_tiles) ? bh[(r0 + r + u) * kRsRadix + d] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (r + u < seg_tiles) bh[(r0 + r + u) * kRsRadix + d] = run;
+            run += v[u];
+        }
+    }
+    total[static_cast<uint64_t>(blockIdx.x) * kRsRadix + d] = run;
+}
+
 // exclusive scan of one value per thread over the 256 threads of the workgroup; s_tmp: kRsWaves words
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_tmp) {
     const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
@@ -125,7 +153,8 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_tmp)
 template <typename K>
 __global__ void __launch_bounds__(kRsThreads) rs_scatter_kernel(const K* kin, const uint32_t* vin, K* kout, uint32_t* vout,
                                                                 const uint32_t* d_count, uint32_t n_max, int shift,
-                                                                uint32_t mask, const uint32_t* prefix, const uint32_t* total) {
+                                                                uint32_t mask, const uint32_t* prefix, const uint32_t* total,
+                                                                uint32_t seg_tiles) {
     __shared__ K s_key[kRsTile];
     __shared__ uint32_t s_val[kRsTile];
     __shared__ uint32_t s_wcnt[kRsWaves][kRsRadix];   // per wave: running digit counts, later the wave's base inside the digit
@@ -176,9 +205,11 @@ __global__ void __launch_bounds__(kRsThreads) rs_scatter_kernel(const K* kin, co
             acc += c;
         }
         const uint32_t dstart = block_excl_scan(acc, s_tmp);
-        const uint32_t gdigit = block_excl_scan(total[d], s_tmp);
+        // segmented: the tile's segment starts at seg * seg_tiles * tile size and has its own digit totals
+        const uint32_t seg = seg_tiles ? blockIdx.x / seg_tiles : 0u;
+        const uint32_t gdigit = block_excl_scan(total[static_cast<uint64_t>(seg) * kRsRadix + d], s_tmp);
         s_dstart[d] = dstart;
-        s_gbase[d] = gdigit + prefix[static_cast<uint64_t>(blockIdx.x) * kRsRadix + d];
+        s_gbase[d] = seg * seg_tiles * static_cast<uint32_t>(kRsTile) + gdigit + prefix[static_cast<uint64_t>(blockIdx.x) * kRsRadix + d];
     }
     __syncthreads();
 #pragma unroll
@@ -209,8 +240,9 @@ inline size_t rs_tiles(size_t n_max) { return (n_max + kRsTile - 1) / kRsTile; }
 
 }  // namespace
 
+// tile counts + per-segment digit totals (at most one segment per tile)
 size_t rs_scratch_bytes(size_t n_max) {
-    return (rs_tiles(n_max) * kRsRadix + kRsRadix) * sizeof(uint32_t) + 256;
+    return (2 * rs_tiles(n_max) * kRsRadix + kRsRadix) * sizeof(uint32_t) + 256;
 }
 
 int rs_num_passes(int begin_bit, int end_bit) {
@@ -220,11 +252,16 @@ int rs_num_passes(int begin_bit, int end_bit) {
 
 // Sorts by key bits [begin_bit, end_bit).  The pairs start in (keys_a, vals_a); passes alternate between the a and b
 // buffers, so the result is in the b buffers iff rs_num_passes() is odd (0 passes: nothing moves, result in a).
+// seg_len > 0: the array is a sequence of segments of seg_len elements (a multiple of the 4096-element tile, n_max a
+// multiple of seg_len, no d_count), each sorted on its own -- the backward's tables (x bag phases) when every bag has the
+// same number of lookups: the table bits then need no pass at all.
 template <typename K>
 hipError_t rs_sort_pairs(K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n_max, const uint32_t* d_count,
-                         int begin_bit, int end_bit, void* scratch, hipStream_t stream) {
+                         int begin_bit, int end_bit, void* scratch, hipStream_t stream, size_t seg_len) {
     if (n_max == 0) return hipSuccess;
     if (n_max > 0xffffffffull) return hipErrorInvalidValue;
+    if (seg_len && (seg_len % kRsTile || n_max % seg_len || d_count)) return hipErrorInvalidValue;
+    const uint32_t seg_tiles = static_cast<uint32_t>(seg_len / kRsTile);
     const int passes = rs_num_passes(begin_bit, end_bit);
     const int bits = end_bit - begin_bit;
     uint32_t* bh = reinterpret_cast<uint32_t*>(scratch);
@@ -241,17 +278,20 @@ hipError_t rs_sort_pairs(K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_
         const uint32_t* vin = (p % 2 == 0) ? vals_a : vals_b;
         uint32_t* vout = (p % 2 == 0) ? vals_b : vals_a;
         hipLaunchKernelGGL((rs_hist_kernel<K>), dim3(grid), dim3(kRsThreads), 0, stream, kin, d_count, n32, shift, mask, bh);
-        hipLaunchKernelGGL(rs_scan_kernel, dim3(kRsRadix / kScanDigits), dim3(kScanThreads), 0, stream, bh, total, d_count, n32);
+        if (seg_tiles)
+            hipLaunchKernelGGL(rs_scan_seg_kernel, dim3(grid / seg_tiles), dim3(kRsRadix), 0, stream, bh, total, seg_tiles);
+        else
+            hipLaunchKernelGGL(rs_scan_kernel, dim3(kRsRadix / kScanDigits), dim3(kScanThreads), 0, stream, bh, total, d_count, n32);
         hipLaunchKernelGGL((rs_scatter_kernel<K>), dim3(grid), dim3(kRsThreads), 0, stream, kin, vin, kout, vout, d_count, n32,
-                           shift, mask, bh, total);
+                           shift, mask, bh, total, seg_tiles);
         shift += w;
     }
     return hipGetLastError();
 }
 
 template hipError_t rs_sort_pairs<uint32_t>(uint32_t*, uint32_t*, uint32_t*, uint32_t*, size_t, const uint32_t*, int, int,
-                                            void*, hipStream_t);
+                                            void*, hipStream_t, size_t);
 template hipError_t rs_sort_pairs<uint64_t>(uint64_t*, uint64_t*, uint32_t*, uint32_t*, size_t, const uint32_t*, int, int,
-                                            void*, hipStream_t);
+                                            void*, hipStream_t, size_t);
 
 }  // namespace pm

@@ -10,7 +10,8 @@ namespace {
 // Block 0 also validates what the kernels assume about the per-table DEVICE arrays, which the host side of the C ABI
 // cannot see: rows[t] in [1, 2^31) (staged indices are narrowed to int32), dims[t] a multiple of the 16-byte vector and
 // <= max_dim, out_offsets[t] 16-byte aligned, table base pointers 16-byte aligned.
-__global__ void __launch_bounds__(kBlock) embbag_check_kernel(const KParams p, int32_t* err, int vec, int max_dim) {
+__global__ void __launch_bounds__(kBlock) embbag_check_kernel(const KParams p, int32_t* err, int vec, int max_dim,
+                                                              int64_t fixed_pooling) {
     const int64_t per_table = p.bag_count;
     const int64_t total = per_table * p.T;
     int bad = 0;
@@ -35,6 +36,7 @@ __global__ void __launch_bounds__(kBlock) embbag_check_kernel(const KParams p, i
             ++bad;
             continue;
         }
+        if (fixed_pooling > 0 && (s != g * fixed_pooling || e - s != fixed_pooling)) ++bad;   // the caller's fixed-pooling claim
         const int64_t rows = p.rows[t];
         for (int64_t j = s; j < e; ++j) {
             const int64_t r = load_index(p.indices, j, p.idx64);
@@ -111,7 +113,8 @@ __global__ void __launch_bounds__(kBlock) fill_random_kernel(void* dst, int64_t 
 
 }  // namespace
 
-hipError_t launch_embbag_check(const KParams& p, int32_t* d_err, int vec, int max_dim, hipStream_t stream) {
+hipError_t launch_embbag_check(const KParams& p, int32_t* d_err, int vec, int max_dim, int64_t fixed_pooling,
+                               hipStream_t stream) {
     hipError_t rc = hipMemsetAsync(d_err, 0, sizeof(int32_t), stream);
     if (rc != hipSuccess) return rc;
     const int64_t total = p.bag_count * p.T;
@@ -119,7 +122,7 @@ hipError_t launch_embbag_check(const KParams& p, int32_t* d_err, int vec, int ma
     if (blocks < 1) blocks = 1;   // the per-table checks run even for an empty batch slice
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(embbag_check_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, p, d_err, vec,
-                       max_dim);
+                       max_dim, fixed_pooling);
     return hipGetLastError();
 }
 

@@ -98,6 +98,7 @@ class _TableSet:
         self.d_col0 = torch.tensor(col0, dtype=torch.int64, device=self.device)
         self._tbd_cache: dict[int, torch.Tensor] = {}
         self._req_key, self._req_op = None, None
+        self._pool_key, self._pool_val = None, 0
 
     def out_desc(self, B: int):
         """(out_offsets device tensor, out_stride, output shape) for a batch of B bags."""
@@ -122,6 +123,23 @@ class _TableSet:
         op = self._build_request(indices, offsets, B, psw, bag_begin, bag_count, d_ptrs)
         self._req_key, self._req_op = key, op
         return op
+
+    def fixed_pooling(self, indices, offsets, B, claim: Optional[int] = None) -> int:
+        """L if every bag of the request has exactly L lookups, else 0 (``pm_embbag_batch.fixed_pooling``: lets the sorted
+        backward use per-table sort segments, the XCD-affine and the two-phase apply).  ``claim``: the caller's word for it
+        (no device read).  Otherwise ONE comparison on the device per new ``offsets`` tensor, remembered while the same
+        tensor is passed again (benchmark loops); pass ``pooling=`` to the module methods to skip it in a training loop."""
+        n, tb = indices.numel(), self.T * B
+        if claim is not None:
+            return int(claim) if claim > 0 and tb * int(claim) == n else 0
+        if tb == 0 or n == 0 or n % tb:
+            return 0
+        key = (offsets.data_ptr(), offsets.numel(), offsets.dtype, n, B)
+        if key != self._pool_key:
+            L = n // tb
+            ramp = torch.arange(tb, dtype=offsets.dtype, device=offsets.device) * L
+            self._pool_key, self._pool_val = key, (L if bool(torch.equal(offsets[:tb], ramp)) else 0)
+        return self._pool_val
 
     def _build_request(self, indices, offsets, B, psw, bag_begin, bag_count, d_ptrs=None) -> _lib.pm_embbag_batch:
         _require_device(indices, "indices")
@@ -155,6 +173,7 @@ class _TableSet:
         op.indices = indices.data_ptr()
         op.offsets = offsets.data_ptr()
         op.per_sample_weights = None if psw is None else psw.data_ptr()
+        op.fixed_pooling = 0          # filled in by the sorted backward (fixed_pooling()); the forward does not use it
         return op
 
 
@@ -184,17 +203,20 @@ def _workspace(ts: _TableSet, op) -> torch.Tensor:
     return ws
 
 
-def _sort_indices(ts: _TableSet, indices, offsets, B, psw=None, bag_begin=0, bag_count=None) -> None:
+def _sort_indices(ts: _TableSet, indices, offsets, B, psw=None, bag_begin=0, bag_count=None, phases: int = 2,
+                  pooling: Optional[int] = None) -> None:
     """Step 1+2 of the deterministic backward (keys + stable radix sort): needs only the request,
-    so it can be issued early / on another stream; ``_bwd(..., presorted=True)`` consumes it."""
+    so it can be issued early / on another stream; ``_bwd(..., presorted=True)`` consumes it.  ``phases=2`` (scatter-add /
+    SGD apply) lets the apply run in two bag phases where the request allows; the fused row-wise Adagrad needs ``phases=1``."""
     op = ts.request(indices, offsets, B, psw, bag_begin, bag_count)
+    op.fixed_pooling = ts.fixed_pooling(indices, offsets, B, pooling)
     ws = _workspace(ts, op)
-    _lib.check(_lib.load().pm_embbag_sort_indices(ctypes.byref(op), max(ts.rows), ws.data_ptr(), ws.numel(),
-                                                  _stream_ptr()))
+    _lib.check(_lib.load().pm_embbag_sort_indices_ex(ctypes.byref(op), max(ts.rows), phases, ws.data_ptr(), ws.numel(),
+                                                     _stream_ptr()))
 
 
 def _bwd(ts: _TableSet, grad, indices, offsets, B, dst_ptrs_dev, dst_dtype, alpha, psw=None,
-         bag_begin=0, bag_count=None, method: str = "sorted", presorted: bool = False):
+         bag_begin=0, bag_count=None, method: str = "sorted", presorted: bool = False, pooling: Optional[int] = None):
     """``method="sorted"`` (default): deterministic, bit-identical to a sequential scatter-add;
     ``method="atomic"``: hardware float atomics (order not fixed)."""
     _require_device(grad, "grad")
@@ -212,7 +234,8 @@ def _bwd(ts: _TableSet, grad, indices, offsets, B, dst_ptrs_dev, dst_dtype, alph
         raise ValueError('method must be "sorted" or "atomic"')
     ws = _workspace(ts, op)
     if not presorted:
-        _lib.check(L.pm_embbag_sort_indices(ctypes.byref(op), max(ts.rows), ws.data_ptr(), ws.numel(), _stream_ptr()))
+        op.fixed_pooling = ts.fixed_pooling(indices, offsets, B, pooling)
+        _lib.check(L.pm_embbag_sort_indices_ex(ctypes.byref(op), max(ts.rows), 2, ws.data_ptr(), ws.numel(), _stream_ptr()))
     _lib.check(L.pm_embbag_bwd_sorted(ctypes.byref(op), grad.data_ptr(), dst_ptrs_dev.data_ptr(), _WDTYPE[dst_dtype],
                                       float(alpha), max(ts.rows), ws.data_ptr(), ws.numel(), _stream_ptr()))
 
@@ -234,7 +257,7 @@ _WD_MODES = {None: _lib.PM_WD_NONE, "none": _lib.PM_WD_NONE, 0: _lib.PM_WD_NONE,
 
 def _adagrad(ts: _TableSet, grad, indices, offsets, B, mom_ptrs_dev, lr: float, eps: float, psw=None,
              presorted: bool = False, weight_decay: float = 0.0, weight_decay_mode=None, stochastic_rounding: bool = False,
-             seed: int = 0):
+             seed: int = 0, pooling: Optional[int] = None):
     """Fused backward + exact row-wise Adagrad on the tables of ``ts`` (``pm_embbag_bwd_sorted_adagrad_ex``)."""
     if weight_decay_mode not in _WD_MODES:
         raise ValueError(f"weight_decay_mode must be one of none / l2 / decouple, got {weight_decay_mode!r}")
@@ -247,7 +270,8 @@ def _adagrad(ts: _TableSet, grad, indices, offsets, B, mom_ptrs_dev, lr: float, 
     L = _lib.load()
     ws = _workspace(ts, op)
     if not presorted:
-        _lib.check(L.pm_embbag_sort_indices(ctypes.byref(op), max(ts.rows), ws.data_ptr(), ws.numel(), _stream_ptr()))
+        op.fixed_pooling = ts.fixed_pooling(indices, offsets, B, pooling)
+        _lib.check(L.pm_embbag_sort_indices_ex(ctypes.byref(op), max(ts.rows), 1, ws.data_ptr(), ws.numel(), _stream_ptr()))
     opt = _lib.pm_rowwise_adagrad(float(lr), float(eps), float(weight_decay), _WD_MODES[weight_decay_mode],
                                   1 if stochastic_rounding else 0, 0, int(seed) & (2**64 - 1))
     _lib.check(L.pm_embbag_bwd_sorted_adagrad_ex(ctypes.byref(op), grad.data_ptr(), ts.d_ptrs.data_ptr(), _WDTYPE[ts.dtype],
@@ -436,19 +460,24 @@ class BatchedEmbeddingBagMI355(nn.Module):
             return _FusedUpdateFn.apply(self._anchor, self, indices, offsets, per_sample_weights)
         return self.lookup(indices, offsets, per_sample_weights)
 
-    def sort_indices(self, indices, offsets, per_sample_weights=None, batch: Optional[int] = None) -> None:
-        """Pre-sort the request for the deterministic backward (can overlap the forward)."""
+    def sort_indices(self, indices, offsets, per_sample_weights=None, batch: Optional[int] = None,
+                     for_adagrad: Optional[bool] = None, pooling: Optional[int] = None) -> None:
+        """Pre-sort the request for the deterministic backward (can overlap the forward).  ``for_adagrad`` (default: what
+        the module's optimizer is): the fused row-wise Adagrad needs a one-phase sort, the scatter-add apply may use two."""
         B = self._batch_of(offsets, indices) if batch is None else batch
-        _sort_indices(self._tables(), indices, offsets, B, per_sample_weights)
+        if for_adagrad is None:
+            for_adagrad = self.optimizer == "rowwise_adagrad"
+        _sort_indices(self._tables(), indices, offsets, B, per_sample_weights, phases=1 if for_adagrad else 2, pooling=pooling)
 
     def scatter_add_(self, grad, indices, offsets, alpha: float, per_sample_weights=None,
                      batch: Optional[int] = None, bag_begin=0, bag_count=None, method: str = "sorted",
-                     presorted: bool = False):
-        """In place ``W_t[idx[j]] += alpha * psw[j] * grad(t, bag(j))`` (alpha = -lr: SGD step)."""
+                     presorted: bool = False, pooling: Optional[int] = None):
+        """In place ``W_t[idx[j]] += alpha * psw[j] * grad(t, bag(j))`` (alpha = -lr: SGD step).  ``pooling``: the
+        caller's word that every bag has exactly that many lookups (saves the one-off device check of a new request)."""
         ts = self._tables()
         B = self._batch_of(offsets, indices) if batch is None else batch
         _bwd(ts, grad, indices, offsets, B, ts.d_ptrs, self.weights.dtype, alpha, per_sample_weights,
-             bag_begin, bag_count, method, presorted)
+             bag_begin, bag_count, method, presorted, pooling)
 
     def momentum_table(self, t: int) -> torch.Tensor:
         """row-wise Adagrad state of table t (allocated zero on first use)"""
@@ -466,7 +495,7 @@ class BatchedEmbeddingBagMI355(nn.Module):
         return self.momentum[s:s + self.rows[t]]
 
     def adagrad_step_(self, grad, indices, offsets, per_sample_weights=None, batch: Optional[int] = None,
-                      presorted: bool = False):
+                      presorted: bool = False, pooling: Optional[int] = None):
         """Fused backward + exact row-wise Adagrad (TBE ``EXACT_ROWWISE_ADAGRAD``, the optimizer the reference
         configures at comms_utils.py:2014): ``m[r] += mean_d(G[r,d]^2); W[r] -= lr / (sqrt(m[r]) + eps) * G[r]``,
         with the module's ``weight_decay`` / ``weight_decay_mode`` (l2 | decouple) and, for 16-bit tables,
@@ -476,7 +505,7 @@ class BatchedEmbeddingBagMI355(nn.Module):
         self._sr_step += 1          # a fresh stochastic-rounding stream every step, reproducible run to run
         _adagrad(self._tables(), grad, indices, offsets, B, self._mom_ptrs, self.learning_rate, self.eps,
                  per_sample_weights, presorted, self.weight_decay, self.weight_decay_mode, self.stochastic_rounding,
-                 seed=0x5EED0000 + self._sr_step)
+                 seed=0x5EED0000 + self._sr_step, pooling=pooling)
 
     def optimizer_step_(self, grad, indices, offsets, per_sample_weights=None, batch: Optional[int] = None,
                         presorted: bool = False):

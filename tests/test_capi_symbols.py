@@ -30,8 +30,9 @@ def test_library_loads_and_exports_every_symbol():
 
 
 def test_struct_layout_matches_header():
-    # 4 x int32, 4 x int64, 4 pointers, int64, 3 pointers = 16 + 32 + 32 + 8 + 24
-    assert ctypes.sizeof(_lib.pm_embbag_batch) == 112
+    # 4 x int32, 4 x int64, 4 pointers, int64, 3 pointers, int64 = 16 + 32 + 32 + 8 + 24 + 8
+    assert ctypes.sizeof(_lib.pm_embbag_batch) == 120
+    assert _lib.pm_embbag_batch.fixed_pooling.offset == 112
     assert _lib.pm_embbag_batch.tables.offset == 48
     assert _lib.pm_embbag_batch.out_stride.offset == 80
     assert _lib.pm_embbag_batch.per_sample_weights.offset == 104
@@ -54,6 +55,14 @@ def test_argument_validation_without_gpu():
     assert b"bag_begin" in L.pm_last_error()
     assert L.pm_set_tuning(3, 0, -1, -1) == _lib.PM_ERR_INVALID
     assert L.pm_set_tuning(0, 0, -1, -1) == _lib.PM_OK
+    assert L.pm_set_backward_tuning(2, 0, 0, -1) == _lib.PM_ERR_INVALID and L.pm_set_backward_tuning(-1, -1, -1, -1) == _lib.PM_OK
+    in_b = ctypes.c_int32(-1)
+    assert L.pm_radix_sort_pairs(None, None, None, None, 0, None, 4, 0, 24, 0, None, 0, ctypes.byref(in_b), None) == _lib.PM_OK
+    assert in_b.value == 1                                        # 3 passes: the result would be in the b buffers
+    assert L.pm_radix_sort_pairs(None, None, None, None, 10, None, 3, 0, 24, 0, None, 0, ctypes.byref(in_b), None) == _lib.PM_ERR_INVALID
+    assert L.pm_radix_sort_pairs(None, None, None, None, 8192, None, 4, 0, 24, 1000, None, 0, ctypes.byref(in_b), None) == _lib.PM_ERR_INVALID
+    assert b"segment_len" in L.pm_last_error()
+    assert L.pm_radix_sort_scratch_bytes(1 << 20) > 0 and L.pm_radix_sort_scratch_bytes(-1) == _lib.PM_ERR_INVALID
     assert L.pm_fill_random(None, -1, _lib.PM_F32, 0, 0.0, 1.0, 0, None) == _lib.PM_ERR_INVALID
     # empty request: nothing to launch, succeeds without a device
     op.batch = op.bag_begin = op.bag_count = 0

@@ -20,7 +20,7 @@ def _need_gpu_and_lib():
     param_amd.set_backward_tuning()
 
 
-def _sort(keys: np.ndarray, begin: int, end: int, count=None):
+def _sort(keys: np.ndarray, begin: int, end: int, count=None, seg_len: int = 0):
     """runs pm_radix_sort_pairs with values = original positions; returns (keys_out, vals_out) of the first `count`"""
     from param_amd import _lib
 
@@ -37,7 +37,7 @@ def _sort(keys: np.ndarray, begin: int, end: int, count=None):
     dcount = None if count is None else torch.tensor([count], dtype=torch.int32, device=DEV)
     in_b = ctypes.c_int32(-1)
     _lib.check(L.pm_radix_sort_pairs(ka.data_ptr(), kbuf.data_ptr(), va.data_ptr(), vb.data_ptr(), n,
-                                     None if dcount is None else dcount.data_ptr(), kb, begin, end, scratch.data_ptr(), need,
+                                     None if dcount is None else dcount.data_ptr(), kb, begin, end, seg_len, scratch.data_ptr(), need,
                                      ctypes.byref(in_b), torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert in_b.value == (((end - begin) + 7) // 8) % 2
@@ -98,6 +98,22 @@ def test_radix_sort_device_side_count():
         assert np.array_equal(vo, ev) and np.array_equal(ko, ek), count
 
 
+def test_radix_sort_segmented():
+    """segments of 8192 / 4096 pairs sorted independently: the order inside every segment is numpy's stable order, and no
+    pair leaves its segment"""
+    rng = np.random.default_rng(12)
+    for seg, nseg in [(8192, 37), (4096, 5), (163840, 3)]:
+        n = seg * nseg
+        keys = rng.integers(0, 1 << 24, n, dtype=np.uint32) | (np.repeat(np.arange(nseg, dtype=np.uint32), seg) << np.uint32(24))
+        keys[:seg // 2] = keys[0]                                # a run of equal keys inside segment 0
+        ko, vo = _sort(keys, 0, 24, seg_len=seg)
+        for s_ in range(nseg):
+            sl = slice(s_ * seg, (s_ + 1) * seg)
+            ek, ev = _expect(keys[sl], 0, 24)
+            assert np.array_equal(ko[sl], ek), (seg, s_)
+            assert np.array_equal(vo[sl], ev + np.uint32(s_ * seg)), (seg, s_)
+
+
 @pytest.mark.parametrize("sort_impl,order,xcd", [(0, 0, 0), (0, 1, 0), (0, 1, 1), (1, 0, 0), (1, 1, 1)])
 def test_sorted_backward_under_every_tuning(coracle, sort_impl, order, xcd):
     """8 tables x 1024 bags x 16 lookups (per-table lookups = 16 tiles of 1024: the XCD-affine mapping engages), Zipf
@@ -136,3 +152,49 @@ def test_sorted_backward_under_every_tuning(coracle, sort_impl, order, xcd):
                 assert (~cold).sum() >= 1
     finally:
         param_amd.set_backward_tuning()
+
+
+def test_two_phase_apply_engages_and_adagrad_refuses_it(coracle):
+    """fixed pooling + aligned sizes: the scatter-add sorts for two bag phases (pm_embbag_sort_indices_ex(phases=2)); the
+    same request declared ragged (pooling=0) takes the general one-launch path -- both give the oracle's bits; the fused
+    Adagrad refuses a two-phase sort; pm_embbag_check verifies a fixed-pooling claim."""
+    import param_amd
+    from param_amd import BatchedEmbeddingBagMI355, _lib
+    from param_amd.embedding_bag import _sort_indices
+
+    T, R, D, B, L = 4, 5000, 64, 512, 8          # (B / 2) * L = 2048: two apply tiles per (table, phase) segment
+    g = torch.Generator().manual_seed(4)
+    idx = torch.randint(0, R, (T * B * L,), generator=g)
+    idx[: 3 * L] = 7                             # one row looked up in bags 0..2 (lower half) ...
+    idx[(B - 2) * L:(B - 2) * L + L] = 7         # ... and in bag B-2 (upper half): updated by both phases, in order
+    off = torch.arange(T * B + 1) * L
+    grad = torch.randn(B, T * D, generator=g)
+    results = []
+    for pooling in (None, 0):
+        m = BatchedEmbeddingBagMI355([R] * T, D, device=DEV, init="normal", seed=9, fused_update=False)
+        W0 = [m.table(t).cpu().numpy().copy() for t in range(T)]
+        m.scatter_add_(grad.to(DEV), idx.to(DEV), off.to(DEV), alpha=0.5, pooling=pooling)
+        for t in range(T):
+            s, e = t * B * L, (t + 1) * B * L
+            gt = np.ascontiguousarray(grad.numpy()[:, t * D:(t + 1) * D])
+            exp = coracle.bwd_f32(W0[t].copy(), idx.numpy()[s:e], np.arange(B, dtype=np.int64) * L, gt, None, alpha=0.5)
+            assert np.array_equal(m.table(t).cpu().numpy(), exp), (pooling, t)
+        results.append(m)
+    m = results[0]
+    ts = m._tables()
+    assert ts.fixed_pooling(idx.to(DEV), off.to(DEV), B) == L and ts.fixed_pooling(idx.to(DEV), off.to(DEV), B, claim=3) == 0
+    di, do = idx.to(DEV), off.to(DEV)
+    _sort_indices(ts, di, do, B, phases=2)
+    m.optimizer = "rowwise_adagrad"
+    with pytest.raises(param_amd.ParamAmdError, match="two-phase"):
+        m.adagrad_step_(grad.to(DEV), di, do, presorted=True)
+    m.adagrad_step_(grad.to(DEV), di, do)                        # sorts for itself (one phase): fine
+    # a wrong fixed-pooling claim is caught by the check entry point
+    ragged = off.clone()
+    ragged[5] += 1
+    op = ts.request(di, ragged.to(DEV), B, None, 0, None)
+    op.fixed_pooling = L
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.check(_lib.load().pm_embbag_check(ctypes.byref(op), err.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    assert int(err.item()) >= 1
+    op.fixed_pooling = 0

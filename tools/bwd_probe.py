@@ -19,13 +19,15 @@ ap.add_argument("--tables", type=int, default=48)
 ap.add_argument("--rows", type=int, default=10_000_000)
 ap.add_argument("--dtype", default="fp32")
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--layout", default="bd")
+ap.add_argument("--configs", default="", help="semicolon-separated sort_impl,order,xcd,nt tuples (default: the full matrix)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 T, R, D, B, L = a.tables, a.rows, 128, 8192, 20
 dt = {"fp32": torch.float32, "bf16": torch.bfloat16}[a.dtype]
 es = 4 if a.dtype == "fp32" else 2
-m = param_amd.BatchedEmbeddingBagMI355([R] * T, D, dtype=dt, device=dev, init="normal", seed=1, fused_update=False)
-grad = torch.randn(B, T * D, device=dev)
+m = param_amd.BatchedEmbeddingBagMI355([R] * T, D, dtype=dt, device=dev, init="normal", seed=1, fused_update=False, layout=a.layout)
+grad = torch.randn((B, T * D) if a.layout == "bd" else (T, B, D), device=dev)
 reqs = {"uniform": tbe_request([R] * T, B, L, 0.0, device=dev, seed=2), "zipf1.05": tbe_request([R] * T, B, L, 1.05, device=dev, seed=1)}
 bwd_bytes = T * B * L * (2 * D * es + 8) + T * B * (D * 4 + 8)
 
@@ -43,15 +45,17 @@ def timed(fn, n):
     return e0.elapsed_time(e1) * 1e-3 / n
 
 
-for sort_impl, order, xcd, nt in [(1, 1, 0, 0), (1, 0, 0, 0), (0, 0, 0, 0), (0, 1, 0, 0), (0, 1, 1, 0), (0, 1, 1, 1), (0, 0, 0, 1), (1, 1, 1, 0)]:
-    param_amd.set_backward_tuning(sort_impl, order, xcd)
-    param_amd.set_tuning(nt_loads=nt)
+# (sort_impl, order, xcd, max_phases)
+CONFIGS = [(1, 1, 0, 1), (0, 0, 0, 1), (0, 1, 0, 1), (0, 1, 1, 1), (0, 1, 1, 2), (0, 1, 0, 2), (1, 1, 1, 2)]
+if a.configs:
+    CONFIGS = [tuple(int(x) for x in c.split(",")) for c in a.configs.split(";")]
+for sort_impl, order, xcd, ph in CONFIGS:
+    param_amd.set_backward_tuning(sort_impl, order, xcd, ph)
     for name, (idx, off) in reqs.items():
         sort_s = timed(lambda: m.sort_indices(idx, off, batch=B), a.iters)
         apply_s = timed(lambda: m.scatter_add_(grad, idx, off, alpha=-1e-6, batch=B, presorted=True), a.iters)
         both_s = timed(lambda: m.scatter_add_(grad, idx, off, alpha=-1e-6, batch=B), a.iters)
-        print(json.dumps({"sort": ["own", "rocprim"][sort_impl], "order": ["row,table", "table,row"][order], "xcd": xcd, "nt_rows": nt,
-                          "indices": name, "dtype": a.dtype, "sort_ms": sort_s * 1e3, "apply_ms": apply_s * 1e3, "total_ms": both_s * 1e3,
+        print(json.dumps({"sort": ["own", "rocprim"][sort_impl], "order": ["row,table", "table,row"][order], "xcd": xcd, "max_phases": ph,
+                          "indices": name, "dtype": a.dtype, "layout": a.layout, "sort_ms": sort_s * 1e3, "apply_ms": apply_s * 1e3, "total_ms": both_s * 1e3,
                           "alg_frac_total": bwd_bytes / both_s / 8e12, "alg_frac_apply": bwd_bytes / apply_s / 8e12}), flush=True)
 param_amd.set_backward_tuning()
-param_amd.set_tuning()
