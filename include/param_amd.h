@@ -257,15 +257,16 @@ int pm_set_tuning(int32_t unroll, int32_t bags_per_block, int32_t xcd_affine, in
 
 /*
  * Tuning knobs of the sorted backward (process-wide; -1 = default, which the environment can change:
- * PARAM_AMD_SORT=rocprim, PARAM_AMD_SORT_ORDER=row, PARAM_AMD_BWD_XCD=0, PARAM_AMD_BWD_PHASES=1):
+ * PARAM_AMD_SORT=rocprim, PARAM_AMD_SORT_ORDER=row, PARAM_AMD_BWD_XCD=0, PARAM_AMD_BWD_PHASES=2):
  *   sort_impl   0 (default): the build's own radix sort (pm_radix_sort_pairs), 1: rocPRIM's radix_sort_pairs (kept
  *               as the measured alternative)
  *   order       1 (default): pairs ordered by (table, [bag phase,] row, position); 0: (row, table, position) -- only
  *               the row bits are sorted, the request being table-major already (one radix pass fewer, a slower apply)
  *   xcd_affine  1 (default; needs order 1 and a fixed-pooling request): the apply kernel's tiles of table t run on
  *               XCD t % 8, so one table's gradient rows are fetched into one L2
- *   max_phases  2 (default): pm_embbag_sort_indices_ex(phases = 2) may lay a fixed-pooling request out for the
- *               two-phase apply; 1: never.
+ *   max_phases  1 (default): every apply is one launch; 2: pm_embbag_sort_indices_ex(phases = 2) lays a
+ *               fixed-pooling request out for the two-phase apply (kept as a measured alternative: it pays under
+ *               uniform indices only).
  * Placement, pass count and phases change speed only; every setting gives the same result for rows looked up at
  * most 256 times (longer runs: same value up to fp32 association).
  * Settings are read when a request is SORTED; its apply follows what the sort recorded.

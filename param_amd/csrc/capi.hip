@@ -103,7 +103,7 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p) {
     const int xa = g_xcd_affine.load();
     p.xcd_affine = (op->num_tables % pm::kXcds == 0 && xa != 0) ? 1 : 0;
     const int nt = g_nt_loads.load();
-    p.nt_loads = nt > 0 ? 1 : 0;
+    p.nt_loads = nt > 0 ? nt : 0;   // forward: any non-zero = non-temporal row loads; sorted backward: 1 nt, 2 system scope
     // lookups that do not divide evenly over the bags: certainly ragged (fixed-size requests -- every benchmark shape --
     // always divide; a ragged request that happens to divide merely runs the unordered kernel)
     // ... and only where the order can matter: with one bag per lane group (short-bag tiles) nothing is pulled

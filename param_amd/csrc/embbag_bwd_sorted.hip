@@ -124,13 +124,18 @@ __global__ void __launch_bounds__(kBlock) build_keys_kernel(const KParams p, K* 
 // step 3 helpers: destination element types
 // 16-byte destination-row accesses; nt = streaming hint (every touched row is read once and written
 // once per call, so it should not displace the gradient rows that ARE re-read from L2)
-__device__ __forceinline__ u32x4 raw16_load(const char* p, bool nt) {
+// cache policy of the destination-row accesses (SortedParams::nt_rows, pm_set_tuning nt_loads): 0 default, 1 non-temporal
+// (nt), 2 system scope (volatile: sc0 sc1 -- misses the non-coherent caches on the way in, writes through on the way out)
+__device__ __forceinline__ u32x4 raw16_load(const char* p, int pol) {
     const PM_GLOBAL u32x4* q = as_global<u32x4>(p);   // global, not flat (common.h)
-    return nt ? __builtin_nontemporal_load(q) : *q;
+    if (pol == 2) return *reinterpret_cast<const volatile PM_GLOBAL u32x4*>(q);
+    return pol == 1 ? __builtin_nontemporal_load(q) : *q;
 }
-__device__ __forceinline__ void raw16_store(char* p, const u32x4 v, bool nt) {
+__device__ __forceinline__ void raw16_store(char* p, const u32x4 v, int pol) {
     PM_GLOBAL u32x4* q = as_global<u32x4>(p);
-    if (nt) __builtin_nontemporal_store(v, q); else *q = v;
+    if (pol == 2) *reinterpret_cast<volatile PM_GLOBAL u32x4*>(q) = v;
+    else if (pol == 1) __builtin_nontemporal_store(v, q);
+    else *q = v;
 }
 
 // counter-based random bits for stochastic rounding: one 64-bit splitmix output per (seed, row key, column pair)
@@ -144,14 +149,14 @@ __device__ __forceinline__ uint32_t sr_bits(uint64_t seed, uint64_t rowkey, int 
 
 struct SDstF32 {
     static constexpr int kVec = 4, kES = 4;
-    __device__ static __forceinline__ void store_sr(char* p, const float (&a)[4], bool nt, uint64_t, uint64_t, int) {
+    __device__ static __forceinline__ void store_sr(char* p, const float (&a)[4], int nt, uint64_t, uint64_t, int) {
         store(p, a, nt);   // fp32 tables: nothing to round
     }
-    __device__ static __forceinline__ void load(const char* p, float (&a)[4], bool nt = false) {
+    __device__ static __forceinline__ void load(const char* p, float (&a)[4], int nt = 0) {
         const u32x4 v = raw16_load(p, nt);
         a[0] = __uint_as_float(v.x); a[1] = __uint_as_float(v.y); a[2] = __uint_as_float(v.z); a[3] = __uint_as_float(v.w);
     }
-    __device__ static __forceinline__ void store(char* p, const float (&a)[4], bool nt = false) {
+    __device__ static __forceinline__ void store(char* p, const float (&a)[4], int nt = 0) {
         raw16_store(p, u32x4{__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3])}, nt);
     }
 };
@@ -169,7 +174,7 @@ __device__ __forceinline__ uint32_t f32_to_bf16_sr(float f, uint32_t r16) {
 }
 struct SDstBF16 {
     static constexpr int kVec = 8, kES = 2;
-    __device__ static __forceinline__ void store_sr(char* p, const float (&a)[8], bool nt, uint64_t seed, uint64_t rowkey, int c) {
+    __device__ static __forceinline__ void store_sr(char* p, const float (&a)[8], int nt, uint64_t seed, uint64_t rowkey, int c) {
         uint32_t w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -178,13 +183,13 @@ struct SDstBF16 {
         }
         raw16_store(p, u32x4{w[0], w[1], w[2], w[3]}, nt);
     }
-    __device__ static __forceinline__ void load(const char* p, float (&a)[8], bool nt = false) {
+    __device__ static __forceinline__ void load(const char* p, float (&a)[8], int nt = 0) {
         const u32x4 v = raw16_load(p, nt);
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) { a[2 * i] = __uint_as_float(w[i] << 16); a[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
     }
-    __device__ static __forceinline__ void store(char* p, const float (&a)[8], bool nt = false) {
+    __device__ static __forceinline__ void store(char* p, const float (&a)[8], int nt = 0) {
         uint32_t w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[i] = f32_to_bf16_rne(a[2 * i]) | (f32_to_bf16_rne(a[2 * i + 1]) << 16);
@@ -200,7 +205,7 @@ __device__ __forceinline__ uint32_t f32_to_f16_sr(float f, uint32_t r13) {
 }
 struct SDstF16 {
     static constexpr int kVec = 8, kES = 2;
-    __device__ static __forceinline__ void store_sr(char* p, const float (&a)[8], bool nt, uint64_t seed, uint64_t rowkey, int c) {
+    __device__ static __forceinline__ void store_sr(char* p, const float (&a)[8], int nt, uint64_t seed, uint64_t rowkey, int c) {
         uint32_t w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -209,7 +214,7 @@ struct SDstF16 {
         }
         raw16_store(p, u32x4{w[0], w[1], w[2], w[3]}, nt);
     }
-    __device__ static __forceinline__ void load(const char* p, float (&a)[8], bool nt = false) {
+    __device__ static __forceinline__ void load(const char* p, float (&a)[8], int nt = 0) {
         const u32x4 v = raw16_load(p, nt);
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -218,7 +223,7 @@ struct SDstF16 {
             a[2 * i + 1] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(w[i] >> 16)));
         }
     }
-    __device__ static __forceinline__ void store(char* p, const float (&a)[8], bool nt = false) {
+    __device__ static __forceinline__ void store(char* p, const float (&a)[8], int nt = 0) {
         uint32_t w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -285,8 +290,11 @@ int knob(std::atomic<int>& k, int env_default) {
 bool use_rocprim_sort() { return knob(g_sort_impl, env_is("PARAM_AMD_SORT", "rocprim")) == 1; }
 bool table_major_order() { return knob(g_sort_order, env_is("PARAM_AMD_SORT_ORDER", "row") ? 0 : 1) == 1; }
 bool want_xcd() { return knob(g_bwd_xcd, env_is("PARAM_AMD_BWD_XCD", "0") ? 0 : 1) == 1; }
-//   max_phases 2 (default): a phases = 2 sort may lay the request out for the two-phase apply; 1: never  PARAM_AMD_BWD_PHASES=1
-int max_phases() { return knob(g_max_phases, env_is("PARAM_AMD_BWD_PHASES", "1") ? 1 : 2); }
+//   max_phases 1 (default): one apply launch; 2: a phases = 2 sort lays a fixed-pooling request out for the two-phase
+//              apply (measured at benchmark size: uniform indices 1.60 -> 1.58 ms, Zipf 0.97 -> 1.12 ms: rows looked up in
+//              both bag halves are read and written twice, and halving the gradient working set does not make it stay in
+//              L2 -- 1 KB of row traffic streams through for every 512 B gradient row)              PARAM_AMD_BWD_PHASES=2
+int max_phases() { return knob(g_max_phases, env_is("PARAM_AMD_BWD_PHASES", "2") ? 2 : 1); }
 
 hipError_t ws_layout(void* base, int64_t n, int key_bytes, int kbits_sort, bool weighted, int max_dim, SortWs& ws) {
     size_t tb = 0;

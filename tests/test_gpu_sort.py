@@ -114,8 +114,9 @@ def test_radix_sort_segmented():
             assert np.array_equal(vo[sl], ev + np.uint32(s_ * seg)), (seg, s_)
 
 
-@pytest.mark.parametrize("sort_impl,order,xcd", [(0, 0, 0), (0, 1, 0), (0, 1, 1), (1, 0, 0), (1, 1, 1)])
-def test_sorted_backward_under_every_tuning(coracle, sort_impl, order, xcd):
+@pytest.mark.parametrize("sort_impl,order,xcd,phases", [(0, 0, 0, 1), (0, 1, 0, 1), (0, 1, 1, 1), (0, 1, 1, 2), (0, 1, 0, 2), (1, 0, 0, 1),
+                                                        (1, 1, 1, 1), (1, 1, 1, 2)])
+def test_sorted_backward_under_every_tuning(coracle, sort_impl, order, xcd, phases):
     """8 tables x 1024 bags x 16 lookups (per-table lookups = 16 tiles of 1024: the XCD-affine mapping engages), Zipf
     duplicates incl. rows past the exact-run limit: every (own | rocPRIM) x (row | table order) x XCD-mapping setting
     gives the oracle's bits on rows looked up <= 256 times and 1e-5 of an fp64 sum on the hot rows."""
@@ -123,7 +124,7 @@ def test_sorted_backward_under_every_tuning(coracle, sort_impl, order, xcd):
     from param_amd import BatchedEmbeddingBagMI355
     from param_amd.indices import zipf_indices
 
-    param_amd.set_backward_tuning(sort_impl, order, xcd)
+    param_amd.set_backward_tuning(sort_impl, order, xcd, phases)
     try:
         T, R, D, B, L = 8, 30000, 128, 1024, 16
         m = BatchedEmbeddingBagMI355([R] * T, D, device=DEV, init="normal", seed=3, fused_update=False)
@@ -163,6 +164,7 @@ def test_two_phase_apply_engages_and_adagrad_refuses_it(coracle):
     from param_amd.embedding_bag import _sort_indices
 
     T, R, D, B, L = 4, 5000, 64, 512, 8          # (B / 2) * L = 2048: two apply tiles per (table, phase) segment
+    param_amd.set_backward_tuning(max_phases=2)  # the two-phase layout is opt-in (default: one apply launch)
     g = torch.Generator().manual_seed(4)
     idx = torch.randint(0, R, (T * B * L,), generator=g)
     idx[: 3 * L] = 7                             # one row looked up in bags 0..2 (lower half) ...
@@ -198,3 +200,4 @@ def test_two_phase_apply_engages_and_adagrad_refuses_it(coracle):
     _lib.check(_lib.load().pm_embbag_check(ctypes.byref(op), err.data_ptr(), torch.cuda.current_stream().cuda_stream))
     assert int(err.item()) >= 1
     op.fixed_pooling = 0
+    param_amd.set_backward_tuning()

@@ -20,6 +20,7 @@ ap.add_argument("--rows", type=int, default=10_000_000)
 ap.add_argument("--dtype", default="fp32")
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--layout", default="bd")
+ap.add_argument("--nt", type=int, default=0, help="row cache policy of the apply kernel: 0 default, 1 nt, 2 system scope")
 ap.add_argument("--configs", default="", help="semicolon-separated sort_impl,order,xcd,nt tuples (default: the full matrix)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -51,11 +52,12 @@ if a.configs:
     CONFIGS = [tuple(int(x) for x in c.split(",")) for c in a.configs.split(";")]
 for sort_impl, order, xcd, ph in CONFIGS:
     param_amd.set_backward_tuning(sort_impl, order, xcd, ph)
+    param_amd.set_tuning(nt_loads=a.nt)
     for name, (idx, off) in reqs.items():
         sort_s = timed(lambda: m.sort_indices(idx, off, batch=B), a.iters)
         apply_s = timed(lambda: m.scatter_add_(grad, idx, off, alpha=-1e-6, batch=B, presorted=True), a.iters)
         both_s = timed(lambda: m.scatter_add_(grad, idx, off, alpha=-1e-6, batch=B), a.iters)
-        print(json.dumps({"sort": ["own", "rocprim"][sort_impl], "order": ["row,table", "table,row"][order], "xcd": xcd, "max_phases": ph,
+        print(json.dumps({"sort": ["own", "rocprim"][sort_impl], "order": ["row,table", "table,row"][order], "xcd": xcd, "max_phases": ph, "row_policy": a.nt,
                           "indices": name, "dtype": a.dtype, "layout": a.layout, "sort_ms": sort_s * 1e3, "apply_ms": apply_s * 1e3, "total_ms": both_s * 1e3,
                           "alg_frac_total": bwd_bytes / both_s / 8e12, "alg_frac_apply": bwd_bytes / apply_s / 8e12}), flush=True)
 param_amd.set_backward_tuning()
