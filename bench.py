@@ -150,56 +150,71 @@ def _one_cpu_per_core():
     return by_pkg
 
 
-def _cpu_modes(W: torch.Tensor, idx: torch.Tensor, B: int, L: int, budget_s: float, bound: bool):
-    """runs INSIDE a child process (see cpu_baseline): the reference CPU engine, measure_cpu protocol (pytorch_emb.py:37-45),
-    per mode 3 discarded warm-up steps then 5 repeats of a fixed step count -> median"""
+def _cpu_modes(W: torch.Tensor, idx_sets, B: int, L: int, budget_s: float, param_default: bool):
+    """runs INSIDE a child process (see cpu_baseline): the reference CPU engine under the measure_cpu protocol
+    (pytorch_emb.py:37-45); per mode 3 discarded warm-up steps, then 5 repeats of a fixed step count -> median.  Successive
+    steps take successive index sets (those of the first tables of the GPU request), so a step's rows are not the previous
+    step's: the whole workload touches 48 x 84 MB of rows per step and can never sit in the CPUs' caches, a one-table
+    sample looping over ONE index set does (64 us vs 300 us per step in the same run, at the scheduler's whim)."""
     from param_amd.compute.pt.pytorch_emb import measure_cpu
 
     off = torch.arange(B, dtype=torch.int64) * L
     emb = torch.nn.EmbeddingBag(W.shape[0], W.shape[1], mode="sum", _weight=W)
-    by_pkg = _one_cpu_per_core()
-    n_all = sum(len(v) for v in by_pkg.values())
-    n_socket = len(by_pkg[min(by_pkg)])
-    modes = [("all_cores_no_grad", n_all, True), ("all_cores_grad_on_param_default", n_all, False),
-             ("one_socket_no_grad", n_socket, True), ("one_thread_no_grad", 1, True)]
+    k = [0]
+
+    def cycler(_indices, _offsets):
+        k[0] += 1
+        return emb(idx_sets[k[0] % len(idx_sets)], off)
+
+    n_here = len(os.sched_getaffinity(0))
+    if param_default:   # what PARAM does out of the box: torch's default thread count, autograd on, nothing pinned
+        modes = [("param_default_all_threads_grad_on", torch.get_num_threads(), False)]
+    else:               # the calling process is confined to one socket's cores (one hardware thread each)
+        modes = [("one_socket_no_grad", n_here, True), ("half_socket_no_grad", max(1, n_here // 2), True),
+                 ("quarter_socket_no_grad", max(1, n_here // 4), True), ("one_thread_no_grad", 1, True)]
     res = {}
     per_mode = budget_s / len(modes)
     for tag, nthr, no_grad in modes:
-        if not bound:   # unbound threads float inside the calling thread's mask: confine each mode to the cores it is named after
-            cpus = sorted(by_pkg[min(by_pkg)]) if tag.startswith("one_socket") else sorted(c for v in by_pkg.values() for c in v)
-            os.sched_setaffinity(0, set(cpus[:1] if tag.startswith("one_thread") else cpus))
         torch.set_num_threads(nthr)
         ctx = torch.no_grad() if no_grad else torch.enable_grad()
         with ctx:
-            t3, _ = measure_cpu(0, 3, emb, idx, off)
-            steps = max(3, min(300, int(per_mode / 6 / max(t3 / 3, 1e-5))))
+            t3, _ = measure_cpu(0, 3, cycler, None, None)
+            steps = max(len(idx_sets), min(304, int(per_mode / 6 / max(t3 / 3, 1e-5))))
             reps = []
             for _ in range(5):
-                el, _ = measure_cpu(0, steps, emb, idx, off)
+                el, _ = measure_cpu(0, steps, cycler, None, None)
                 reps.append(el / steps)
         med = statistics.median(reps)
         res[tag] = {"lookups_per_s": B * L / med, "s_per_step": med, "threads": nthr, "steps": steps,
                     "repeats_s_per_step": reps, "spread": (max(reps) - min(reps)) / med}
-    return {"modes": res, "physical_cores": n_all, "sockets": len(by_pkg)}
+    return res
 
 
 def cpu_child(spec: dict) -> dict:
-    """entry of the child process: rebuild table 0 of the parent's workload on the GPU (counter-based fill: same seed ->
-    same bits), copy it to the host with the first table's indices, time the CPU modes"""
+    """entry of the child process: confine the process to one socket (memory first-touched there, OpenMP workers created
+    there), rebuild table 0 of the parent's workload on the GPU (counter-based fill: same seed -> same bits), copy it to the
+    host with the index sets of the first tables of the request, time the CPU modes"""
+    by_pkg = _one_cpu_per_core()
+    if not spec["param_default"]:
+        os.sched_setaffinity(0, set(by_pkg[min(by_pkg)]))
     dev = torch.device("cuda", spec["device"])
     torch.cuda.set_device(dev)
     m = param_amd.BatchedEmbeddingBagMI355([spec["rows"]], spec["dim"], dtype=_DT[spec["dtype"]], device=dev, init="normal",
                                            seed=spec["table_seed"], fused_update=False)
-    idx, _ = tbe_request([spec["rows"]], spec["batch"], spec["pooling"], alpha=spec["alpha"], device=dev, seed=spec["request_seed"])
+    K = spec["index_sets"]
+    idx, _ = tbe_request([spec["rows"]] * K, spec["batch"], spec["pooling"], alpha=spec["alpha"], device=dev, seed=spec["request_seed"])
+    n1 = spec["batch"] * spec["pooling"]
+    sets = [idx[i * n1:(i + 1) * n1].cpu() for i in range(K)]
     W = m.table(0).float().cpu()
-    out = _cpu_modes(W, idx.cpu(), spec["batch"], spec["pooling"], spec["budget_s"], spec["bound"])
+    out = {"modes": _cpu_modes(W, sets, spec["batch"], spec["pooling"], spec["budget_s"], spec["param_default"]),
+           "cpus_in_mask": len(os.sched_getaffinity(0)), "sockets": len(by_pkg), "physical_cores": sum(len(v) for v in by_pkg.values())}
     if spec.get("c_oracle"):
         try:
             from oracle.embbag_oracle import COracle
 
             nb = min(spec["batch"], 2048)
             orc = COracle()
-            Wn, In = W.numpy(), idx.cpu()[: nb * spec["pooling"]].numpy()
+            Wn, In = W.numpy(), sets[0][: nb * spec["pooling"]].numpy()
             On = (torch.arange(nb, dtype=torch.int64) * spec["pooling"]).numpy()
             orc.fwd(Wn, In, On)
             t0 = time.perf_counter()
@@ -210,21 +225,19 @@ def cpu_child(spec: dict) -> dict:
     return out
 
 
-def cpu_baseline(spec: dict, budget_s: float = 10.0):
+def cpu_baseline(spec: dict, budget_s: float = 12.0):
     """Reference CPU engine (torch.nn.EmbeddingBag(sum), the reference's measure_cpu protocol) on a bounded sample: ONE table
-    of the workload with the same rows / dim / indices as table 0 on the GPU.  Thread placement decides whether the 84 MB of
-    rows a step touches stay in the cores' L3 slices (64 us per step) or stream from DRAM (300 us), and an unbound pool of
-    as many threads as cores can collapse altogether (57 ms per step, measured on this host type), so the modes are timed in
-    TWO child processes -- OpenMP threads bound one per core (OMP_PLACES=cores OMP_PROC_BIND=close, which must be in the
-    environment before the OpenMP runtime loads) and unbound -- and ``value`` is the best median over both."""
+    of the workload (same rows / dim as table 0 on the GPU) looked up with the index sets of the request's first 8 tables in
+    turn.  Timed in a CHILD process confined to one socket (memory and threads local; 64 / 32 / 16 / 1 threads), so that no
+    affinity or thread-pool setting leaks into the GPU timing; a second child records what PARAM does out of the box (all
+    threads, autograd on).  ``value`` = the best median of the confined modes, named in ``sample``."""
     import subprocess
 
     results = {}
-    for tag, env_extra in (("bound", {"OMP_PLACES": "cores", "OMP_PROC_BIND": "close"}), ("unbound", {})):
-        child_spec = dict(spec, bound=(tag == "bound"), budget_s=budget_s, c_oracle=(tag == "bound"))
+    for tag, pd, share in (("one_socket", False, 0.8), ("param_default", True, 0.2)):
+        child_spec = dict(spec, param_default=pd, budget_s=budget_s * share, c_oracle=not pd, index_sets=8)
         env = {k: v for k, v in os.environ.items() if not k.startswith(("OMP_", "GOMP_", "KMP_")) and k not in
                ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-        env.update(env_extra)
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", json.dumps(child_spec)], env=env,
                                capture_output=True, text=True, timeout=300)
@@ -232,17 +245,19 @@ def cpu_baseline(spec: dict, budget_s: float = 10.0):
             results[tag] = json.loads(line[-1]) if r.returncode == 0 and line else {"error": (r.stderr or r.stdout)[-400:]}
         except Exception as exc:
             results[tag] = {"error": str(exc)}
-    cands = [(m["lookups_per_s"], tag, name, m) for tag, r in results.items() for name, m in r.get("modes", {}).items()]
-    if not cands:
+    modes = results.get("one_socket", {}).get("modes", {})
+    if not modes:
         return {"value": None, "unit": "lookups/s", "cores": None, "kind": "port", "sample": f"failed: {results}"}
-    best_v, best_tag, best_name, best = max(cands, key=lambda c: c[0])
+    best_name = max(modes, key=lambda n: modes[n]["lookups_per_s"])
+    best = modes[best_name]
     return {
-        "value": best_v, "unit": "lookups/s", "cores": best["threads"], "kind": "port",
+        "value": best["lookups_per_s"], "unit": "lookups/s", "cores": best["threads"], "kind": "port",
         "sample": (f"torch.nn.EmbeddingBag(sum) on host (the engine the reference calls, its measure_cpu protocol), 1 table "
-                   f"{spec['rows']}x{spec['dim']} fp32, batch {spec['batch']}, pool {spec['pooling']}, same indices as GPU table 0; "
-                   f"best of 2 x 4 modes = {best_name} with {best_tag} OpenMP threads: {best['threads']} threads, median of "
-                   f"5 x {best['steps']} steps after 3 warm-ups"),
-        "best_mode": f"{best_tag}/{best_name}", "host_cpu_count": os.cpu_count(), "children": results,
+                   f"{spec['rows']}x{spec['dim']} fp32, batch {spec['batch']}, pool {spec['pooling']}, the index sets of the request's "
+                   f"first 8 tables in turn (672 MB of rows per cycle: no cache residency, like the 48-table workload); process "
+                   f"confined to one socket; best mode = {best_name}: {best['threads']} threads, median of 5 x {best['steps']} steps "
+                   f"after 3 warm-ups"),
+        "best_mode": best_name, "host_cpu_count": os.cpu_count(), "children": results,
     }
 
 

@@ -201,3 +201,50 @@ def test_two_phase_apply_engages_and_adagrad_refuses_it(coracle):
     assert int(err.item()) >= 1
     op.fixed_pooling = 0
     param_amd.set_backward_tuning()
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PARAM_AMD_FUZZ_SEEDS", "24"))))
+def test_random_fixed_pooling_requests_under_random_tuning(coracle, seed):
+    """fixed-pooling requests whose sizes do / do not line up with the sort tile (4096) and the apply tile (1024), tables of
+    3 ... 70000 rows (runs far beyond the exact-run limit included), with and without per-sample weights, under a random
+    backward tuning each: per-table sort segments, XCD-affine tiles, two bag phases, the general path -- all against the
+    sequential oracle (bit-exact up to 256 lookups per row, 1e-5 of an fp64 sum beyond)."""
+    import param_amd
+    from param_amd import BatchedEmbeddingBagMI355
+
+    rng = np.random.default_rng(7000 + seed)
+    T = int(rng.integers(1, 21))
+    B = int(rng.choice([64, 128, 256, 512, 1024, 2048]))
+    L = int(rng.choice([1, 2, 4, 8, 16, 32]))
+    D = int(rng.choice([16, 64, 128]))
+    rows = [int(rng.choice([3, 100, 5000, 70000])) for _ in range(T)]
+    weighted = rng.random() < 0.3
+    knobs = (int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(1, 3)))
+    param_amd.set_backward_tuning(*knobs)
+    try:
+        m = BatchedEmbeddingBagMI355(rows, D, device=DEV, init="normal", seed=seed, fused_update=False)
+        idx = np.concatenate([rng.integers(0, r, B * L) for r in rows]).astype(np.int64)
+        off = (np.arange(T * B + 1) * L).astype(np.int64)
+        psw = rng.uniform(0.5, 1.5, idx.size).astype(np.float32) if weighted else None
+        grad = rng.standard_normal((B, T * D)).astype(np.float32)
+        W0 = [m.table(t).cpu().numpy().copy() for t in range(T)]
+        t_ = lambda a: torch.from_numpy(a).to(DEV)   # noqa: E731
+        m.scatter_add_(t_(grad), t_(idx), t_(off), alpha=0.25, per_sample_weights=None if psw is None else t_(psw))
+        for t in range(T):
+            s, e = t * B * L, (t + 1) * B * L
+            gt = np.ascontiguousarray(grad[:, t * D:(t + 1) * D])
+            pw = None if psw is None else psw[s:e]
+            exp = coracle.bwd_f32(W0[t].copy(), idx[s:e], np.arange(B, dtype=np.int64) * L, gt, pw, alpha=0.25)
+            got = m.table(t).cpu().numpy()
+            cnt = np.bincount(idx[s:e], minlength=rows[t])
+            cold = cnt <= 256
+            assert np.array_equal(got[cold], exp[cold]), (seed, t, knobs, T, B, L, D, rows[t])
+            contrib = 0.25 * gt.astype(np.float64)[np.repeat(np.arange(B), L)] * (1.0 if pw is None else pw.astype(np.float64)[:, None])
+            truth = W0[t].astype(np.float64)
+            mag = np.abs(W0[t]).astype(np.float64)
+            np.add.at(truth, idx[s:e], contrib)
+            np.add.at(mag, idx[s:e], np.abs(contrib))
+            tol = np.maximum(1e-5, (256 + cnt[:, None] / 32) * 2.0 ** -24) * mag + 1e-30
+            assert (np.abs(got - truth) <= tol).all(), (seed, t, knobs, T, B, L, D, rows[t])
+    finally:
+        param_amd.set_backward_tuning()

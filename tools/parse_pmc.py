@@ -55,7 +55,11 @@ def label_rows(rows):
             n_fix += 1
             out["bwd_fixup_uniform" if n_fix <= reps else "bwd_fixup_zipf"].append(val)
         elif "radix_sort" in name and "onesweep" in name:
-            out["bwd_sort_pass_uniform"].append(val)
+            out["bwd_sort_pass_rocprim"].append(val)
+        elif "rs_scatter_kernel" in name:
+            out["bwd_sort_scatter_pass"].append(val)
+        elif "rs_hist_kernel" in name:
+            out["bwd_sort_hist_pass"].append(val)
     if out["_fill_all"]:
         out["calib_write"] = out["_fill_all"][-reps:]
     if out["_reduce_all"]:
