@@ -152,7 +152,7 @@ def _one_cpu_per_core():
 
 def _cpu_modes(W: torch.Tensor, idx_sets, B: int, L: int, budget_s: float, param_default: bool):
     """runs INSIDE a child process (see cpu_baseline): the reference CPU engine under the measure_cpu protocol
-    (pytorch_emb.py:37-45); per mode 3 discarded warm-up steps, then 5 repeats of a fixed step count -> median.  Successive
+    (pytorch_emb.py:37-45); per mode 3 discarded warm-up steps, then 7 repeats of a fixed step count -> median.  Successive
     steps take successive index sets (those of the first tables of the GPU request), so a step's rows are not the previous
     step's: the whole workload touches 48 x 84 MB of rows per step and can never sit in the CPUs' caches, a one-table
     sample looping over ONE index set does (64 us vs 300 us per step in the same run, at the scheduler's whim)."""
@@ -170,7 +170,9 @@ def _cpu_modes(W: torch.Tensor, idx_sets, B: int, L: int, budget_s: float, param
     if param_default:   # what PARAM does out of the box: torch's default thread count, autograd on, nothing pinned
         modes = [("param_default_all_threads_grad_on", torch.get_num_threads(), False)]
     else:               # the calling process is confined to one socket's cores (one hardware thread each)
-        modes = [("one_socket_no_grad", n_here, True), ("half_socket_no_grad", max(1, n_here // 2), True),
+        # (as many threads as CPUs in the mask collapses on this host type -- 6 M lookups/s with 64 threads on 64 CPUs against
+        #  1.6 G with 32: the pool then has no CPU left for whatever else wakes up -- so the widest mode leaves two free)
+        modes = [("one_socket_less_2_no_grad", max(1, n_here - 2), True), ("half_socket_no_grad", max(1, n_here // 2), True),
                  ("quarter_socket_no_grad", max(1, n_here // 4), True), ("one_thread_no_grad", 1, True)]
     res = {}
     per_mode = budget_s / len(modes)
@@ -179,9 +181,9 @@ def _cpu_modes(W: torch.Tensor, idx_sets, B: int, L: int, budget_s: float, param
         ctx = torch.no_grad() if no_grad else torch.enable_grad()
         with ctx:
             t3, _ = measure_cpu(0, 3, cycler, None, None)
-            steps = max(len(idx_sets), min(304, int(per_mode / 6 / max(t3 / 3, 1e-5))))
+            steps = max(len(idx_sets), min(304, int(per_mode / 8 / max(t3 / 3, 1e-5))))
             reps = []
-            for _ in range(5):
+            for _ in range(7):
                 el, _ = measure_cpu(0, steps, cycler, None, None)
                 reps.append(el / steps)
         med = statistics.median(reps)
@@ -255,7 +257,7 @@ def cpu_baseline(spec: dict, budget_s: float = 12.0):
         "sample": (f"torch.nn.EmbeddingBag(sum) on host (the engine the reference calls, its measure_cpu protocol), 1 table "
                    f"{spec['rows']}x{spec['dim']} fp32, batch {spec['batch']}, pool {spec['pooling']}, the index sets of the request's "
                    f"first 8 tables in turn (672 MB of rows per cycle: no cache residency, like the 48-table workload); process "
-                   f"confined to one socket; best mode = {best_name}: {best['threads']} threads, median of 5 x {best['steps']} steps "
+                   f"confined to one socket; best mode = {best_name}: {best['threads']} threads, median of 7 x {best['steps']} steps "
                    f"after 3 warm-ups"),
         "best_mode": best_name, "host_cpu_count": os.cpu_count(), "children": results,
     }
