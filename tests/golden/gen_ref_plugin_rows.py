@@ -2,17 +2,18 @@
 """Runs the REFERENCE's unmodified drivers with this build's plug-ins and writes tests/golden/ref_plugin_rows.json.
 Needs /root/reference (build container only); the fixture is data, nothing of the reference travels.
 
-1. ``train/comms/pt/comms.py --backend rccl_xgmi --device cpu`` on 2 gloo ranks with ``MI355XBackend`` registered in the
-   reference's ``customized_backend`` table (this is the command documented there).  The
+1. ``examples/reference_plugin/launch_comms.py <reference>/train/comms/pt/comms.py --backend rccl_xgmi --device cpu`` on 2
+   gloo ranks: ``MI355XBackend`` registered in the reference's ``customized_backend`` table, then the reference's script
+   run unmodified (this is the command documented there).  The
    deterministic columns of every COMMS-RES row (collective, dtype, bytes, elements per rank, column count) are stored,
    after checking that they equal what the reference's OWN backend (``--backend gloo``) prints for the same arguments.
    Blocking and non-blocking mode, the all-to-all family plus the collectives the driver itself needs (all_gather for
    its latency report) and the rest of the ABC's table.
-2. ``train/comms/pt/dlrm.py`` with ``dlrm.PyTorchDistBackend`` bound to ``MI355XBackend`` (dlrm.py:1327 hard-codes its
-   backend class: that assignment is the one line a maintainer adds).  The embedding tables are a torch CPU stand-in
-   in THIS script only -- the product lookup has no CPU path -- so what is exercised is every collective of the DLRM
-   iteration through the plug-in: the ``--print-comms`` records must equal tests/golden/dlrm_np2 (made by the reference
-   with its own backend).
+2. ``examples/reference_plugin/launch_dlrm.py``: the reference's ``dlrm.py`` with ``dlrm.PyTorchDistBackend`` bound to
+   ``MI355XBackend`` (dlrm.py:1327 hard-codes its backend class: that assignment is the one line a maintainer adds).
+   With PARAM_AMD_HOST_TABLES=1 the embedding tables are a torch CPU stand-in -- the product lookup has no CPU path --
+   so what is exercised here is every collective of the DLRM iteration through the plug-in: the ``--print-comms``
+   records must equal tests/golden/dlrm_np2 (made by the reference with its own backend).
 3. ``train/compute/python``: the operator, its input iterator and data generator registered in the reference's
    registries (param_amd/compute/python/reference_plugin.py); the reference's ``BenchmarkConfig`` resolves its example
    config to them and the (id, arguments) stream of build and input configs is stored for the host test to replay
@@ -29,37 +30,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 
-COMMS_LAUNCH = f'''
-import runpy, sys
-sys.path.insert(0, {REPO!r})
-from param_amd.comms.pt import mi355_backend
-mi355_backend.register()                      # -> param_bench...pytorch_backend_utils.customized_backend["rccl_xgmi"]
-sys.argv[0] = "{REF}/train/comms/pt/comms.py"
-runpy.run_path(sys.argv[0], run_name="__main__")
-'''
-
-DLRM_LAUNCH = f'''
-import argparse, sys
-sys.path.insert(0, {REPO!r})
-import torch
-from param_amd.comms.pt import mi355_backend
-import dlrm
-from param_bench.train.comms.pt import comms_utils
-
-class _HostTables(mi355_backend.MI355XBackend):      # generator-only stand-in: the HIP lookup needs a GPU
-    def alloc_embedding_tables(self, n, m, curRankDevice, dtype):
-        return torch.nn.EmbeddingBag(n, m, mode="sum", sparse=False).to(curRankDevice)
-
-dlrm.PyTorchDistBackend = _HostTables               # dlrm.py:1327 hard-codes the class it instantiates
-mi355_backend.register()
-env = comms_utils.read_comms_env_vars()
-b = dlrm.commsDLRMBench()
-p = argparse.ArgumentParser()
-p.add_argument("--use-device-time", action="store_true", default=False)   # reference bug R1 (SURVEY.md)
-args = b.readArgs(p); b.checkArgs(args); b.initBench(args, env)
-bi = comms_utils.bootstrap_info_holder(args.master_ip, args.master_port, args.num_tpu_cores, env)
-b.runBench(bi, comms_utils.commsDlrmParamsHolder(args, env), args)
-'''
+# the launchers a user runs: committed files, used here as they are
+COMMS_LAUNCH = os.path.join(REPO, "examples", "reference_plugin", "launch_comms.py")
+DLRM_LAUNCH = os.path.join(REPO, "examples", "reference_plugin", "launch_dlrm.py")
 
 SWEEPS = [
     {"name": "blocking_a2a_family", "z": "1",
@@ -69,10 +42,10 @@ SWEEPS = [
 ]
 
 
-def run2(work, script, argv, port, pythonpath, stdout=True):
+def run2(work, script, argv, port, pythonpath, pre=(), extra_env=None):
     env = dict(os.environ, PYTHONPATH=pythonpath, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2",
-               LOCAL_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, script, "--master-ip", "127.0.0.1", "--master-port", str(port)] + argv, cwd=work,
+               LOCAL_SIZE="2", **(extra_env or {}))
+    procs = [subprocess.Popen([sys.executable, script, *pre, "--master-ip", "127.0.0.1", "--master-port", str(port)] + argv, cwd=work,
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                               text=True) for r in (0, 1)]
     outs = [p.communicate(timeout=600) for p in procs]
@@ -96,8 +69,6 @@ def main():
     os.makedirs(os.path.join(work, "pb"))
     os.symlink(REF, os.path.join(work, "pb", "param_bench"))
     pb = os.path.join(work, "pb")
-    open(os.path.join(work, "comms_launch.py"), "w").write(COMMS_LAUNCH)
-    open(os.path.join(work, "dlrm_launch.py"), "w").write(DLRM_LAUNCH)
     result = {"comms": [], "dlrm": {}, "compute_python": {}}
     port = 29581
 
@@ -105,7 +76,7 @@ def main():
     for sw in SWEEPS:
         common = ["--b", "64", "--e", "1024", "--f", "4", "--n", "3", "--w", "1", "--z", sw["z"], "--c", "1",
                   "--collective", sw["collective"], "--device", "cpu"]
-        plug = run2(work, os.path.join(work, "comms_launch.py"), common + ["--backend", "rccl_xgmi"], port, pb)
+        plug = run2(work, COMMS_LAUNCH, common + ["--backend", "rccl_xgmi"], port, pb, pre=(f"{REF}/train/comms/pt/comms.py",))
         own = run2(work, f"{REF}/train/comms/pt/comms.py", common + ["--backend", "gloo"], port + 1, pb)
         port += 2
         assert "Hello from Rank 1" in plug, "sayHello() under the reference driver"
@@ -119,7 +90,7 @@ def main():
     flags = ["--backend", "rccl_xgmi", "--device", "cpu", "--mini-batch-size", "8", "--num-batches", "4", "--warmup-batches", "1",
              "--arch-mlp-bot", "16-8", "--arch-mlp-top", "8-1", "--arch-sparse-feature-size", "8",
              "--arch-embedding-size", "100-200-300-400", "--num-indices-per-lookup", "5", "--print-comms"]
-    run2(work, os.path.join(work, "dlrm_launch.py"), flags, port, f"{pb}:{REF}/train/comms/pt")
+    run2(work, DLRM_LAUNCH, flags, port, f"{pb}:{REF}/train/comms/pt", extra_env={"PARAM_AMD_HOST_TABLES": "1"})
     for r in (0, 1):
         got = json.load(open(os.path.join(work, "dlrm_np2", f"rank{r}.json")))
         exp = json.load(open(os.path.join(HERE, "dlrm_np2", f"rank{r}.json")))
