@@ -256,6 +256,14 @@ int pm_fill_random(void* dst, int64_t count, int32_t dtype, int32_t dist, float 
 int pm_set_tuning(int32_t unroll, int32_t bags_per_block, int32_t xcd_affine, int32_t nt_loads);
 
 /*
+ * stage_out = 1 (default; -1 = default, PARAM_AMD_FWD_STAGE=0 in the environment changes it): the forward collects a
+ * tile's pooled rows in LDS and writes them in one burst when the tile is done (fixed-pooling requests whose tile of
+ * rows fits 16 KB).  Results are bit-identical either way; it changes how the output write stream mixes with the row
+ * reads (uniform indices: 0.69 -> 0.72-0.74 of the HBM peak).
+ */
+int pm_set_forward_tuning(int32_t stage_out);
+
+/*
  * Tuning knobs of the sorted backward (process-wide; -1 = default, which the environment can change:
  * PARAM_AMD_SORT=rocprim, PARAM_AMD_SORT_ORDER=row, PARAM_AMD_BWD_XCD=0, PARAM_AMD_BWD_PHASES=2):
  *   sort_impl   0 (default): the build's own radix sort (pm_radix_sort_pairs), 1: rocPRIM's radix_sort_pairs (kept

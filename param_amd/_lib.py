@@ -38,6 +38,7 @@ EXPORTED_SYMBOLS = (
     "pm_embbag_check",
     "pm_fill_random",
     "pm_set_tuning",
+    "pm_set_forward_tuning",
     "pm_set_backward_tuning",
     "pm_radix_sort_scratch_bytes",
     "pm_radix_sort_pairs",
@@ -144,6 +145,8 @@ def load() -> ctypes.CDLL:
         L.pm_fill_random.argtypes = [vp, i64, i32, i32, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, vp]
         L.pm_set_tuning.restype = ctypes.c_int
         L.pm_set_tuning.argtypes = [i32, i32, i32, i32]
+        L.pm_set_forward_tuning.restype = ctypes.c_int
+        L.pm_set_forward_tuning.argtypes = [i32]
         L.pm_set_backward_tuning.restype = ctypes.c_int
         L.pm_set_backward_tuning.argtypes = [i32, i32, i32, i32]
         L.pm_radix_sort_scratch_bytes.restype = ctypes.c_int64
@@ -163,6 +166,11 @@ def check(rc: int) -> None:
 
 def set_tuning(unroll: int = 0, bags_per_block: int = 0, xcd_affine: int = -1, nt_loads: int = -1) -> None:
     check(load().pm_set_tuning(unroll, bags_per_block, xcd_affine, nt_loads))
+
+
+def set_forward_tuning(stage_out: int = -1) -> None:
+    """``pm_set_forward_tuning``: 1 (default) = LDS-staged output burst per tile, 0 = one row store per finished bag"""
+    check(load().pm_set_forward_tuning(stage_out))
 
 
 def set_backward_tuning(sort_impl: int = -1, order: int = -1, xcd_affine: int = -1, max_phases: int = -1) -> None:

@@ -1,6 +1,7 @@
 // param_amd/csrc/capi.hip -- extern "C" entry points of libparam_amd.so (include/param_amd.h).
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "common.h"
@@ -13,6 +14,7 @@ std::atomic<int> g_unroll{0};
 std::atomic<int> g_bags_per_block{0};
 std::atomic<int> g_xcd_affine{-1};
 std::atomic<int> g_nt_loads{-1};
+std::atomic<int> g_stage_out{-1};
 
 int fail(int code, const std::string& msg) {
     g_last_error = msg;
@@ -109,6 +111,37 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p) {
     // ... and only where the order can matter: with one bag per lane group (short-bag tiles) nothing is pulled
     p.ordered = (total_bags > 0 && op->num_indices % total_bags != 0 && bpb > NG) ? 1 : 0;
     p.alpha = 1.0f;
+    // LDS-staged output (forward): the tile's pooled rows leave in one burst at the end of the tile (embbag_fwd.hip).
+    // Measured at benchmark size: uniform indices 0.69 -> 0.72-0.74 of the HBM peak in both output layouts, Zipf within
+    // +-2 % -- provided the workgroup's LDS stays small (at 6 workgroups per CU the latency-bound Zipf launch lost 12 %):
+    // so only for requests whose lookups divide evenly over the bags (fixed pooling: every benchmark shape), whose index
+    // tile can then be sized for what a tile really holds instead of the 4096-entry default, and only where the staging
+    // buffer fits 16 KB (the tile is halved until it does).  pm_set_forward_tuning(0) / PARAM_AMD_FWD_STAGE=0 turn it off.
+    p.stage_out = 0;
+    {
+        int want = g_stage_out.load();
+        if (want < 0) {
+            const char* e = getenv("PARAM_AMD_FWD_STAGE");
+            want = (e && e[0] == '0') ? 0 : 1;
+        }
+        const bool even = total_bags > 0 && op->num_indices % total_bags == 0;
+        if (want && even && !p.ordered && g_bags_per_block.load() <= 0) {
+            while (bpb > NG && static_cast<int64_t>(bpb) * op->max_dim * 4 > 16384) bpb /= 2;
+            if (static_cast<int64_t>(bpb) * op->max_dim * 4 <= 16384) {
+                const int64_t tiles2 = (op->bag_count + bpb - 1) / bpb;
+                if (tiles2 * op->num_tables <= 0x7fffffffLL) {
+                    p.bags_per_block = bpb;
+                    p.tiles_per_table = static_cast<int32_t>(tiles2);
+                    p.stage_out = op->max_dim;
+                    int64_t need = (2 * static_cast<int64_t>(bpb) * avg_l + 255) / 256 * 256;
+                    if (need < 512) need = 512;
+                    if (need < p.idx_cap) p.idx_cap = static_cast<int32_t>(need);
+                }
+            }
+        } else if (want && even && !p.ordered && static_cast<int64_t>(bpb) * op->max_dim * 4 <= 16384) {
+            p.stage_out = op->max_dim;   // explicit bags_per_block (sweeps): stage if it fits, index tile as configured
+        }
+    }
     return PM_OK;
 }
 
@@ -132,6 +165,12 @@ int pm_set_tuning(int32_t unroll, int32_t bags_per_block, int32_t xcd_affine, in
     g_bags_per_block.store(bags_per_block);
     g_xcd_affine.store(xcd_affine);
     g_nt_loads.store(nt_loads);
+    return PM_OK;
+}
+
+int pm_set_forward_tuning(int32_t stage_out) {
+    if (stage_out < -1 || stage_out > 1) return fail(PM_ERR_INVALID, "stage_out must be -1, 0 or 1");
+    g_stage_out.store(stage_out);
     return PM_OK;
 }
 

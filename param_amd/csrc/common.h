@@ -49,6 +49,7 @@ struct KParams {
     int32_t xcd_affine;          // 1: table t is served by XCD t % 8 (requires T % 8 == 0)
     int32_t nt_loads;            // 1: non-temporal table-row loads
     int32_t ordered;             // forward: 1 = ragged request, lane groups take the longest bags of a tile first
+    int32_t stage_out;           // forward: > 0 = collect the tile's pooled rows in LDS (this many floats per row), write at tile end
     float alpha;                 // bwd scale
 };
 
@@ -111,7 +112,7 @@ __device__ __forceinline__ bool stage_tile(const KParams& p, int t, int tile, ch
     return staged;
 }
 
-inline size_t tile_lds_bytes(int bags_per_block, int idx_cap, bool weighted) {
+__host__ __device__ inline size_t tile_lds_bytes(int bags_per_block, int idx_cap, bool weighted) {
     return (static_cast<size_t>(bags_per_block + 2) / 2 * 2) * sizeof(int64_t) +
            static_cast<size_t>(idx_cap) * 4 * (weighted ? 2 : 1);
 }

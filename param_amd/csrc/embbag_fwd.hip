@@ -63,7 +63,7 @@ __device__ __forceinline__ u32x4 load16(const char* p, bool nt) {
     return nt ? __builtin_nontemporal_load(q) : *q;
 }
 
-template <typename WT, int G, int UNROLL, bool WEIGHTED, bool ORDERED>
+template <typename WT, int G, int UNROLL, bool WEIGHTED, bool ORDERED, bool STAGE>
 __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
     constexpr int VEC = Elem<WT>::kVec;
     constexpr int NG = kBlock / G;  // bags processed concurrently per workgroup
@@ -127,6 +127,10 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
     const int64_t bag0 = p.bag_begin + static_cast<int64_t>(tile) * p.bags_per_block;
     float* out_t = p.io + p.out_offsets[t];
     const bool nt = p.nt_loads != 0;
+    // STAGE: the tile's pooled rows are collected in LDS and leave together when the tile is done -- one burst of
+    // bags_per_block rows (16 KB, contiguous in the [T, B, D] layout) instead of one 512-byte row whenever a lane group
+    // finishes a bag.  LDS: after the index tile, bags_per_block * D floats.
+    float* s_out = reinterpret_cast<float*>(smem + tile_lds_bytes(p.bags_per_block, p.idx_cap, WEIGHTED));
 
     for (int slot = gid; slot < nb;) {
         const int bg = ORDERED ? s_ord[slot] : slot;
@@ -186,12 +190,18 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
                 }
             }
 
-            // streaming stores: the pooled row is consumed by another kernel / the all-to-all
-            f32x4* o4 = reinterpret_cast<f32x4*>(orow + c);
+            if (STAGE) {
+                f32x4* o4 = reinterpret_cast<f32x4*>(s_out + static_cast<size_t>(bg) * D + c);
 #pragma unroll
-            for (int k = 0; k < VEC; k += 4) {
-                f32x4 v = {acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
-                __builtin_nontemporal_store(v, o4 + k / 4);
+                for (int k = 0; k < VEC; k += 4) o4[k / 4] = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+            } else {
+                // streaming stores: the pooled row is consumed by another kernel / the all-to-all
+                f32x4* o4 = reinterpret_cast<f32x4*>(orow + c);
+#pragma unroll
+                for (int k = 0; k < VEC; k += 4) {
+                    f32x4 v = {acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+                    __builtin_nontemporal_store(v, o4 + k / 4);
+                }
             }
         }
         // next bag: one LDS atomic per bag, broadcast inside the group.  Which group pools which bag does not
@@ -200,16 +210,28 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
         if (lig == 0) nxt = atomicAdd(&s_next, 1);
         slot = __shfl(nxt, 0, G);
     }
+    if (STAGE) {
+        __syncthreads();
+        const int q = D / 4;                       // 16-byte pieces per row
+        for (int i = threadIdx.x; i < nb * q; i += kBlock) {
+            const int bg = i / q, c4 = i % q;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(s_out + static_cast<size_t>(bg) * D + c4 * 4);
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out_t + (bag0 + bg) * p.out_stride + c4 * 4));
+        }
+    }
 }
 
 template <typename WT, int G, int UNROLL>
 hipError_t launch_w(const KParams& p, hipStream_t stream) {
     const bool weighted = p.psw != nullptr;
     const int grid = p.T * p.tiles_per_table;
-    const size_t lds = tile_lds_bytes(p.bags_per_block, p.idx_cap, weighted);
-#define PM_FWD(W_, O_) hipLaunchKernelGGL((embbag_fwd_kernel<WT, G, UNROLL, W_, O_>), dim3(grid), dim3(kBlock), lds, stream, p)
-    if (weighted) { if (p.ordered) PM_FWD(true, true); else PM_FWD(true, false); }
-    else { if (p.ordered) PM_FWD(false, true); else PM_FWD(false, false); }
+    size_t lds = tile_lds_bytes(p.bags_per_block, p.idx_cap, weighted);
+#define PM_FWD(W_, O_, S_) hipLaunchKernelGGL((embbag_fwd_kernel<WT, G, UNROLL, W_, O_, S_>), dim3(grid), dim3(kBlock), lds, stream, p)
+    if (p.stage_out && !p.ordered) {   // fixed-pooling requests (capi.hip decides)
+        lds += static_cast<size_t>(p.bags_per_block) * p.stage_out * sizeof(float);   // stage_out = widest row (elements)
+        if (weighted) PM_FWD(true, false, true); else PM_FWD(false, false, true);
+    } else if (weighted) { if (p.ordered) PM_FWD(true, true, false); else PM_FWD(true, false, false); }
+    else { if (p.ordered) PM_FWD(false, true, false); else PM_FWD(false, false, false); }
 #undef PM_FWD
     return hipGetLastError();
 }

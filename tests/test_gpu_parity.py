@@ -138,6 +138,39 @@ def test_seeded_mid_size_vs_c_oracle(coracle):
             assert np.array_equal(got.cpu().numpy(), exp), (D, dtype, it)
 
 
+@pytest.mark.parametrize("wdt,D", [(torch.float32, 128), (torch.float32, 16), (torch.float32, 512), (torch.float32, 1024),
+                                   (torch.bfloat16, 128), (torch.float16, 256)])
+def test_staged_output_forward_bit_identical(coracle, wdt, D):
+    """fixed-pooling requests take the LDS-staged output burst (pm_set_forward_tuning, default on): same bits as the
+    row-by-row stores and as the oracle, both layouts, with and without per-sample weights, tile tails included
+    (batch not a multiple of the tile), rows too wide for a 16 KB staging buffer (D = 1024: not staged)"""
+    import param_amd
+    from param_amd import BatchedEmbeddingBagMI355
+
+    rng = np.random.default_rng(D)
+    T, R, B, L = 5, 3000, 531, 7
+    for layout in ("bd", "tbd"):
+        m = BatchedEmbeddingBagMI355([R] * T, D, dtype=wdt, device=DEV, init="normal", seed=2, layout=layout, fused_update=False)
+        tabs = [m.table(t).float().cpu().numpy() for t in range(T)]
+        idx = rng.integers(0, R, T * B * L).astype(np.int64)
+        off = (np.arange(T * B + 1) * L).astype(np.int64)
+        for psw in (None, rng.standard_normal(idx.size).astype(np.float32)):
+            exp = coracle.fwd_batched(tabs, idx, off, B, psw=psw, layout=layout)
+            outs = []
+            for stage in (1, 0):
+                param_amd.set_forward_tuning(stage)
+                outs.append(m.lookup(_t(idx), _t(off), None if psw is None else _t(psw)).cpu().numpy())
+            param_amd.set_forward_tuning()
+            assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], exp), (layout, psw is not None)
+            # a batch slice through the staged kernel writes exactly its rows
+            o2 = torch.full(exp.shape, float("nan"), device=DEV)
+            m.lookup(_t(idx), _t(off), None if psw is None else _t(psw), out=o2, bag_begin=100, bag_count=333)
+            o2 = o2.cpu().numpy()
+            sel = (slice(100, 433),) if layout == "bd" else (slice(None), slice(100, 433))
+            assert np.array_equal(o2[sel], exp[sel])
+            assert np.isnan(np.delete(o2, np.arange(100, 433), axis=0 if layout == "bd" else 1)).all()
+
+
 def test_weighted_forward_vs_oracle(coracle):
     rng = np.random.default_rng(5)
     R, D, B, L = 3000, 128, 300, 20
@@ -504,6 +537,9 @@ def test_full_size_properties_and_live_torch_oracle():
         param_amd.set_tuning(unroll=unroll, xcd_affine=xcd, nt_loads=nt)
         assert torch.equal(m.lookup(idx, off), out)
     param_amd.set_tuning()
+    param_amd.set_forward_tuning(0)                 # row-by-row output stores instead of the staged burst
+    assert torch.equal(m.lookup(idx, off), out)
+    param_amd.set_forward_tuning()
     # (5) fused update round trip on the big slab: +g then -g restores touched rows to ~1e-6, untouched exactly
     t0 = m.table(0)
     probe = t0[:1000].clone()
