@@ -15,6 +15,13 @@ timeout 600 python bench.py --steps 20 --warmup 5 --workload criteo --no-cpu-bas
 timeout 600 python bench.py --dist-debug --tables 26 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_distdebug_26tables.json 2> $OUT/${TAG}_dd26.err
 timeout 600 python bench.py --dist-debug --workload criteo --steps 10 --warmup 3 --no-cpu-baseline --lookup-cus 224 > $OUT/${TAG}_distdebug_criteo_cu224.json 2> $OUT/${TAG}_ddc.err
 cd /tmp; export TMPDIR=/tmp
+# the dominant kernel alone: every embbag_fwd_kernel launch of these two runs is the headline launch (Zipf) / the
+# roofline-defining launch (uniform), so the kernel's average in the stats file is directly comparable with the bench line
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_zipf -o bench -- \
+    python $REPO/bench.py --steps 20 --warmup 5 --only-headline > $OUT/${TAG}_headline_zipf_under_rocprofv3.json 2> $OUT/${TAG}_prof_zipf.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_uniform -o bench -- \
+    python $REPO/bench.py --steps 20 --warmup 5 --only-headline --alpha 0 > $OUT/${TAG}_headline_uniform_under_rocprofv3.json 2> $OUT/${TAG}_prof_uniform.err
+# the whole default command (forward both layouts and both distributions, backward, fwd+bwd): per-kernel totals
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_bench -o bench -- \
     python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_line_under_rocprofv3.json 2> $OUT/${TAG}_prof_bench.err
 i=0
@@ -25,5 +32,5 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
 done
 cd $REPO
 tail -3 $OUT/${TAG}_pytest.log; cat $OUT/${TAG}_smoke.log
-for f in bench_line bench_line_run2 bench_line_bf16_T64 bench_line_criteo distdebug_26tables distdebug_criteo_cu224 bench_line_under_rocprofv3; do echo "== $f: $(head -c 300 $OUT/${TAG}_$f.json)"; done
+for f in bench_line bench_line_run2 bench_line_bf16_T64 bench_line_criteo distdebug_26tables distdebug_criteo_cu224 bench_line_under_rocprofv3 headline_zipf_under_rocprofv3 headline_uniform_under_rocprofv3; do echo "== $f: $(head -c 300 $OUT/${TAG}_$f.json)"; done
 find $OUT/${TAG}_prof_bench -name "*kernel_stats.csv" | head -2; ls $OUT/${TAG}_pmc
