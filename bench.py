@@ -166,18 +166,31 @@ def _cpu_modes(W: torch.Tensor, idx_sets, B: int, L: int, budget_s: float, param
         k[0] += 1
         return emb(idx_sets[k[0] % len(idx_sets)], off)
 
-    n_here = len(os.sched_getaffinity(0))
+    socket_cpus = sorted(os.sched_getaffinity(0))
+    n_here = len(socket_cpus)
     if param_default:   # what PARAM does out of the box: torch's default thread count, autograd on, nothing pinned
         modes = [("param_default_all_threads_grad_on", torch.get_num_threads(), False)]
     else:               # the calling process is confined to one socket's cores (one hardware thread each)
-        # (as many threads as CPUs in the mask collapses on this host type -- 6 M lookups/s with 64 threads on 64 CPUs against
-        #  1.6 G with 32: the pool then has no CPU left for whatever else wakes up -- so the widest mode leaves two free)
-        modes = [("one_socket_less_2_no_grad", max(1, n_here - 2), True), ("half_socket_no_grad", max(1, n_here // 2), True),
-                 ("quarter_socket_no_grad", max(1, n_here // 4), True), ("one_thread_no_grad", 1, True)]
+        # n threads float inside a mask of n + 2 CPUs spread evenly over the socket: as many threads as CPUs in the mask
+        # collapses on this host type (6 M lookups/s with 64 threads on 64 CPUs against ~1 G with 16: the pool then has no
+        # CPU left for whatever else wakes up), and a mask much wider than the pool lets the scheduler pack the threads
+        # onto a few core complexes one run and spread them the next (32 threads in a 64-CPU mask: 0.53 ... 1.67 G)
+        modes = [("quarter_socket_no_grad", max(1, n_here // 4), True), ("half_socket_no_grad", max(1, n_here // 2), True),
+                 ("one_socket_less_2_no_grad", max(1, n_here - 2), True), ("one_thread_no_grad", 1, True)]
     res = {}
     per_mode = budget_s / len(modes)
     for tag, nthr, no_grad in modes:
         torch.set_num_threads(nthr)
+        if not param_default:
+            want = min(n_here, nthr + 2)
+            cpus = {socket_cpus[(i * n_here) // want] for i in range(want)}
+            with torch.no_grad():
+                cycler(None, None)                                  # the pool's threads exist from here on
+            for tid in os.listdir("/proc/self/task"):               # every thread of the process, workers included
+                try:
+                    os.sched_setaffinity(int(tid), cpus)
+                except OSError:
+                    pass
         ctx = torch.no_grad() if no_grad else torch.enable_grad()
         with ctx:
             t3, _ = measure_cpu(0, 3, cycler, None, None)
