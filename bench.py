@@ -150,7 +150,7 @@ def _one_cpu_per_core():
     return by_pkg
 
 
-def _cpu_modes(W: torch.Tensor, idx_sets, B: int, L: int, budget_s: float, param_default: bool):
+def _cpu_modes(W: torch.Tensor, idx_sets, B: int, L: int, budget_s: float):
     """runs INSIDE a child process (see cpu_baseline): the reference CPU engine under the measure_cpu protocol
     (pytorch_emb.py:37-45); per mode 3 discarded warm-up steps, then 7 repeats of a fixed step count -> median.  Successive
     steps take successive index sets (those of the first tables of the GPU request), so a step's rows are not the previous
@@ -166,31 +166,14 @@ def _cpu_modes(W: torch.Tensor, idx_sets, B: int, L: int, budget_s: float, param
         k[0] += 1
         return emb(idx_sets[k[0] % len(idx_sets)], off)
 
-    socket_cpus = sorted(os.sched_getaffinity(0))
-    n_here = len(socket_cpus)
-    if param_default:   # what PARAM does out of the box: torch's default thread count, autograd on, nothing pinned
-        modes = [("param_default_all_threads_grad_on", torch.get_num_threads(), False)]
-    else:               # the calling process is confined to one socket's cores (one hardware thread each)
-        # n threads float inside a mask of n + 2 CPUs spread evenly over the socket: as many threads as CPUs in the mask
-        # collapses on this host type (6 M lookups/s with 64 threads on 64 CPUs against ~1 G with 16: the pool then has no
-        # CPU left for whatever else wakes up), and a mask much wider than the pool lets the scheduler pack the threads
-        # onto a few core complexes one run and spread them the next (32 threads in a 64-CPU mask: 0.53 ... 1.67 G)
-        modes = [("quarter_socket_no_grad", max(1, n_here // 4), True), ("half_socket_no_grad", max(1, n_here // 2), True),
-                 ("one_socket_less_2_no_grad", max(1, n_here - 2), True), ("one_thread_no_grad", 1, True)]
+    n_default = torch.get_num_threads()          # torch's choice: one thread per physical core
+    modes = [("param_default_all_threads_grad_on", n_default, False),   # what PARAM does out of the box
+             ("all_threads_no_grad", n_default, True), ("half_threads_no_grad", max(1, n_default // 2), True),
+             ("one_thread_no_grad", 1, True)]
     res = {}
     per_mode = budget_s / len(modes)
     for tag, nthr, no_grad in modes:
         torch.set_num_threads(nthr)
-        if not param_default:
-            want = min(n_here, nthr + 2)
-            cpus = {socket_cpus[(i * n_here) // want] for i in range(want)}
-            with torch.no_grad():
-                cycler(None, None)                                  # the pool's threads exist from here on
-            for tid in os.listdir("/proc/self/task"):               # every thread of the process, workers included
-                try:
-                    os.sched_setaffinity(int(tid), cpus)
-                except OSError:
-                    pass
         ctx = torch.no_grad() if no_grad else torch.enable_grad()
         with ctx:
             t3, _ = measure_cpu(0, 3, cycler, None, None)
@@ -206,12 +189,12 @@ def _cpu_modes(W: torch.Tensor, idx_sets, B: int, L: int, budget_s: float, param
 
 
 def cpu_child(spec: dict) -> dict:
-    """entry of the child process: confine the process to one socket (memory first-touched there, OpenMP workers created
-    there), rebuild table 0 of the parent's workload on the GPU (counter-based fill: same seed -> same bits), copy it to the
-    host with the index sets of the first tables of the request, time the CPU modes"""
-    by_pkg = _one_cpu_per_core()
-    if not spec["param_default"]:
-        os.sched_setaffinity(0, set(by_pkg[min(by_pkg)]))
+    """entry of the child process: rebuild table 0 of the parent's workload on the GPU (counter-based fill: same seed ->
+    same bits), copy it to the host with the index sets of the first tables of the request, drop the device objects, time
+    the CPU modes.  The process keeps the CPU mask it was given: every attempt to confine or pin the OpenMP pool on this
+    host type (OMP_PLACES / OMP_PROC_BIND, a socket mask, a mask of threads + 2 CPUs) ran into the same cliff -- a pool as
+    wide as its mask collapses to ~6 M lookups/s, presumably against the runtime's own helper threads -- while the
+    unconfined default (one thread per core on 256 hardware threads) is both the fastest and the steadiest."""
     dev = torch.device("cuda", spec["device"])
     torch.cuda.set_device(dev)
     m = param_amd.BatchedEmbeddingBagMI355([spec["rows"]], spec["dim"], dtype=_DT[spec["dtype"]], device=dev, init="normal",
@@ -221,58 +204,57 @@ def cpu_child(spec: dict) -> dict:
     n1 = spec["batch"] * spec["pooling"]
     sets = [idx[i * n1:(i + 1) * n1].cpu() for i in range(K)]
     W = m.table(0).float().cpu()
-    out = {"modes": _cpu_modes(W, sets, spec["batch"], spec["pooling"], spec["budget_s"], spec["param_default"]),
+    del m, idx
+    torch.cuda.empty_cache()
+    by_pkg = _one_cpu_per_core()
+    out = {"modes": _cpu_modes(W, sets, spec["batch"], spec["pooling"], spec["budget_s"]),
            "cpus_in_mask": len(os.sched_getaffinity(0)), "sockets": len(by_pkg), "physical_cores": sum(len(v) for v in by_pkg.values())}
-    if spec.get("c_oracle"):
-        try:
-            from oracle.embbag_oracle import COracle
+    try:
+        from oracle.embbag_oracle import COracle
 
-            nb = min(spec["batch"], 2048)
-            orc = COracle()
-            Wn, In = W.numpy(), sets[0][: nb * spec["pooling"]].numpy()
-            On = (torch.arange(nb, dtype=torch.int64) * spec["pooling"]).numpy()
-            orc.fwd(Wn, In, On)
-            t0 = time.perf_counter()
-            orc.fwd(Wn, In, On)
-            out["c_oracle_1core"] = {"lookups_per_s": nb * spec["pooling"] / (time.perf_counter() - t0), "bags": nb}
-        except Exception as exc:  # the checker is optional for the baseline leg
-            out["c_oracle_1core"] = {"error": str(exc)}
+        nb = min(spec["batch"], 2048)
+        orc = COracle()
+        Wn, In = W.numpy(), sets[0][: nb * spec["pooling"]].numpy()
+        On = (torch.arange(nb, dtype=torch.int64) * spec["pooling"]).numpy()
+        orc.fwd(Wn, In, On)
+        t0 = time.perf_counter()
+        orc.fwd(Wn, In, On)
+        out["c_oracle_1core"] = {"lookups_per_s": nb * spec["pooling"] / (time.perf_counter() - t0), "bags": nb}
+    except Exception as exc:  # the checker is optional for the baseline leg
+        out["c_oracle_1core"] = {"error": str(exc)}
     return out
 
 
 def cpu_baseline(spec: dict, budget_s: float = 12.0):
     """Reference CPU engine (torch.nn.EmbeddingBag(sum), the reference's measure_cpu protocol) on a bounded sample: ONE table
     of the workload (same rows / dim as table 0 on the GPU) looked up with the index sets of the request's first 8 tables in
-    turn.  Timed in a CHILD process confined to one socket (memory and threads local; 64 / 32 / 16 / 1 threads), so that no
-    affinity or thread-pool setting leaks into the GPU timing; a second child records what PARAM does out of the box (all
-    threads, autograd on).  ``value`` = the best median of the confined modes, named in ``sample``."""
+    turn.  Timed in a CHILD process, so that no thread-pool setting leaks into the GPU timing.  ``value`` = the best median
+    of the modes, named in ``sample``."""
     import subprocess
 
-    results = {}
-    for tag, pd, share in (("one_socket", False, 0.8), ("param_default", True, 0.2)):
-        child_spec = dict(spec, param_default=pd, budget_s=budget_s * share, c_oracle=not pd, index_sets=8)
-        env = {k: v for k, v in os.environ.items() if not k.startswith(("OMP_", "GOMP_", "KMP_")) and k not in
-               ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-        try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", json.dumps(child_spec)], env=env,
-                               capture_output=True, text=True, timeout=300)
-            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-            results[tag] = json.loads(line[-1]) if r.returncode == 0 and line else {"error": (r.stderr or r.stdout)[-400:]}
-        except Exception as exc:
-            results[tag] = {"error": str(exc)}
-    modes = results.get("one_socket", {}).get("modes", {})
+    child_spec = dict(spec, budget_s=budget_s, index_sets=8)
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("OMP_", "GOMP_", "KMP_")) and k not in
+           ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", json.dumps(child_spec)], env=env,
+                           capture_output=True, text=True, timeout=300)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        result = json.loads(line[-1]) if r.returncode == 0 and line else {"error": (r.stderr or r.stdout)[-400:]}
+    except Exception as exc:
+        result = {"error": str(exc)}
+    modes = result.get("modes", {})
     if not modes:
-        return {"value": None, "unit": "lookups/s", "cores": None, "kind": "port", "sample": f"failed: {results}"}
+        return {"value": None, "unit": "lookups/s", "cores": None, "kind": "port", "sample": f"failed: {result}"}
     best_name = max(modes, key=lambda n: modes[n]["lookups_per_s"])
     best = modes[best_name]
     return {
         "value": best["lookups_per_s"], "unit": "lookups/s", "cores": best["threads"], "kind": "port",
         "sample": (f"torch.nn.EmbeddingBag(sum) on host (the engine the reference calls, its measure_cpu protocol), 1 table "
                    f"{spec['rows']}x{spec['dim']} fp32, batch {spec['batch']}, pool {spec['pooling']}, the index sets of the request's "
-                   f"first 8 tables in turn (672 MB of rows per cycle: no cache residency, like the 48-table workload); process "
-                   f"confined to one socket; best mode = {best_name}: {best['threads']} threads, median of 7 x {best['steps']} steps "
-                   f"after 3 warm-ups"),
-        "best_mode": best_name, "host_cpu_count": os.cpu_count(), "children": results,
+                   f"first 8 tables in turn (672 MB of rows per cycle: no cache residency across steps, like the 48-table "
+                   f"workload); best mode = {best_name}: {best['threads']} threads, median of 7 x {best['steps']} steps after "
+                   f"3 warm-ups"),
+        "best_mode": best_name, "host_cpu_count": os.cpu_count(), "child": result,
     }
 
 
