@@ -140,6 +140,11 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p) {
             }
         } else if (want && even && !p.ordered && static_cast<int64_t>(bpb) * op->max_dim * 4 <= 16384) {
             p.stage_out = op->max_dim;   // explicit bags_per_block (sweeps): stage if it fits, index tile as configured
+        } else if (want && !even && !p.ordered && g_bags_per_block.load() <= 0 &&
+                   static_cast<int64_t>(bpb) * op->max_dim * 4 <= 4096) {
+            // short-bag tiles of requests with per-table pooling (Criteo multi-hot: one bag per lane group, 8 bags per
+            // tile): the staging buffer is 4 KB, the full-size index tile stays -- 20.6 KB per workgroup
+            p.stage_out = op->max_dim;
         }
     }
     return PM_OK;

@@ -171,6 +171,33 @@ def test_staged_output_forward_bit_identical(coracle, wdt, D):
             assert np.isnan(np.delete(o2, np.arange(100, 433), axis=0 if layout == "bd" else 1)).all()
 
 
+def test_staged_forward_when_lookups_divide_evenly_but_bags_are_ragged(coracle):
+    """the output burst is chosen from a host-visible fact (lookups divide evenly over the bags) and sizes the index tile
+    for the AVERAGE bag: a ragged request that happens to divide evenly -- a quarter of the bags 80 lookups long, the rest
+    empty -- overflows that tile and must take the direct-index path, with the same bits"""
+    from param_amd import BatchedEmbeddingBagMI355
+
+    rng = np.random.default_rng(77)
+    T, R, D, B = 3, 4000, 128, 256
+    lens = np.zeros(T * B, dtype=np.int64)
+    lens[::4] = 80                                   # average 20; tiles of 32 bags hold 640 lookups on average ...
+    lens[:64] = 0
+    lens[64:96] = 160                                # ... but this one 5120
+    lens[96:128] = 0
+    # make the total divide evenly: pad the last bag
+    short = (-int(lens.sum())) % (T * B)
+    lens[-1] += short
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    idx = np.concatenate([rng.integers(0, R, int(lens[t * B:(t + 1) * B].sum())) for t in range(T)]).astype(np.int64)
+    assert idx.size % (T * B) == 0
+    for layout in ("bd", "tbd"):
+        m = BatchedEmbeddingBagMI355([R] * T, D, device=DEV, init="normal", seed=5, layout=layout, fused_update=False)
+        tabs = [m.table(t).cpu().numpy() for t in range(T)]
+        out = m.lookup(_t(idx), _t(off), batch=B)
+        exp = coracle.fwd_batched(tabs, idx, off, B, layout=layout)
+        assert np.array_equal(out.cpu().numpy(), exp), layout
+
+
 def test_weighted_forward_vs_oracle(coracle):
     rng = np.random.default_rng(5)
     R, D, B, L = 3000, 128, 300, 20
