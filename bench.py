@@ -26,9 +26,12 @@ profile, labelled with the profile's file name -- counters are never collected i
 unless ``--traffic-from-profile`` is given, and then ``traffic_from_profile`` says where the number comes from.
 
 Also timed in the default N == 1 run (BASELINE configs[2]): the deterministic scatter-add backward (key sort + apply,
-apply alone) and the whole fwd + bwd step, under Zipf and under uniform indices.  ``cpu_baseline`` times the reference's
-CPU engine (torch.nn.EmbeddingBag, pytorch_emb.py:37-45 protocol) and the 1-core C oracle on a bounded sample on the
-box's host cores (rank 0, N == 1 only).
+apply alone) and the whole fwd + bwd step, under Zipf and under uniform indices, and the forward writing the other output
+layout.  Order: the uniform block runs first (with 25 warm-up launches of its own), the timed headline steps (W warm-ups, K
+steps, as given) directly after it -- a block that runs first after the set-up phase rides a clock / power transient of
+3-4 %.  ``cpu_baseline`` times the reference's CPU engine (torch.nn.EmbeddingBag, pytorch_emb.py:37-45 protocol) in a child
+process on a bounded sample -- one table, the index sets of the request's first 8 tables in turn -- and the 1-core C oracle
+(rank 0, N == 1 only); ``value`` there is the reference's own mode (all threads, autograd on).
 
 N > 1 additionally reports the exchange alone (algBW / busBW with the reference's definitions), the lookup alone, the
 overlap efficiency max(lookup, exchange) / step, and a fwd + bwd training step with BOTH exchanges (pooled embeddings out,

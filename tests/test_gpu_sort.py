@@ -1,6 +1,7 @@
 """The build's own radix sort (param_amd/csrc/radix_sort.hip, C ABI pm_radix_sort_pairs) against numpy's stable argsort,
 and the sorted backward under every sort / order / XCD-mapping setting against the CPU oracle."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -203,7 +204,7 @@ def test_two_phase_apply_engages_and_adagrad_refuses_it(coracle):
     param_amd.set_backward_tuning()
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("PARAM_AMD_FUZZ_SEEDS", "24"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PARAM_AMD_FUZZ_SEEDS", "24"))))
 def test_random_fixed_pooling_requests_under_random_tuning(coracle, seed):
     """fixed-pooling requests whose sizes do / do not line up with the sort tile (4096) and the apply tile (1024), tables of
     3 ... 70000 rows (runs far beyond the exact-run limit included), with and without per-sample weights, under a random
