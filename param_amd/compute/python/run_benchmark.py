@@ -69,7 +69,7 @@ class OpExecutor:
     def _bind(self, data) -> None:
         """the two callables the timing loops launch: eager calls, or replays of HIP graphs captured once
         (``--cuda-graph``, reference ``op_executor.py:82-97``; the kernels go through the C ABI on the capturing stream,
-        rocPRIM's sort included; the stochastic-rounding seed of a captured Adagrad step is frozen)"""
+        the radix sort's launches included; the stochastic-rounding seed of a captured Adagrad step is frozen)"""
         if not self.use_graph:
             self._fwd = lambda: self.op.forward(*data)
 

@@ -486,6 +486,7 @@ hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, int64_t
     if (rc != hipSuccess) return rc;
     {
         std::lock_guard<std::mutex> lock(g_plan_mutex);
+        if (g_plans.size() >= 4096 && g_plans.find(workspace) == g_plans.end()) g_plans.clear();   // bound the record table
         g_plans[workspace] = g;
     }
     // the key type follows the PLAN (a one-phase plan of a request whose two-phase key would need 33 bits still sorts
