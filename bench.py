@@ -584,14 +584,29 @@ def main():
             return r
 
         out_fb = torch.empty(out_shape, dtype=torch.float32, device=dev)
+        side_stream = torch.cuda.Stream(device=dev)
+        ev_sorted = torch.cuda.Event()
 
         def fwd_bwd_block(i, o, uniform):
             def fwd_bwd():
                 model.lookup(i, o, out=out_fb, batch=B_glob)
                 model.scatter_add_(grad, i, o, alpha=-1e-6, batch=B_glob)
             _, fb = time_steps(fwd_bwd, n_sub, 2, barrier)
+
+            # the key sort needs only the request: on a second HIP stream it runs UNDER the lookup; the apply waits for both
+            def fwd_bwd_sort_aside():
+                main = torch.cuda.current_stream()
+                side_stream.wait_stream(main)            # the previous step's apply is done with the sort scratch
+                with torch.cuda.stream(side_stream):
+                    model.sort_indices(i, o, batch=B_glob)
+                    ev_sorted.record(side_stream)
+                model.lookup(i, o, out=out_fb, batch=B_glob)
+                main.wait_event(ev_sorted)
+                model.scatter_add_(grad, i, o, alpha=-1e-6, batch=B_glob, presorted=True)
+            _, fo = time_steps(fwd_bwd_sort_aside, n_sub, 2, barrier)
             fb_bytes = alg_bytes + bwd_bytes
-            return {"avg_s": fb, "lookups_per_s": lookups_step_rank / fb, "algorithmic_GBps": fb_bytes / fb / 1e9,
+            return {"avg_s": fb, "avg_s_sort_on_side_stream": fo, "lookups_per_s": lookups_step_rank / fb,
+                    "algorithmic_GBps": fb_bytes / fb / 1e9,
                     ("frac" if uniform else "alg_frac"): fb_bytes / fb / 1e9 / HBM_PEAK_GBPS,
                     "bytes_per_lookup": fb_bytes / lookups_step_rank}
 

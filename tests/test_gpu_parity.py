@@ -647,6 +647,58 @@ def test_full_size_zipf_headline_workload():
     torch.cuda.empty_cache()
 
 
+def test_full_size_bf16_tables_forward_and_inplace_update():
+    """BASELINE configs[2]'s other dtype at full size: all 64 x 10 M x 128 bf16 tables (163.8 GB) resident, B = 8192, L = 20,
+    Zipf(1.05).  Forward against torch-ROCm's fp32 embedding_bag on the widened copies of 2 tables (rows are widened exactly,
+    accumulation is fp32 on both sides: 1e-5 of sum |row|); L = 1 gather bit-exact; the sorted in-place update (fp32
+    accumulate, ONE rounding per touched row) on a slice of table 0 against that definition computed in fp64 -> bf16; rows
+    never looked up keep their bits."""
+    from param_amd import BatchedEmbeddingBagMI355
+    from param_amd.indices import tbe_request
+
+    free, _total = torch.cuda.mem_get_info()
+    R, D, B, L = 10_000_000, 128, 8192, 20
+    T = int(min(64, (free - (24 << 30)) // (R * D * 2)) // 8 * 8)
+    assert T >= 8, f"only {free / 2**30:.0f} GiB free"
+    m = BatchedEmbeddingBagMI355([R] * T, D, dtype=torch.bfloat16, device=DEV, init="normal", seed=4, fused_update=False)
+    idx, off = tbe_request([R] * T, B, L, alpha=1.05, device=DEV, seed=6)
+    out = m.lookup(idx, off)
+    for t in (0, T - 1):
+        Wf = m.table(t).float()
+        sl = slice(t * B * L, (t + 1) * B * L)
+        ref = torch.nn.functional.embedding_bag(idx[sl], Wf, off[t * B:(t + 1) * B] - t * B * L, mode="sum")
+        mag = torch.nn.functional.embedding_bag(idx[sl], Wf.abs(), off[t * B:(t + 1) * B] - t * B * L, mode="sum")
+        assert ((out[:, t * D:(t + 1) * D] - ref).abs() <= 1e-5 * mag + 1e-30).all(), t
+        del Wf, ref, mag
+    g_idx = torch.randint(0, R, (T * B,), device=DEV)
+    g_out = m.lookup(g_idx, torch.arange(T * B + 1, device=DEV))
+    assert torch.equal(g_out[:, :D], m.table(0)[g_idx[:B]].float())
+    # in-place update of the whole request; checked on table 0: hottest rows, mid-frequency rows, singles, untouched rows
+    i0 = idx[:B * L]
+    counts0 = torch.bincount(i0, minlength=R)
+    sel = torch.unique(torch.cat([torch.argsort(counts0, descending=True)[:32],
+                                  ((counts0 >= 2) & (counts0 <= 256)).nonzero().squeeze(1)[:1500],
+                                  (counts0 == 1).nonzero().squeeze(1)[:1500], (counts0 == 0).nonzero().squeeze(1)[:1500]]))
+    before = m.table(0)[sel].clone()
+    grad = torch.randn(B, T * D, device=DEV)
+    alpha = -0.5
+    m.scatter_add_(grad, idx, off, alpha=alpha)
+    after = m.table(0)[sel]
+    pos = torch.isin(i0, sel).nonzero().squeeze(1)
+    slot = torch.searchsorted(sel, i0[pos])
+    g0 = grad[:, :D].double()
+    G = torch.zeros(sel.numel(), D, dtype=torch.float64, device=DEV).index_add_(0, slot, g0[pos // L])
+    Gabs = torch.zeros(sel.numel(), D, dtype=torch.float64, device=DEV).index_add_(0, slot, g0[pos // L].abs())
+    exact = before.double() + alpha * G
+    # one bf16 rounding of the fp32-accumulated row: within half a bf16 ulp of the exact value, plus the fp32 accumulation error
+    tol = exact.abs() * 2.0 ** -8 + 1e-5 * (abs(alpha) * Gabs + before.double().abs()) + 1e-30
+    assert ((after.double() - exact).abs() <= tol).all()
+    untouched = counts0[sel] == 0
+    assert torch.equal(after[untouched], before[untouched]) and int((counts0[sel] > 256).sum()) >= 16
+    del m
+    torch.cuda.empty_cache()
+
+
 def test_fused_rowwise_adagrad_vs_oracle(coracle):
     """pm_embbag_bwd_sorted_adagrad vs the CPU restatement of fbgemm's exact row-wise Adagrad (parity UNPINNED:
     fbgemm is absent; the oracle itself is checked against an fp64 numpy form here).  Two steps, Zipf duplicates
