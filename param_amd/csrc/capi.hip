@@ -139,7 +139,10 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p) {
                 }
             }
         } else if (want && even && !p.ordered && static_cast<int64_t>(bpb) * op->max_dim * 4 <= 16384) {
-            p.stage_out = op->max_dim;   // explicit bags_per_block (sweeps): stage if it fits, index tile as configured
+            p.stage_out = op->max_dim;   // explicit bags_per_block (sweeps): stage if it fits, index tile sized the same way
+            int64_t need = (2 * static_cast<int64_t>(bpb) * avg_l + 255) / 256 * 256;
+            if (need < 512) need = 512;
+            if (need < p.idx_cap) p.idx_cap = static_cast<int32_t>(need);
         } else if (want && !even && !p.ordered && g_bags_per_block.load() <= 0 &&
                    static_cast<int64_t>(bpb) * op->max_dim * 4 <= 4096) {
             // short-bag tiles of requests with per-table pooling (Criteo multi-hot: one bag per lane group, 8 bags per

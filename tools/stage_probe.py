@@ -12,8 +12,9 @@ T, R, D, B, L = 48, 10_000_000, 128, 8192, 20
 m = param_amd.BatchedEmbeddingBagMI355([R] * T, D, device=dev, init="normal", seed=1, fused_update=False)
 alg = T * B * L * (D * 4 + 8) + T * B * (D * 4 + 8)
 bpb = int(os.environ.get("BPB", "0"))
-param_amd.set_tuning(bags_per_block=bpb)
-for layout in ("tbd", "bd"):
+unroll = int(os.environ.get("UNROLL", "0"))
+param_amd.set_tuning(unroll=unroll, bags_per_block=bpb)
+for layout in ("tbd",):
     ts = _TableSet([m.table(t) for t in range(T)], layout)
     out = torch.empty((T, B, D) if layout == "tbd" else (B, T * D), device=dev)
     for name, alpha in (("uniform", 0.0), ("zipf", 1.05)):
@@ -27,5 +28,5 @@ for layout in ("tbd", "bd"):
             for _ in range(20): _fwd(ts, idx, off, B, out=out)
             e1.record(); torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) * 1e-3 / 20)
-        print(json.dumps({"stage": os.environ.get("PARAM_AMD_FWD_STAGE", "0"), "bpb": bpb, "layout": layout, "indices": name, "ms": best * 1e3,
+        print(json.dumps({"stage": os.environ.get("PARAM_AMD_FWD_STAGE", "0"), "bpb": bpb, "unroll": unroll, "layout": layout, "indices": name, "ms": best * 1e3,
                           "alg_frac": alg / best / 8e12, "checksum": float(out.double().sum())}), flush=True)
