@@ -166,6 +166,12 @@ int pm_embbag_sort_indices(const pm_embbag_batch* op, int64_t max_rows, void* wo
  */
 int pm_embbag_sort_indices_ex(const pm_embbag_batch* op, int64_t max_rows, int32_t phases, void* workspace,
                               int64_t workspace_bytes, pm_stream_t stream);
+/*
+ * Host-only: writes a one-line description of the layout pm_embbag_sort_indices_ex would choose for this request under
+ * the current tuning ("sort=own key_bytes=4 ... passes=3 segmented=1 ... xcd=1 ...") into out.  No device access; for
+ * tests, sweeps and bug reports.
+ */
+int pm_embbag_sort_plan(const pm_embbag_batch* op, int64_t max_rows, int32_t phases, char* out, int32_t out_bytes);
 int pm_embbag_bwd_sorted(const pm_embbag_batch* op, const float* grad, void* const* dst_tables,
                          int32_t dst_dtype, float alpha, int64_t max_rows, const void* workspace,
                          int64_t workspace_bytes, pm_stream_t stream);

@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = (
     "pm_embbag_bwd_sorted_workspace",
     "pm_embbag_sort_indices",
     "pm_embbag_sort_indices_ex",
+    "pm_embbag_sort_plan",
     "pm_embbag_bwd_sorted",
     "pm_embbag_bwd_sorted_adagrad",
     "pm_embbag_bwd_sorted_adagrad_ex",
@@ -128,6 +129,8 @@ def load() -> ctypes.CDLL:
         L.pm_embbag_sort_indices.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, vp, i64, vp]
         L.pm_embbag_sort_indices_ex.restype = ctypes.c_int
         L.pm_embbag_sort_indices_ex.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, i32, vp, i64, vp]
+        L.pm_embbag_sort_plan.restype = ctypes.c_int
+        L.pm_embbag_sort_plan.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, i32, ctypes.c_char_p, i32]
         L.pm_embbag_bwd_sorted.restype = ctypes.c_int
         L.pm_embbag_bwd_sorted.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, ctypes.c_float, i64, vp,
                                            i64, vp]

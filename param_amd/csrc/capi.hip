@@ -302,6 +302,18 @@ int pm_embbag_sort_indices_ex(const pm_embbag_batch* op, int64_t max_rows, int32
     return PM_OK;
 }
 
+int pm_embbag_sort_plan(const pm_embbag_batch* op, int64_t max_rows, int32_t phases, char* out, int32_t out_bytes) {
+    if (phases != 1 && phases != 2) return fail(PM_ERR_INVALID, "phases must be 1 or 2");
+    if (!out || out_bytes < 1) return fail(PM_ERR_INVALID, "out buffer is NULL / empty");
+    pm::KParams p;
+    int rc = make_params(op, op ? op->weight_dtype : -1, p);
+    if (rc != PM_OK) return rc;
+    if ((rc = sorted_args_ok(op, max_rows)) != PM_OK) return rc;
+    const std::string d = pm::sort_plan_describe(p, max_rows, op->fixed_pooling, phases);
+    snprintf(out, static_cast<size_t>(out_bytes), "%s", d.c_str());
+    return PM_OK;
+}
+
 int pm_embbag_bwd_sorted(const pm_embbag_batch* op, const float* grad, void* const* dst_tables, int32_t dst_dtype,
                          float alpha, int64_t max_rows, const void* workspace, int64_t workspace_bytes,
                          pm_stream_t stream) {

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+
 #include "param_amd.h"
 
 namespace pm {
@@ -132,6 +134,7 @@ hipError_t sorted_workspace_bytes(const KParams& p, int64_t max_rows, int max_di
 hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, int64_t fixed_pooling, int phases, void* workspace,
                         hipStream_t stream);
 int bwd_sorted_plan_check(const KParams& p, int64_t max_rows, const void* workspace, bool adagrad);
+std::string sort_plan_describe(const KParams& p, int64_t max_rows, int64_t fixed_pooling, int phases);
 hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, int max_dim, const void* workspace,
                             float* const* momentum, const pm_rowwise_adagrad* opt, hipStream_t stream);
 

@@ -26,6 +26,7 @@
 // Step 1+2 depend only on the indices, not on the gradient: pm_embbag_sort_indices() can run
 // on a side stream under the forward pass; pm_embbag_bwd_sorted() is step 3.
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <string>
@@ -492,6 +493,20 @@ hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, int64_t
     // the key type follows the PLAN (a one-phase plan of a request whose two-phase key would need 33 bits still sorts
     // 4-byte keys); the buffers were sized for the wider of the two
     return g.key_bytes == 4 ? sort_impl<uint32_t>(p, g, ws, stream) : sort_impl<uint64_t>(p, g, ws, stream);
+}
+
+// human-readable form of the plan a sort of this request would use (host-only; tests and sweeps)
+std::string sort_plan_describe(const KParams& p, int64_t max_rows, int64_t fixed_pooling, int phases) {
+    const SortPlan g = make_plan(p, max_rows, fixed_pooling, phases);
+    const int passes = g.rocprim ? -1 : rs_num_passes(0, g.sort_end_bit);
+    char buf[512];
+    snprintf(buf, sizeof(buf),
+             "sort=%s key_bytes=%d rbits=%d hbits=%d kbits=%d sort_bits=%d passes=%d segmented=%d seg_len=%lld phases=%d "
+             "apply_seg_tiles=%d xcd=%d sliced=%d weighted=%d result_in_b=%d",
+             g.rocprim ? "rocprim" : "own", g.key_bytes, g.rbits, g.hbits, g.kbits, g.sort_end_bit, passes, g.segmented ? 1 : 0,
+             static_cast<long long>(g.segmented ? g.seg_len : 0), g.H, (g.xcd || g.H > 1) ? g.seg_tiles : 0, g.xcd ? 1 : 0,
+             g.sliced ? 1 : 0, g.weighted ? 1 : 0, g.in_b ? 1 : 0);
+    return buf;
 }
 
 // 0: ok, 1: no sort was recorded for this workspace / it was for another request, 2: sorted in two bag phases but the

@@ -120,3 +120,53 @@ def test_c_abi_demo_runs_on_gpu(tmp_path):
     r = subprocess.run([_build_c_demo(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "forward bit-exact, sorted backward bit-exact" in r.stdout
+
+
+def _plan(L, T, B, Lp, max_rows, phases=1, fixed=True, slice_=None, weighted=False):
+    op = _lib.pm_embbag_batch()
+    op.num_tables, op.weight_dtype, op.index_dtype, op.max_dim = T, _lib.PM_F32, _lib.PM_I64, 128
+    op.batch, op.num_indices = B, T * B * Lp
+    op.bag_begin, op.bag_count = (0, B) if slice_ is None else slice_
+    op.tables = op.rows = op.dims = op.out_offsets = op.indices = op.offsets = 8     # never dereferenced on the host
+    op.per_sample_weights = 8 if weighted else None
+    op.out_stride = T * 128
+    op.fixed_pooling = Lp if fixed else 0
+    buf = ctypes.create_string_buffer(512)
+    assert L.pm_embbag_sort_plan(ctypes.byref(op), max_rows, phases, buf, 512) == _lib.PM_OK, L.pm_last_error()
+    return dict(kv.split("=") for kv in buf.value.decode().split())
+
+
+def test_sort_plan_decisions_on_the_host():
+    """which layout the sorted backward picks for a request is a host-side decision (make_plan): pinned here without a GPU"""
+    L = _lib.load()
+    assert L.pm_set_backward_tuning(-1, -1, -1, -1) == _lib.PM_OK
+    bench = _plan(L, 48, 8192, 20, 10_000_000)                       # the benchmark step
+    assert bench["sort"] == "own" and bench["key_bytes"] == "4" and bench["rbits"] == "24" and bench["kbits"] == "30"
+    assert bench["segmented"] == "1" and bench["seg_len"] == str(8192 * 20) and bench["passes"] == "3" and bench["sort_bits"] == "24"
+    assert bench["apply_seg_tiles"] == "160" and bench["xcd"] == "1" and bench["phases"] == "1" and bench["result_in_b"] == "1"
+    ragged = _plan(L, 48, 8192, 20, 10_000_000, fixed=False)          # no fixed-pooling claim: all key bits, global, linear tiles
+    assert ragged["segmented"] == "0" and ragged["sort_bits"] == "30" and ragged["passes"] == "4" and ragged["xcd"] == "0"
+    assert ragged["apply_seg_tiles"] == "0" and ragged["result_in_b"] == "0"
+    sliced = _plan(L, 48, 8192, 20, 10_000_000, slice_=(100, 50))     # batch slice: padding keys must sort last
+    assert sliced["sliced"] == "1" and sliced["sort_bits"] == "31" and sliced["segmented"] == "0" and sliced["xcd"] == "0"
+    odd = _plan(L, 5, 100, 7, 1000)                                   # fixed pooling, nothing tile-aligned
+    assert odd["segmented"] == "0" and odd["apply_seg_tiles"] == "0" and odd["sort_bits"] == str(10 + 3)
+    one = _plan(L, 1, 8192, 20, 10_000_000)                           # a single table: segments yes, XCD mapping pointless
+    assert one["segmented"] == "1" and one["xcd"] == "0" and one["apply_seg_tiles"] == "0"
+    wide = _plan(L, 1024, 64, 64, 1 << 30)                            # 30 + 10 key bits: 8-byte keys
+    assert wide["key_bytes"] == "8" and wide["kbits"] == "40"
+    # two bag phases only on request AND with the knob: default max_phases = 1
+    assert _plan(L, 48, 8192, 20, 10_000_000, phases=2)["phases"] == "1"
+    assert L.pm_set_backward_tuning(-1, -1, -1, 2) == _lib.PM_OK
+    two = _plan(L, 48, 8192, 20, 10_000_000, phases=2)
+    assert two["phases"] == "2" and two["hbits"] == "1" and two["kbits"] == "31" and two["seg_len"] == str(4096 * 20)
+    assert two["apply_seg_tiles"] == "80" and two["key_bytes"] == "4"
+    assert _plan(L, 48, 8192, 20, 10_000_000, phases=1)["phases"] == "1"
+    # row order: only the row bits, no segments, no XCD mapping; rocPRIM: no segments either
+    assert L.pm_set_backward_tuning(-1, 0, -1, -1) == _lib.PM_OK
+    row = _plan(L, 48, 8192, 20, 10_000_000)
+    assert row["sort_bits"] == "24" and row["segmented"] == "0" and row["xcd"] == "0"
+    assert L.pm_set_backward_tuning(1, -1, -1, -1) == _lib.PM_OK
+    rp = _plan(L, 48, 8192, 20, 10_000_000)
+    assert rp["sort"] == "rocprim" and rp["segmented"] == "0" and rp["sort_bits"] == "30" and rp["xcd"] == "1" and rp["result_in_b"] == "1"
+    assert L.pm_set_backward_tuning(-1, -1, -1, -1) == _lib.PM_OK
