@@ -288,6 +288,24 @@ int pm_set_forward_tuning(int32_t stage_out);
 int pm_set_backward_tuning(int32_t sort_impl, int32_t order, int32_t xcd_affine, int32_t max_phases);
 
 /*
+ * Row-wise quantisation of fp32 rows for the quantised all-to-all of pooled embeddings (the reference's --bitwidth
+ * {2,4,8,16} / --quant-a2a-embedding-dim flags, train/comms/pt/comms_utils.py:1788-1806; downcast / restore around the
+ * exchange, pytorch_dist_backend.py:48-76 and the unpublished all_to_allv_internal at :273).  src: n_rows x dim fp32,
+ * row-major, dim a multiple of 8 in [8, 512].  Quantised row layouts (what torch's
+ * quantized::embedding_bag_{byte,4bit,2bit}_prepack produce, i.e. fbgemm's fused row-wise formats):
+ *   16: dim x fp16 (round to nearest even)                      2 * dim bytes
+ *    8: dim x u8, fp32 scale, fp32 bias                         dim + 8 bytes
+ *  4/2: dim * bits / 8 x u8 (low bits first), fp16 scale, bias  dim * bits / 8 + 4 bytes
+ * pm_rows_dequantize restores x = fma(code, scale, bias).  Rows are packed back to back; the fp32 buffer is 16-byte aligned,
+ * the quantised one aligned to the format's word (16 / 8 / 4 / 2 bytes for 16 / 8 / 4 / 2 bits: any whole number of rows into
+ * an aligned buffer qualifies, so per-peer chunks of an exchange buffer can be produced in place).
+ * pm_rows_quantized_bytes returns n_rows * row bytes (or a negative PM_ERR_* code).
+ */
+int64_t pm_rows_quantized_bytes(int64_t n_rows, int32_t dim, int32_t bitwidth);
+int pm_rows_quantize(const float* src, int64_t n_rows, int32_t dim, int32_t bitwidth, void* dst, pm_stream_t stream);
+int pm_rows_dequantize(const void* src, int64_t n_rows, int32_t dim, int32_t bitwidth, float* dst, pm_stream_t stream);
+
+/*
  * Stable LSD radix sort of (key, uint32 value) pairs by key bits [begin_bit, end_bit) -- the sort the sorted
  * backward runs on its (table,row) keys (replaces the sort inside aten::_embedding_bag_dense_backward /
  * fbgemm's TBE backward at the call sites of pm_embbag_bwd_sorted).  key_bytes: 4 or 8.  The pairs start in

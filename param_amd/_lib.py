@@ -32,6 +32,9 @@ EXPORTED_SYMBOLS = (
     "pm_embbag_sort_indices",
     "pm_embbag_sort_indices_ex",
     "pm_embbag_sort_plan",
+    "pm_rows_quantized_bytes",
+    "pm_rows_quantize",
+    "pm_rows_dequantize",
     "pm_embbag_bwd_sorted",
     "pm_embbag_bwd_sorted_adagrad",
     "pm_embbag_bwd_sorted_adagrad_ex",
@@ -129,6 +132,12 @@ def load() -> ctypes.CDLL:
         L.pm_embbag_sort_indices.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, vp, i64, vp]
         L.pm_embbag_sort_indices_ex.restype = ctypes.c_int
         L.pm_embbag_sort_indices_ex.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, i32, vp, i64, vp]
+        L.pm_rows_quantized_bytes.restype = i64
+        L.pm_rows_quantized_bytes.argtypes = [i64, i32, i32]
+        L.pm_rows_quantize.restype = ctypes.c_int
+        L.pm_rows_quantize.argtypes = [vp, i64, i32, i32, vp, vp]
+        L.pm_rows_dequantize.restype = ctypes.c_int
+        L.pm_rows_dequantize.argtypes = [vp, i64, i32, i32, vp, vp]
         L.pm_embbag_sort_plan.restype = ctypes.c_int
         L.pm_embbag_sort_plan.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, i32, ctypes.c_char_p, i32]
         L.pm_embbag_bwd_sorted.restype = ctypes.c_int

@@ -34,6 +34,8 @@ _DTYPES = {"float32": torch.float32, "float16": torch.float16, "bfloat16": torch
            "long": torch.long, "float64": torch.float64, "int8": torch.int8}
 
 HEADER_FMT = "{:>40}{:>18}{:>18}{:>12}{:>12}{:>12}{:>12}{:>15}{:>12}{:>18}"
+QUANT_HEADER_FMT = "-QUANT\t{:>40}{:>18}{:>25}{:>15}{:>15}{:>15}"
+QUANT_ROW_FMT = "\tCOMMS-RES-QUANT-{}-{}{}\t{:>15}{:>18}{:>25}{:>15}{:>15}{:>15}"
 ROW_FMT = "\tCOMMS-RES-{}-{}{}{:>18}{:>18}{:>18}{:>12}{:>12}{:>12}{:>12}{:>15}{:>12}{:>20}"
 
 
@@ -57,8 +59,9 @@ class commsParamsHolder:
         self.collective = collective
         self.numWarmupIters = args.w
         self.numIters = args.n
-        self.bitwidth = 32
-        self.quant_a2a_embedding_dim = 0
+        self.bitwidth = args.bitwidth
+        self.quant_a2a_embedding_dim = args.quant_a2a_embedding_dim
+        self.quant_threshold = max(args.e, args.quant_threshold)     # as the reference (comms_utils.py:885-887)
         self.init_only = False
         self.use_device_time = args.use_device_time
         self.include_0B = args.include_0B
@@ -71,6 +74,18 @@ def format_header() -> str:
     return "\n\tCOMMS-RES" + HEADER_FMT.format(
         "total-size (B)", "nElementsPerRank", "Time(us):p50", "p75", "p95", "Min", "Max", "AlgBW(GB/s)",
         "BusBW(GB/s)", "TotalTime(us):p50")
+
+
+def format_quant_header() -> str:
+    """the ``--bitwidth < 32`` preamble (comms.py:976-986); ``str.format`` drops the reference's surplus seventh title"""
+    return "\n\tCOMMS-RES" + QUANT_HEADER_FMT.format("size (B)", "nElementsPerRank", "P95 Latency(us): Quant", "Comms",
+                                                      "De-Quant", "Overall", "TotalLatency(us):p50")
+
+
+def format_quant_row(collective, data_type, tag, memSize, numElements, quant_p95, dequant_p95, p95):
+    """``reportBenchTimeCollWithQuant`` (comms.py:1005-1040): comms = overall p95 - quant p95 - de-quant p95"""
+    return QUANT_ROW_FMT.format(collective, data_type, tag, memSize, "%d" % numElements, "%.1f" % quant_p95,
+                                "%.1f" % (p95 - quant_p95 - dequant_p95), "%.1f" % dequant_p95, "%.1f" % p95)
 
 
 def format_row(collective, data_type, tag, memSize, numElements, p50, p75, p95, mn, mx, algBW, busBW, total_p50=0.0):
@@ -101,6 +116,11 @@ class commsCollBench:
         parser.add_argument("--sb", "--step-bytes", type=int, default=0, dest="sb")
         parser.add_argument("--z", "--blocking", type=int, default=1, dest="z")
         parser.add_argument("--c", "--check", type=int, default=0, dest="c")
+        parser.add_argument("--bitwidth", type=int, default=32, choices=[2, 4, 8, 16, 32], help="Quantization bitwidth")
+        parser.add_argument("--quant-a2a-embedding-dim", type=int, default=32, choices=[32, 64, 128, 256],
+                            help="Embedding dimension used by quantization alltoall if enabled")
+        parser.add_argument("--quant-threshold", type=int, default=33554432,
+                            help="threshold of message sizes to perform quantization if enabled")
         parser.add_argument("--collective", type=str, default="all_to_all")
         parser.add_argument("--data-types", "--dtype", type=str, default="float32", dest="data_types")
         parser.add_argument("--use-device-time", action="store_true", default=False)
@@ -130,6 +150,12 @@ class commsCollBench:
             raise ValueError(f"backend {args.backend} does not support device cpu")
         # --backend rccl_xgmi --device cpu: the plug-in moves host tensors over gloo (MI355XBackend._pg_backend), which is
         # how it runs under the reference's own comms.py on a box without GPUs (tests/golden/gen_ref_plugin_rows.py)
+        if args.bitwidth < 32:                                       # _check_bitwidth (comms.py:251-265)
+            if args.device == "cpu":
+                logger.error(f"collective quantization may not be fully supported for {args.device}")
+            for c in args.collectives:
+                for d in args.dtypes:
+                    comms_utils.checkQuantArgs(c, _DTYPES[d], args.b, args.quant_a2a_embedding_dim, args.z)
         if args.c == 1 and args.z == 0:
             logger.warning("data validation requires blocking mode: forcing --z 1")
             args.z = 1
@@ -193,6 +219,8 @@ class commsCollBench:
                 elapsed_ns = 0.0
                 if dev_timer:
                     dev_timer.reset()
+                ca.quant_time.reset()
+                ca.dequant_time.reset()
             if dcheck and ca.collective in ("all_reduce", "reduce"):
                 ca.ipTensor.fill_(self.initVal)  # in-place reductions: reset before every iteration (comms.py:474-476)
             if is_blocking:
@@ -253,6 +281,19 @@ class commsCollBench:
         self.results.append(rec)
         return rec
 
+    def reportBenchTimeCollWithQuant(self, commsParams, results, lat, quant_lat, dequant_lat):
+        ca = self.collectiveArgs
+        p95, quant_p95, dequant_p95 = (float(np.percentile(a, 95)) for a in (lat, quant_lat, dequant_lat))
+        rec = {"collective": ca.collective, "dtype": ca.data_type, "memSize": results["memSize"],
+               "numElements": results["numElements"], "bitwidth": commsParams.bitwidth, "quant_p95_us": quant_p95,
+               "comms_p95_us": p95 - quant_p95 - dequant_p95, "dequant_p95_us": dequant_p95, "p95_us": p95,
+               "world_size": ca.world_size}
+        if ca.global_rank == 0:
+            print(format_quant_row(ca.collective, ca.data_type, self.tag, results["memSize"], results["numElements"],
+                                   quant_p95, dequant_p95, p95))
+        self.results.append(rec)
+        return rec
+
     def benchComm(self, commsParams):
         ca, bf = self.collectiveArgs, self.backendFuncs
         ca.collective = commsParams.collective
@@ -263,8 +304,10 @@ class commsCollBench:
         ca.comm_dev_time = paramDeviceTimer("comm_timer", bf) if (commsParams.use_device_time and ca.device.type == "cuda") else None
         comm_fn = bf.collectiveFunc[commsParams.collective]
         comms_utils.fixBeginSize(commsParams, ca.world_size)
+        if commsParams.bitwidth < 32:
+            comms_utils.initQuantCommCtx(ca, commsParams)
         if ca.global_rank == 0:
-            print(format_header())
+            print(format_quant_header() if commsParams.bitwidth < 32 else format_header())
         for curSize in comms_utils.getSizes(commsParams.beginSize, commsParams.endSize, commsParams.stepFactor,
                                             commsParams.stepBytes):
             numElements = self.prepComm(commsParams, curSize)
@@ -274,8 +317,14 @@ class commsCollBench:
             if commsParams.dcheck == 1:
                 self.dcheck(commsParams, curSize)
             lat = self.gatherBenchTime(results["timeUS"])
-            self.reportBenchTimeColl(commsParams, results, lat)
+            if commsParams.bitwidth < 32:                    # average (de-)quantisation overhead per iteration (comms.py:1387-1396)
+                qlat = self.gatherBenchTime(ca.quant_time.getTimeUS() / ca.numIters)
+                dlat = self.gatherBenchTime(ca.dequant_time.getTimeUS() / ca.numIters)
+                self.reportBenchTimeCollWithQuant(commsParams, results, lat, qlat, dlat)
+            else:
+                self.reportBenchTimeColl(commsParams, results, lat)
             bf.clear_memory(ca)
+        comms_utils.clearQuantCommCtx(ca)
 
     # ------------------------------------------------------------------ whole run
     def initBackend(self, bootstrap_info, args):

@@ -16,7 +16,7 @@ barrier / collective / wait-all / barrier with ``global_latency = latency + trai
 launched ``count`` times on a separate HIP stream ``runCompute :723-754`` with ``--reuse-tensors`` caching the tables
 and requests per entry shape ``prepComputeReplay :853-932``; per-operation records + latency tables
 ``recordCommReplay :934-972``, ``reportBenchTime :311-446``; ``replayedCommsPerf.rank<r>.json`` ``:43-86``.
-Left out: remote (http / internal) trace stores, the kineto profiler hooks, quantised collectives, process-group
+Left out: remote (http / internal) trace stores, the kineto profiler hooks, process-group
 creation from ``init`` entries (entries naming a ``pg_id`` other than the default group are skipped with a warning),
 point-to-point ops, and the ``et`` / ``kineto`` trace formats (commsTraceParser.py).
 """
@@ -70,12 +70,17 @@ class replayParamsHolder:
         self.dcheck = 0
         self.blockingFlag = 1
         self.bitwidth = 32
+        self.quant_a2a_embedding_dim = 32
+        self.quant_threshold = 33554432
         self.size_from_trace = True
         if args is not None:
             self.device = "cuda" if args.device == "rocm" else args.device
             self.backend = args.backend
             self.dcheck = args.c
             self.blockingFlag = args.z
+            self.bitwidth = getattr(args, "bitwidth", 32)
+            self.quant_a2a_embedding_dim = getattr(args, "quant_a2a_embedding_dim", 32)
+            self.quant_threshold = getattr(args, "quant_threshold", 33554432)
 
 
 class _StatDict(dict):
@@ -139,6 +144,10 @@ class commsTraceReplayBench:
         parser.add_argument("--z", "--blocking", type=int, default=0, dest="z", help="1: barrier + wait around every collective")
         parser.add_argument("--c", "--check", type=int, default=0, dest="c")
         parser.add_argument("--log", type=str, default="ERROR")
+        parser.add_argument("--bitwidth", type=int, default=32, choices=[2, 4, 8, 16, 32], help="Quantization bitwidth")
+        parser.add_argument("--quant-a2a-embedding-dim", type=int, default=32, choices=[32, 64, 128, 256])
+        parser.add_argument("--quant-threshold", type=int, default=33554432,
+                            help="quantise collectives of at least this many elements")
         parser.add_argument("--trace-path", type=str, default="./",
                             help="trace file, or a directory holding <rank>.json per rank")
         parser.add_argument("--trace-type", type=str, default="basic", help=f"supported: {VALID_TRACE_TYPES}")
@@ -374,6 +383,8 @@ class commsTraceReplayBench:
 
     def runComms(self, collName: str, curComm: commsArgs, curBlockStack: str):
         ca, bf = self.collectiveArgs, self.backendFuncs
+        ca.quant_time.reset()          # per replayed collective (reference commsTraceReplay.py:769-770)
+        ca.dequant_time.reset()
         timer = paramTimer()
         if self.is_blocking:
             bf.sync_barrier(ca)
@@ -427,8 +438,8 @@ class commsTraceReplayBench:
         rec = curComm.toDict()
         rec["dtype_size"] = torch.tensor([], dtype=self.dtypeMap[curComm.dtype]).element_size() if curComm.dtype in self.dtypeMap else 0
         rec["marker_stack"] = curBlockStack
-        rec["quant_us"] = 0.0
-        rec["dequant_us"] = 0.0
+        rec["quant_us"] = self.collectiveArgs.quant_time.getTimeUS()        # (reference :952-953)
+        rec["dequant_us"] = self.collectiveArgs.dequant_time.getTimeUS()
         rec["latency_us"] = latency
         rec["global_latency_us"] = global_latency
         if curComm.compute is not None:
@@ -510,6 +521,9 @@ class commsTraceReplayBench:
         ca.op = bf.get_reduce_op("sum")
         ca.asyncOp = not self.is_blocking
         ca.ipTensor = ca.opTensor = None
+        ca.quant_threshold = getattr(commsParams, "quant_threshold", 0)      # (reference :1382)
+        if getattr(commsParams, "bitwidth", 32) < 32:                        # (reference :1424-1425)
+            comms_utils.initQuantCommCtx(ca, commsParams)
         if self.allowList in ("all", "default", "*"):
             self.allowList = list(bf.collectiveFunc.keys())
         elif isinstance(self.allowList, str):

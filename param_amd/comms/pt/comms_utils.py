@@ -89,6 +89,42 @@ def fixBeginSize(commsParams, world_size: int) -> None:
             commsParams.beginSize = commsParams.element_size
 
 
+def checkQuantArgs(collective: str, dtype, beginSize: int, quant_a2a_embedding_dim: int, blockingFlag) -> None:
+    """What the reference refuses for ``--bitwidth < 32`` (comms_utils.py:395-429): only the all_to_all family, reduce and
+    all_reduce; float32 payloads; a quantised all_to_all must be blocking; a begin size that is not a whole number of
+    rows only warns."""
+    import torch
+
+    if "all_to_all" not in collective and collective not in ("reduce", "all_reduce"):
+        raise NotImplementedError(f"quantized communication for {collective} is currently unsupported.")
+    if "all_to_all" in collective:
+        if (beginSize // 4) % quant_a2a_embedding_dim != 0:
+            logger.warning(f"begin size {beginSize} must be a multiple of --quant-a2a-embedding-dim "
+                           f"{quant_a2a_embedding_dim} for all_to_all operation")
+        if blockingFlag != 1:
+            raise NotImplementedError("quantized All_to_all must be synchronous.")
+    if dtype != torch.float32:
+        raise NotImplementedError(f"quantization for {dtype} is not supported. Use float32 instead.")
+
+
+def initQuantCommCtx(collectiveArgs, commsParams) -> None:
+    """Arm the quantised collectives of the backend (reference comms_utils.py:371-391, where the handlers come from an
+    unpublished package and the open-source build resets ``bitwidth`` to 32): the all_to_all family exchanges row-wise
+    quantised payloads (``param_amd.quant``: fp16 / fused 8-, 4-, 2-bit rows of ``quant_a2a_embedding_dim`` values),
+    all_reduce / reduce downcast as the reference's ``_downcast`` does (pytorch_dist_backend.py:48-54)."""
+    logger.info(f"communication bitwidth set to {commsParams.bitwidth}")
+    collectiveArgs.all2all_qcomm = commsParams.bitwidth
+    collectiveArgs.allreduce_qcomm = commsParams.bitwidth
+    collectiveArgs.reduce_qcomm = commsParams.bitwidth
+    collectiveArgs.quant_a2a_embedding_dim = commsParams.quant_a2a_embedding_dim
+
+
+def clearQuantCommCtx(collectiveArgs) -> None:
+    collectiveArgs.all2all_qcomm = None
+    collectiveArgs.allreduce_qcomm = 32
+    collectiveArgs.reduce_qcomm = 32
+
+
 def env2int(env_list, default: int = -1) -> int:
     for e in env_list:
         val = int(os.environ.get(e, -1))
@@ -136,6 +172,9 @@ class paramTimer:
 
     def stop(self) -> None:
         self.elapsedTimeNS += time.monotonic_ns() - self._t0
+
+    def incrTimeNS(self, timeNS: float) -> None:
+        self.elapsedTimeNS += timeNS
 
     def getTimeUS(self) -> float:
         return self.elapsedTimeNS / 1e3

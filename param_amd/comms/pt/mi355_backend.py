@@ -88,6 +88,130 @@ class MI355XBackend(backendFunctions):
             return collectiveArgs.ipTensor_pair[pairIdx], collectiveArgs.opTensor_pair[pairIdx]
         return collectiveArgs.ipTensor, collectiveArgs.opTensor
 
+    # ------------------------------------------------------------------ quantised payloads (--bitwidth < 32)
+    def _timed(self, timer, fn):
+        """run ``fn`` under the reference's quant / de-quant timers (``paramProfile(timer=...)``,
+        pytorch_dist_backend.py:124-130): host clock, closed by a device sync on the GPU so that the report's
+        quant / comms / de-quant split (comms.py:1028-1036) is one of device work, not of launch times"""
+        import time
+
+        t0 = time.monotonic_ns()
+        out = fn()
+        self.device_sync()
+        if timer is not None and hasattr(timer, "incrTimeNS"):
+            timer.incrTimeNS(float(time.monotonic_ns() - t0))
+        return out
+
+    @staticmethod
+    def _host_quant_ops(bits):
+        q = torch.ops.quantized
+        return {8: (q.embedding_bag_byte_prepack, q.embedding_bag_byte_unpack),
+                4: (q.embedding_bag_4bit_prepack, q.embedding_bag_4bit_unpack),
+                2: (q.embedding_bag_2bit_prepack, q.embedding_bag_2bit_unpack)}[bits]
+
+    def _quantize_rows(self, t, dim, bits, out=None):
+        """fp32 -> quantised rows, flat uint8.  GPU tensors: the HIP kernels (no fallback).  Host tensors (``--device cpu``,
+        the gloo mode the plug-in is tested in without GPUs): torch's own CPU operators for the same formats."""
+        if t.is_cuda:
+            from ... import quant
+            return quant.quantize_rows(t, dim, bits, out=out).view(-1)
+        q = (t.reshape(-1).to(torch.float16).view(torch.uint8) if bits == 16
+             else self._host_quant_ops(bits)[0](t.reshape(-1, dim)).reshape(-1))
+        if out is not None:
+            out.view(-1).copy_(q)
+            return out.view(-1)
+        return q
+
+    def _dequantize_rows(self, q, dim, bits, out):
+        if q.is_cuda:
+            from ... import quant
+            quant.dequantize_rows(q, dim, bits, out=out)
+            return out
+        from ...quant import host_row_bytes
+        d = (q.view(torch.float16).to(torch.float32) if bits == 16
+             else self._host_quant_ops(bits)[1](q.view(-1, host_row_bytes(dim, bits))))
+        out.view(-1).copy_(d.reshape(-1))
+        return out
+
+    def _wants_quant_a2a(self, collectiveArgs, ip, op, pair) -> bool:
+        """the reference's test (pytorch_dist_backend.py:262-272): armed, float32, at or above the threshold, not pair mode"""
+        bits = getattr(collectiveArgs, "all2all_qcomm", None)
+        if not bits or int(bits) >= 32 or pair:
+            return False
+        ips = ip if isinstance(ip, (list, tuple)) else [ip]
+        ops = op if isinstance(op, (list, tuple)) else [op]
+        if any(t.dtype != torch.float32 for t in ips):
+            return False
+        thr = getattr(collectiveArgs, "quant_threshold", 0)
+        return sum(t.numel() for t in ops) >= thr or sum(t.numel() for t in ips) >= thr
+
+    def _quantized_all_to_all(self, collectiveArgs, ip, op, isp, osp, retFlag):
+        """Row-wise quantised exchange: quantise every peer's chunk in place of the send buffer, ONE byte all-to-all,
+        restore into the caller's output.  Chunks are whole rows of ``quant_a2a_embedding_dim`` values (pooled
+        embeddings); blocking, as the reference requires (comms_utils.py:424-425)."""
+        from ...quant import host_row_bytes
+        bits, dim = int(collectiveArgs.all2all_qcomm), int(collectiveArgs.quant_a2a_embedding_dim)
+        group = self._group(collectiveArgs)
+        world = dist.get_world_size(group)
+        in_list = list(ip) if isinstance(ip, (list, tuple)) else None
+        out_list = list(op) if isinstance(op, (list, tuple)) else None
+        isp = [t.numel() for t in in_list] if in_list is not None else (list(isp) if isp is not None and len(isp) else [ip.numel() // world] * world)
+        osp = [t.numel() for t in out_list] if out_list is not None else (list(osp) if osp is not None and len(osp) else [op.numel() // world] * world)
+        if any(n % dim for n in isp + osp):
+            raise ValueError(f"quantized all_to_all: every per-peer chunk must be a whole number of rows of "
+                             f"--quant-a2a-embedding-dim {dim} elements (chunks {isp} / {osp})")
+        rb = host_row_bytes(dim, bits)
+        qi = [n // dim * rb for n in isp]
+        qo = [n // dim * rb for n in osp]
+        dev = (in_list[0] if in_list is not None else ip).device
+        q_in = torch.empty(sum(qi), dtype=torch.uint8, device=dev)
+        q_out = torch.empty(sum(qo), dtype=torch.uint8, device=dev)
+
+        def quantise():
+            if in_list is None:
+                self._quantize_rows(ip.reshape(-1)[:sum(isp)], dim, bits, out=q_in)
+            else:
+                o = 0
+                for t, nb in zip(in_list, qi):
+                    if nb:
+                        self._quantize_rows(t.contiguous(), dim, bits, out=q_in[o:o + nb])
+                    o += nb
+        self._timed(getattr(collectiveArgs, "quant_time", None), quantise)
+        dist.all_to_all_single(q_out, q_in, qo, qi, group=group)
+        self.device_sync()
+
+        def restore():
+            if out_list is None:
+                self._dequantize_rows(q_out, dim, bits, op.reshape(-1)[:sum(osp)])
+            else:
+                o = 0
+                for t, nb in zip(out_list, qo):
+                    if nb:
+                        self._dequantize_rows(q_out[o:o + nb], dim, bits, t)
+                    o += nb
+        self._timed(getattr(collectiveArgs, "dequant_time", None), restore)
+        return None
+
+    def _downcast_reduce(self, collectiveArgs, ip, bits, issue, retFlag):
+        """reference all_reduce / reduce with ``--bitwidth`` (pytorch_dist_backend.py:107-206): the collective runs on a
+        downcast COPY (fp16 for 16 bits, int8 for 8: ``_downcast``, :48-54) and the restored tensor is the returned /
+        waited object -- ``ipTensor`` keeps its values, the result is for benchmarking only, as the reference notes"""
+        if bits == 16:
+            cast = torch.float16
+        elif bits == 8:
+            cast = torch.int8
+        else:
+            raise NotImplementedError("Unsupported bitwidth. Set --bitwidth to 8/16/32")
+        quantized = self._timed(getattr(collectiveArgs, "quant_time", None), lambda: ip.to(cast))
+        work = issue(quantized)
+        if collectiveArgs.asyncOp and work is not None:
+            ret = work.get_future().then(lambda fut: fut.value()[0].to(torch.float32))
+        else:
+            ret = self._timed(getattr(collectiveArgs, "dequant_time", None), lambda: quantized.to(torch.float32))
+        if collectiveArgs.asyncOp:
+            collectiveArgs.waitObj.append(ret)
+        return ret if retFlag else None
+
     def sayHello(self, *_ignored):
         """Where each process runs.  The reference drivers call it with no arguments (comms.py:1533, dlrm.py:1350,
         commsTraceReplay.py:1331; implementation pytorch_dist_backend.py:85-99: every rank posts its line to the
@@ -110,12 +234,22 @@ class MI355XBackend(backendFunctions):
     # ------------------------------------------------------------------ collectives
     def all_reduce(self, collectiveArgs, retFlag=False, pair=False, pairIdx=0):
         ip, _ = self._io(collectiveArgs, pair, pairIdx)
+        bits = getattr(collectiveArgs, "allreduce_qcomm", 32)
+        if bits != 32 and bits > 4 and ip.dtype == torch.float32 and not pair:      # the reference's test (:109-114)
+            return self._downcast_reduce(collectiveArgs, ip, bits, lambda q: dist.all_reduce(
+                q, op=collectiveArgs.op or dist.ReduceOp.SUM, group=self._group(collectiveArgs),
+                async_op=bool(collectiveArgs.asyncOp)), retFlag)
         work = dist.all_reduce(ip, op=collectiveArgs.op or dist.ReduceOp.SUM,
                                group=self._group(collectiveArgs), async_op=bool(collectiveArgs.asyncOp))
         return self._post(collectiveArgs, work, retFlag)
 
     def reduce(self, collectiveArgs, retFlag=False, pair=False, pairIdx=0):
         ip, _ = self._io(collectiveArgs, pair, pairIdx)
+        if getattr(collectiveArgs, "reduce_qcomm", 32) != 32 and not pair:                 # (:166-177)
+            assert ip.dtype == torch.float32
+            return self._downcast_reduce(collectiveArgs, ip, getattr(collectiveArgs, "allreduce_qcomm", 32), lambda q: dist.reduce(
+                q, dst=collectiveArgs.srcOrDst, op=collectiveArgs.op or dist.ReduceOp.SUM,
+                group=self._group(collectiveArgs), async_op=bool(collectiveArgs.asyncOp)), retFlag)
         work = dist.reduce(ip, dst=collectiveArgs.srcOrDst,
                            op=collectiveArgs.op or dist.ReduceOp.SUM, group=self._group(collectiveArgs),
                            async_op=bool(collectiveArgs.asyncOp))
@@ -130,6 +264,8 @@ class MI355XBackend(backendFunctions):
         if (not pair and collectiveArgs.num_emb_tables_batched > 0 and collectiveArgs.emb is not None
                 and (self.use_ext_dist or self.fused_lookup_a2a)):
             return self.lookup_all_to_all(collectiveArgs, retFlag)
+        if self._wants_quant_a2a(collectiveArgs, ip, op, pair):
+            return self._quantized_all_to_all(collectiveArgs, ip, op, None, None, retFlag)
         if isinstance(op, (list, tuple)):
             if dist.get_backend(self._group(collectiveArgs)) == "gloo":
                 # gloo has no list-form alltoall (reference survey probe): flatten to the single-tensor form
@@ -154,12 +290,17 @@ class MI355XBackend(backendFunctions):
             osp, isp = collectiveArgs.opTensor_split_pair[pairIdx], collectiveArgs.ipTensor_split_pair[pairIdx]
         else:
             osp, isp = collectiveArgs.opTensor_split, collectiveArgs.ipTensor_split
+        if self._wants_quant_a2a(collectiveArgs, ip, op, pair):
+            return self._quantized_all_to_all(collectiveArgs, ip, op, isp, osp, retFlag)
         work = dist.all_to_all_single(
             op, ip, list(osp) if osp is not None and len(osp) else None, list(isp) if isp is not None and len(isp) else None,
             group=self._group(collectiveArgs), async_op=bool(collectiveArgs.asyncOp))
         return self._post(collectiveArgs, work, retFlag)
 
     def all_to_all_single(self, collectiveArgs, retFlag=False, pair=False, pairIdx=0):
+        if getattr(collectiveArgs, "all2all_qcomm", None) and int(collectiveArgs.all2all_qcomm) < 32:
+            logger.warning("all_to_all_single does not support quantization")     # and does nothing (:325-329)
+            return None
         return self.all_to_allv(collectiveArgs, retFlag, pair, pairIdx)
 
     # The rest of the reference ABC's collective table (pytorch_backend_utils.py:161-180).  Only the all-to-all family is

@@ -12,6 +12,8 @@ from __future__ import annotations
 import logging
 from abc import ABC, abstractmethod
 
+from .comms_utils import paramTimer as _paramTimer
+
 logger = logging.getLogger(__name__)
 
 supportedDevices = ["cpu", "cuda", "rocm"]
@@ -64,6 +66,15 @@ class collectiveArgsHolder:
         self.waitObj = []
         self.waitObjIds = {}
         self.op = None
+        # quantised collectives (reference pytorch_backend_utils.py:132-139; set by comms_utils.initQuantCommCtx)
+        self.all2all_qcomm = None
+        self.reducescatter_allgather_qcomm = None
+        self.allreduce_qcomm = 32
+        self.reduce_qcomm = 32
+        self.quant_threshold = 0
+        self.quant_a2a_embedding_dim = 32
+        self.quant_time = _paramTimer()
+        self.dequant_time = _paramTimer()
         self.compute_stream = None
         self.use_ext_dist = False
         self.include_0B = False

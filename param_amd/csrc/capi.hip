@@ -220,6 +220,45 @@ int pm_radix_sort_pairs(void* keys_a, void* keys_b, uint32_t* vals_a, uint32_t* 
     return PM_OK;
 }
 
+static int rowquant_args_ok(int64_t n_rows, int32_t dim, int32_t bitwidth) {
+    if (n_rows < 0) return fail(PM_ERR_INVALID, "n_rows is negative");
+    if (bitwidth != 16 && bitwidth != 8 && bitwidth != 4 && bitwidth != 2) return fail(PM_ERR_INVALID, "bitwidth must be 16, 8, 4 or 2");
+    if (dim < 8 || dim % 8 != 0 || dim > 512) return fail(PM_ERR_UNSUPPORTED, "dim must be a multiple of 8 in [8, 512]");
+    return PM_OK;
+}
+
+static uintptr_t rowquant_align(int32_t bitwidth) { return bitwidth == 16 ? 16 : static_cast<uintptr_t>(bitwidth); }
+
+int64_t pm_rows_quantized_bytes(int64_t n_rows, int32_t dim, int32_t bitwidth) {
+    const int rc = rowquant_args_ok(n_rows, dim, bitwidth);
+    if (rc != PM_OK) return rc;
+    return n_rows * pm::rows_quantized_row_bytes(dim, bitwidth);
+}
+
+int pm_rows_quantize(const float* src, int64_t n_rows, int32_t dim, int32_t bitwidth, void* dst, pm_stream_t stream) {
+    const int rc = rowquant_args_ok(n_rows, dim, bitwidth);
+    if (rc != PM_OK) return rc;
+    if (n_rows == 0) return PM_OK;
+    if (!src || !dst) return fail(PM_ERR_INVALID, "src / dst is NULL");
+    if (reinterpret_cast<uintptr_t>(src) % 16 != 0 || reinterpret_cast<uintptr_t>(dst) % rowquant_align(bitwidth) != 0)
+        return fail(PM_ERR_INVALID, "src must be 16-byte aligned, dst aligned to the format's word (16 / 8 / 4 / 2 bytes for 16 / 8 / 4 / 2 bits)");
+    const hipError_t h = pm::launch_rows_quantize(src, n_rows, dim, bitwidth, dst, static_cast<hipStream_t>(stream));
+    if (h != hipSuccess) return hip_fail(h, "pm_rows_quantize launch");
+    return PM_OK;
+}
+
+int pm_rows_dequantize(const void* src, int64_t n_rows, int32_t dim, int32_t bitwidth, float* dst, pm_stream_t stream) {
+    const int rc = rowquant_args_ok(n_rows, dim, bitwidth);
+    if (rc != PM_OK) return rc;
+    if (n_rows == 0) return PM_OK;
+    if (!src || !dst) return fail(PM_ERR_INVALID, "src / dst is NULL");
+    if (reinterpret_cast<uintptr_t>(dst) % 16 != 0 || reinterpret_cast<uintptr_t>(src) % rowquant_align(bitwidth) != 0)
+        return fail(PM_ERR_INVALID, "dst must be 16-byte aligned, src aligned to the format's word (16 / 8 / 4 / 2 bytes for 16 / 8 / 4 / 2 bits)");
+    const hipError_t h = pm::launch_rows_dequantize(src, n_rows, dim, bitwidth, dst, static_cast<hipStream_t>(stream));
+    if (h != hipSuccess) return hip_fail(h, "pm_rows_dequantize launch");
+    return PM_OK;
+}
+
 int pm_embbag_fwd(const pm_embbag_batch* op, float* out, pm_stream_t stream) {
     pm::KParams p;
     int rc = make_params(op, op ? op->weight_dtype : -1, p);

@@ -145,6 +145,10 @@ template <typename K>
 hipError_t rs_sort_pairs(K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n_max, const uint32_t* d_count,
                          int begin_bit, int end_bit, void* scratch, hipStream_t stream, size_t seg_len = 0);
 
+// rowquant.hip: row-wise quantisation of fp32 rows (bits 16 / 8 / 4 / 2), dim a multiple of 8
+int64_t rows_quantized_row_bytes(int dim, int bits);
+hipError_t launch_rows_quantize(const float* src, int64_t n_rows, int dim, int bits, void* dst, hipStream_t stream);
+hipError_t launch_rows_dequantize(const void* src, int64_t n_rows, int dim, int bits, float* dst, hipStream_t stream);
 void set_backward_tuning(int sort_impl, int order, int xcd, int max_phases);   // -1 = default (environment)
 
 // DLRM input redistribution (dlrm_regroup.hip)

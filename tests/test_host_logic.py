@@ -209,3 +209,56 @@ def test_compute_python_stream_equals_reference_registry_run(golden_dir):
                              "indices_len": int(idx.numel()), "offsets_len": int(off.numel()), "indices_sum": int(idx.sum()),
                              "offsets_last": int(off[-1]), "psw": psw is not None})
     assert len(mine) == 8 and mine == fx["stream"]
+
+
+def test_quantised_sweep_host_logic_equals_the_reference(golden_dir):
+    """``--bitwidth < 32``: flag checks, begin-size fix-up, header / row text and the open downcast, against outputs of the
+    reference's own functions (tests/golden/quant_rows.json, made by gen_quant_rows.py running the reference here)"""
+    from param_amd.comms.pt import comms, comms_utils
+    from param_amd.comms.pt.mi355_backend import MI355XBackend
+    from param_amd.comms.pt.pytorch_backend_utils import collectiveArgsHolder
+
+    gold = json.load(open(os.path.join(golden_dir, "quant_rows.json")))
+    for (coll, dtype, begin, dim, z), want in gold["checkQuantArgs"]:
+        try:
+            comms_utils.checkQuantArgs(coll, getattr(torch, dtype), begin, dim, z)
+            got = None
+        except Exception as e:      # noqa: BLE001
+            got = [type(e).__name__, str(e)]
+        assert got == want, (coll, dtype, z)
+    for (coll, begin, esz, world, bw, dim), want in gold["fixBeginSize"]:
+        p = types.SimpleNamespace(collective=coll, beginSize=begin, element_size=esz, bitwidth=bw, quant_a2a_embedding_dim=dim)
+        comms_utils.fixBeginSize(p, world)
+        assert p.beginSize == want
+    assert comms.format_quant_header() + "\n" == gold["preamble_stdout"]
+    for r in gold["quant_rows"]:
+        q95, d95, p95 = (float(np.percentile(r[k], 95)) for k in ("quant", "dequant", "lat"))
+        assert comms.format_quant_row("all_to_allv", "float32", "", r["memSize"], r["numElements"], q95, d95, p95) + "\n" == r["row"]
+    # arming / disarming the collectives
+    ca = collectiveArgsHolder()
+    assert ca.all2all_qcomm is None and ca.allreduce_qcomm == 32 and ca.quant_threshold == 0
+    comms_utils.initQuantCommCtx(ca, types.SimpleNamespace(bitwidth=8, quant_a2a_embedding_dim=64))
+    assert (ca.all2all_qcomm, ca.allreduce_qcomm, ca.reduce_qcomm, ca.quant_a2a_embedding_dim) == (8, 8, 8, 64)
+    comms_utils.clearQuantCommCtx(ca)
+    assert ca.all2all_qcomm is None and ca.allreduce_qcomm == 32
+    # the reduce-family downcast is the reference's _downcast (fp16 / int8; nothing below 8 bits)
+    bf = MI355XBackend(types.SimpleNamespace(master_ip="127.0.0.1"), types.SimpleNamespace(device="cpu"))
+    x = torch.tensor(gold["downcast"]["x"])
+    ca = collectiveArgsHolder()
+    ca.asyncOp = False
+    for bits in (16, 8):
+        got = bf._downcast_reduce(ca, x, bits, lambda q: None, True)
+        assert got.tolist() == gold["downcast"][str(bits)] and got.dtype == torch.float32
+    with pytest.raises(NotImplementedError, match=gold["downcast"]["4"].split(".")[0]):
+        bf._downcast_reduce(ca, x, 4, lambda q: None, True)
+    assert ca.quant_time.getTimeUS() > 0 and ca.dequant_time.getTimeUS() > 0
+    # CLI: the reference's three flags with its choices and defaults (comms_utils.py:1788-1806)
+    import argparse
+    import sys
+    old = sys.argv
+    sys.argv = ["comms.py", "--bitwidth", "8", "--quant-a2a-embedding-dim", "128"]
+    try:
+        a = comms.commsCollBench().readArgs(argparse.ArgumentParser())
+    finally:
+        sys.argv = old
+    assert (a.bitwidth, a.quant_a2a_embedding_dim, a.quant_threshold) == (8, 128, 33554432)
