@@ -241,6 +241,10 @@ int pm_dlrm_regroup(const int64_t* lengths, const int64_t* indices, int32_t worl
  * forward/backward kernels themselves do not check.
  */
 int pm_embbag_check(const pm_embbag_batch* op, int32_t* d_error_count, pm_stream_t stream);
+/* The same with extra requirements.  PM_CHECK_UNIFORM_DIMS: every table has dims[t] == max_dim and out_offsets[t] is a
+ * multiple of max_dim -- what pm_embbag_fwd_quantized assumes. */
+enum { PM_CHECK_UNIFORM_DIMS = 1 };
+int pm_embbag_check_ex(const pm_embbag_batch* op, int32_t flags, int32_t* d_error_count, pm_stream_t stream);
 
 /*
  * Fill a buffer with counter-based pseudo-random values at HBM write speed:
@@ -286,6 +290,20 @@ int pm_set_forward_tuning(int32_t stage_out);
  * Settings are read when a request is SORTED; its apply follows what the sort recorded.
  */
 int pm_set_backward_tuning(int32_t sort_impl, int32_t order, int32_t xcd_affine, int32_t max_phases);
+
+/*
+ * Forward with a row-wise QUANTISED output: the pooled vector of (bag b, table t) is written as one quantised row
+ * (formats below, bitwidth 16 / 8 / 4 / 2) instead of max_dim floats -- what a quantised all-to-all of pooled embeddings
+ * sends (--bitwidth of the reference's comms drivers), produced inside the lookup kernel's output burst so the fp32
+ * pooled output never reaches HBM.  Same request as pm_embbag_fwd; the output keeps the fp32 layout with one row per
+ * pooled vector: row index b * (out_stride / max_dim) + out_offsets[t] / max_dim, rows packed back to back
+ * (pm_rows_quantized_bytes(rows, max_dim, bitwidth) bytes in all; pm_rows_dequantize restores them).  Contract: every
+ * table has dims[t] == max_dim (a multiple of 8, <= 512) and out_offsets[t], out_stride are multiples of max_dim
+ * (pm_embbag_check_ex(PM_CHECK_UNIFORM_DIMS) verifies the device arrays).  Served by the staged forward only: requests it
+ * does not take (ragged bags, staging disabled) get PM_ERR_UNSUPPORTED -- run pm_embbag_fwd + pm_rows_quantize then.
+ * Values equal pm_rows_quantize(pm_embbag_fwd(...)) bit for bit.
+ */
+int pm_embbag_fwd_quantized(const pm_embbag_batch* op, void* out, int32_t bitwidth, pm_stream_t stream);
 
 /*
  * Row-wise quantisation of fp32 rows for the quantised all-to-all of pooled embeddings (the reference's --bitwidth

@@ -32,6 +32,8 @@ EXPORTED_SYMBOLS = (
     "pm_embbag_sort_indices",
     "pm_embbag_sort_indices_ex",
     "pm_embbag_sort_plan",
+    "pm_embbag_fwd_quantized",
+    "pm_embbag_check_ex",
     "pm_rows_quantized_bytes",
     "pm_rows_quantize",
     "pm_rows_dequantize",
@@ -132,6 +134,10 @@ def load() -> ctypes.CDLL:
         L.pm_embbag_sort_indices.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, vp, i64, vp]
         L.pm_embbag_sort_indices_ex.restype = ctypes.c_int
         L.pm_embbag_sort_indices_ex.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, i32, vp, i64, vp]
+        L.pm_embbag_fwd_quantized.restype = ctypes.c_int
+        L.pm_embbag_fwd_quantized.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, i32, vp]
+        L.pm_embbag_check_ex.restype = ctypes.c_int
+        L.pm_embbag_check_ex.argtypes = [ctypes.POINTER(pm_embbag_batch), i32, vp, vp]
         L.pm_rows_quantized_bytes.restype = i64
         L.pm_rows_quantized_bytes.argtypes = [i64, i32, i32]
         L.pm_rows_quantize.restype = ctypes.c_int

@@ -117,6 +117,7 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p) {
     // so only for requests whose lookups divide evenly over the bags (fixed pooling: every benchmark shape), whose index
     // tile can then be sized for what a tile really holds instead of the 4096-entry default, and only where the staging
     // buffer fits 16 KB (the tile is halved until it does).  pm_set_forward_tuning(0) / PARAM_AMD_FWD_STAGE=0 turn it off.
+    p.out_bits = 0;
     p.stage_out = 0;
     {
         int want = g_stage_out.load();
@@ -270,6 +271,27 @@ int pm_embbag_fwd(const pm_embbag_batch* op, float* out, pm_stream_t stream) {
     if (unroll == 0) unroll = 4;  // sweep r1a: 4 rows in flight/lane at 8 waves/SIMD beats 8 at 5 waves
     hipError_t h = pm::launch_embbag_fwd(p, op->weight_dtype, op->max_dim, unroll, static_cast<hipStream_t>(stream));
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_fwd launch");
+    return PM_OK;
+}
+
+int pm_embbag_fwd_quantized(const pm_embbag_batch* op, void* out, int32_t bitwidth, pm_stream_t stream) {
+    pm::KParams p;
+    int rc = make_params(op, op ? op->weight_dtype : -1, p);
+    if (rc != PM_OK) return rc;
+    if ((rc = rowquant_args_ok(0, op->max_dim, bitwidth)) != PM_OK) return rc;
+    if (op->out_stride % op->max_dim != 0) return fail(PM_ERR_INVALID, "out_stride must be a whole number of max_dim-element rows");
+    if (p.bag_count == 0) return PM_OK;
+    if (!out) return fail(PM_ERR_INVALID, "out is NULL");
+    if (reinterpret_cast<uintptr_t>(out) % 16 != 0) return fail(PM_ERR_INVALID, "out must be 16-byte aligned");
+    if (!p.stage_out)
+        return fail(PM_ERR_UNSUPPORTED, "quantised output needs the staged forward (fixed-pooling requests whose tile fits the staging "
+                                        "buffer, staging not disabled): run pm_embbag_fwd and pm_rows_quantize instead");
+    p.io = static_cast<float*>(out);
+    p.out_bits = bitwidth;
+    int unroll = g_unroll.load();
+    if (unroll == 0) unroll = 4;
+    hipError_t h = pm::launch_embbag_fwd(p, op->weight_dtype, op->max_dim, unroll, static_cast<hipStream_t>(stream));
+    if (h != hipSuccess) return hip_fail(h, "pm_embbag_fwd_quantized launch");
     return PM_OK;
 }
 
@@ -433,15 +455,20 @@ int pm_dlrm_regroup(const int64_t* lengths, const int64_t* indices, int32_t worl
     return PM_OK;
 }
 
-int pm_embbag_check(const pm_embbag_batch* op, int32_t* d_error_count, pm_stream_t stream) {
+int pm_embbag_check_ex(const pm_embbag_batch* op, int32_t flags, int32_t* d_error_count, pm_stream_t stream) {
     pm::KParams p;
     int rc = make_params(op, op ? op->weight_dtype : -1, p);
     if (rc != PM_OK) return rc;
     if (!d_error_count) return fail(PM_ERR_INVALID, "d_error_count is NULL");
+    if (flags & ~PM_CHECK_UNIFORM_DIMS) return fail(PM_ERR_INVALID, "unknown check flag");
     hipError_t h = pm::launch_embbag_check(p, d_error_count, op->weight_dtype == PM_F32 ? 4 : 8, op->max_dim, op->fixed_pooling,
-                                           static_cast<hipStream_t>(stream));
+                                           (flags & PM_CHECK_UNIFORM_DIMS) ? 1 : 0, static_cast<hipStream_t>(stream));
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_check launch");
     return PM_OK;
+}
+
+int pm_embbag_check(const pm_embbag_batch* op, int32_t* d_error_count, pm_stream_t stream) {
+    return pm_embbag_check_ex(op, 0, d_error_count, stream);
 }
 
 int pm_fill_random(void* dst, int64_t count, int32_t dtype, int32_t dist, float lo, float hi, uint64_t seed,

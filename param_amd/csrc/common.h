@@ -52,6 +52,7 @@ struct KParams {
     int32_t nt_loads;            // 1: non-temporal table-row loads
     int32_t ordered;             // forward: 1 = ragged request, lane groups take the longest bags of a tile first
     int32_t stage_out;           // forward: > 0 = collect the tile's pooled rows in LDS (this many floats per row), write at tile end
+    int32_t out_bits;            // forward: 0 = fp32 output; 16 / 8 / 4 / 2 = io holds row-wise quantised rows (rowquant.hip), staged only
     float alpha;                 // bwd scale
 };
 
@@ -125,7 +126,7 @@ hipError_t launch_embbag_fwd(const KParams& p, int weight_dtype, int max_dim, in
 hipError_t launch_embbag_fwd_split(const KParams& p, int weight_dtype, int max_dim, hipStream_t stream);
 hipError_t launch_embbag_bwd(const KParams& p, int dst_dtype, int max_dim, hipStream_t stream);
 hipError_t launch_embbag_check(const KParams& p, int32_t* d_err, int vec, int max_dim, int64_t fixed_pooling,
-                               hipStream_t stream);
+                               int uniform_dims, hipStream_t stream);
 hipError_t launch_fill_random(void* dst, int64_t count, int dtype, int dist, float lo, float hi,
                               uint64_t seed, hipStream_t stream);
 

@@ -20,6 +20,7 @@
 //   * blockIdx -> (table, tile) can be XCD-affine (common.h) so a table's hot rows stay in
 //     one XCD's L2 under Zipf-skewed indices.
 #include "common.h"
+#include "rowquant.inc"
 
 namespace pm {
 namespace {
@@ -61,6 +62,67 @@ template <> struct Elem<f16_t> {
 __device__ __forceinline__ u32x4 load16(const char* p, bool nt) {
     const PM_GLOBAL u32x4* q = as_global<u32x4>(p);   // global_load_dwordx4, not flat_load (common.h)
     return nt ? __builtin_nontemporal_load(q) : *q;
+}
+
+// Quantised output burst (p.out_bits = 16 / 8 / 4 / 2): the tile's pooled rows leave LDS as row-wise quantised rows
+// (rowquant.hip's formats) -- what the quantised all-to-all sends -- so the fp32 pooled output never reaches HBM.  The
+// pooled vector of (bag b, table t) is row b * (out_stride / D) + out_offsets[t] / D of the output: the fp32 layouts
+// with D-element rows.  All tables of the request have the same D (pm_embbag_fwd_quantized's contract).
+__device__ __forceinline__ float shfl_min(float v, int width) {
+    for (int m = width / 2; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m, width));
+    return v;
+}
+__device__ __forceinline__ float shfl_max(float v, int width) {
+    for (int m = width / 2; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, width));
+    return v;
+}
+
+template <int BITS>
+__device__ __forceinline__ void fused_rows_burst(const float* s_out, int nb, int D, uint8_t* qout, int64_t row0, int64_t rows_per_bag) {
+    int gq = 4;
+    while (gq * 8 < D) gq *= 2;                               // lanes per row: two 4-column chunks per lane
+    const int lane = threadIdx.x % gq;
+    const int c0 = lane * 4, c1 = (gq + lane) * 4;
+    const bool has0 = c0 < D, has1 = c1 < D;
+    const int64_t rb = rq::row_bytes(D, BITS);
+    for (int r0 = 0; r0 < nb; r0 += kBlock / gq) {
+        const int bg = r0 + threadIdx.x / gq;                 // uniform inside a lane group
+        const bool live = bg < nb;
+        const float* src = s_out + static_cast<size_t>(live ? bg : 0) * D;
+        const f32x4 a = has0 ? *reinterpret_cast<const f32x4*>(src + c0) : f32x4{0, 0, 0, 0};
+        const f32x4 b = has1 ? *reinterpret_cast<const f32x4*>(src + c1) : f32x4{0, 0, 0, 0};
+        float mn, mx;
+        rq::row_min_max(a, b, has0, has1, mn, mx);
+        mn = shfl_min(mn, gq);
+        mx = shfl_max(mx, gq);
+        if (!live) continue;
+        const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        rq::quantize_row_share<BITS>(x, mn, mx, lane == 0, has0, has1, c0, c1, D, qout + (row0 + bg * rows_per_bag) * rb);
+    }
+}
+
+__device__ __forceinline__ void quantized_burst(const KParams& p, const float* s_out, int nb, int D, int64_t bag0, int64_t out_off) {
+    uint8_t* qout = reinterpret_cast<uint8_t*>(p.io);
+    const int64_t rows_per_bag = p.out_stride / D;
+    const int64_t row0 = bag0 * rows_per_bag + out_off / D;  // row of the tile's first bag
+    switch (p.out_bits) {
+        case 16: {
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const int q = D / 4;                              // 8-byte pieces per row
+            for (int i = threadIdx.x; i < nb * q; i += kBlock) {
+                const int bg = i / q, c4 = i % q;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(s_out + static_cast<size_t>(bg) * D + c4 * 4);
+                u32x2 o;
+                o.x = rq::half_bits(v.x) | (static_cast<uint32_t>(rq::half_bits(v.y)) << 16);
+                o.y = rq::half_bits(v.z) | (static_cast<uint32_t>(rq::half_bits(v.w)) << 16);
+                __builtin_nontemporal_store(o, reinterpret_cast<u32x2*>(qout + (row0 + bg * rows_per_bag) * 2 * D) + c4);
+            }
+            break;
+        }
+        case 8: fused_rows_burst<8>(s_out, nb, D, qout, row0, rows_per_bag); break;
+        case 4: fused_rows_burst<4>(s_out, nb, D, qout, row0, rows_per_bag); break;
+        default: fused_rows_burst<2>(s_out, nb, D, qout, row0, rows_per_bag); break;
+    }
 }
 
 template <typename WT, int G, int UNROLL, bool WEIGHTED, bool ORDERED, bool STAGE>
@@ -212,11 +274,15 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
     }
     if (STAGE) {
         __syncthreads();
-        const int q = D / 4;                       // 16-byte pieces per row
-        for (int i = threadIdx.x; i < nb * q; i += kBlock) {
-            const int bg = i / q, c4 = i % q;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(s_out + static_cast<size_t>(bg) * D + c4 * 4);
-            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out_t + (bag0 + bg) * p.out_stride + c4 * 4));
+        if (p.out_bits == 0) {
+            const int q = D / 4;                       // 16-byte pieces per row
+            for (int i = threadIdx.x; i < nb * q; i += kBlock) {
+                const int bg = i / q, c4 = i % q;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(s_out + static_cast<size_t>(bg) * D + c4 * 4);
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out_t + (bag0 + bg) * p.out_stride + c4 * 4));
+            }
+        } else {
+            quantized_burst(p, s_out, nb, D, bag0, p.out_offsets[t]);
         }
     }
 }

@@ -19,6 +19,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "rowquant.inc"
 
 namespace pm {
 namespace {
@@ -36,31 +37,16 @@ __device__ __forceinline__ float group_max(float v) {
     return v;
 }
 
-__device__ __forceinline__ uint16_t half_bits(float f) { return __builtin_bit_cast(uint16_t, static_cast<_Float16>(f)); }
-__device__ __forceinline__ float half_value(uint16_t h) { return static_cast<float>(__builtin_bit_cast(_Float16, h)); }
-
-__host__ __device__ inline int64_t row_bytes(int dim, int bits) {
-    return bits == 16 ? 2LL * dim : bits == 8 ? dim + 8LL : static_cast<int64_t>(dim) * bits / 8 + 4;
-}
+using rq::half_bits;
+using rq::half_value;
+using rq::load_codes;
+using rq::row_bytes;
 
 // BITS = 8, 4, 2: fused row-wise formats.  A lane owns two 4-column chunks of a row, G * 4 columns apart, so that each of
 // its two 16-byte accesses is contiguous across the lane group; blockDim = kBlock, kBlock / G row slots per block and
 // kRowsPerSlot rows per slot (independent loads first, then the arithmetic and the stores).
 constexpr int kRowsPerSlot = 2;    // restore (write-bound)
 constexpr int kRowsPerSlotQ = 4;   // quantise (read-bound): more loads in flight per lane
-
-template <int BITS>
-__device__ __forceinline__ void store_codes(uint8_t* out, int col, uint32_t packed) {   // 4 codes starting at column col
-    if constexpr (BITS == 8) *reinterpret_cast<uint32_t*>(out + col) = packed;
-    else if constexpr (BITS == 4) *reinterpret_cast<uint16_t*>(out + col / 2) = static_cast<uint16_t>(packed);
-    else out[col / 4] = static_cast<uint8_t>(packed);
-}
-template <int BITS>
-__device__ __forceinline__ uint32_t load_codes(const uint8_t* in, int col) {
-    if constexpr (BITS == 8) return *reinterpret_cast<const uint32_t*>(in + col);
-    else if constexpr (BITS == 4) return *reinterpret_cast<const uint16_t*>(in + col / 2);
-    else return in[col / 4];
-}
 
 template <int G, int BITS>
 __global__ void __launch_bounds__(kBlock) rows_quantize_kernel(const float* __restrict__ src, int64_t n_rows, int dim,
@@ -80,49 +66,13 @@ __global__ void __launch_bounds__(kBlock) rows_quantize_kernel(const float* __re
 #pragma unroll
     for (int r = 0; r < kRowsPerSlotQ; ++r) {
         const bool live = row0 + r < n_rows;
-        float mn = INFINITY, mx = -INFINITY;
-        if (has0) { mn = fminf(fminf(a[r].x, a[r].y), fminf(a[r].z, a[r].w)); mx = fmaxf(fmaxf(a[r].x, a[r].y), fmaxf(a[r].z, a[r].w)); }
-        if (has1) {
-            mn = fminf(mn, fminf(fminf(b[r].x, b[r].y), fminf(b[r].z, b[r].w)));
-            mx = fmaxf(mx, fmaxf(fmaxf(b[r].x, b[r].y), fmaxf(b[r].z, b[r].w)));
-        }
+        float mn, mx;
+        rq::row_min_max(a[r], b[r], has0, has1, mn, mx);
         mn = group_min<G>(mn);
         mx = group_max<G>(mx);
         if (!live) continue;
-        uint8_t* out = dst + (row0 + r) * row_bytes(dim, BITS);
         const float x[8] = {a[r].x, a[r].y, a[r].z, a[r].w, b[r].x, b[r].y, b[r].z, b[r].w};
-        uint32_t w[2] = {0u, 0u};
-        if constexpr (BITS == 8) {
-            const float range = mx - mn;
-            const float scale = range / 255.0f;
-            const float inv = 255.0f / (range + 1e-8f);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) w[i / 4] |= (static_cast<uint32_t>(__float2int_rn((x[i] - mn) * inv)) & 0xffu) << (8 * (i % 4));
-            if (lane == 0) *reinterpret_cast<float2*>(out + dim) = make_float2(scale, mn);
-        } else {
-            constexpr int kLevels = (1 << BITS) - 1;
-            const uint16_t bias_h = half_bits(mn);
-            const float bias = half_value(bias_h);
-            const float range = mx - bias;
-            uint16_t scale_h = half_bits(range == 0.0f ? 1.0f : range / static_cast<float>(kLevels));
-            float scale = half_value(scale_h);
-            if (scale == 0.0f) { scale_h = 0x3c00u; scale = 1.0f; }
-            float inv = 1.0f / scale;
-            if (isinf(inv)) { scale_h = 0x3c00u; inv = 1.0f; }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float q = rintf((x[i] - bias) * inv);
-                q = fminf(fmaxf(q, 0.0f), static_cast<float>(kLevels));
-                w[i / 4] |= static_cast<uint32_t>(q) << (BITS * (i % 4));
-            }
-            if (lane == 0) {
-                uint16_t* sb = reinterpret_cast<uint16_t*>(out + dim * BITS / 8);
-                sb[0] = scale_h;
-                sb[1] = bias_h;
-            }
-        }
-        if (has0) store_codes<BITS>(out, c0, w[0]);
-        if (has1) store_codes<BITS>(out, c1, w[1]);
+        rq::quantize_row_share<BITS>(x, mn, mx, lane == 0, has0, has1, c0, c1, dim, dst + (row0 + r) * row_bytes(dim, BITS));
     }
 }
 

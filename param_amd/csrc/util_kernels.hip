@@ -11,7 +11,7 @@ namespace {
 // cannot see: rows[t] in [1, 2^31) (staged indices are narrowed to int32), dims[t] a multiple of the 16-byte vector and
 // <= max_dim, out_offsets[t] 16-byte aligned, table base pointers 16-byte aligned.
 __global__ void __launch_bounds__(kBlock) embbag_check_kernel(const KParams p, int32_t* err, int vec, int max_dim,
-                                                              int64_t fixed_pooling) {
+                                                              int64_t fixed_pooling, int uniform_dims) {
     const int64_t per_table = p.bag_count;
     const int64_t total = per_table * p.T;
     int bad = 0;
@@ -23,6 +23,8 @@ __global__ void __launch_bounds__(kBlock) embbag_check_kernel(const KParams p, i
             bad += (d < 1 || d % vec != 0 || d > max_dim) ? 1 : 0;
             bad += (p.out_offsets[t] % 4 != 0) ? 1 : 0;
             bad += (reinterpret_cast<uintptr_t>(p.tables[t]) % 16 != 0) ? 1 : 0;
+            // quantised output (pm_embbag_fwd_quantized): every pooled vector is one max_dim-element row of the output
+            if (uniform_dims) bad += (d != max_dim || p.out_offsets[t] % max_dim != 0) ? 1 : 0;
         }
     }
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total;
@@ -114,7 +116,7 @@ __global__ void __launch_bounds__(kBlock) fill_random_kernel(void* dst, int64_t 
 }  // namespace
 
 hipError_t launch_embbag_check(const KParams& p, int32_t* d_err, int vec, int max_dim, int64_t fixed_pooling,
-                               hipStream_t stream) {
+                               int uniform_dims, hipStream_t stream) {
     hipError_t rc = hipMemsetAsync(d_err, 0, sizeof(int32_t), stream);
     if (rc != hipSuccess) return rc;
     const int64_t total = p.bag_count * p.T;
@@ -122,7 +124,7 @@ hipError_t launch_embbag_check(const KParams& p, int32_t* d_err, int vec, int ma
     if (blocks < 1) blocks = 1;   // the per-table checks run even for an empty batch slice
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(embbag_check_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, stream, p, d_err, vec,
-                       max_dim, fixed_pooling);
+                       max_dim, fixed_pooling, uniform_dims);
     return hipGetLastError();
 }
 

@@ -191,6 +191,34 @@ def _fwd(ts: _TableSet, indices, offsets, B, psw=None, out=None, bag_begin=0, ba
     return out
 
 
+def _fwd_quantized(ts: _TableSet, indices, offsets, B, bitwidth: int, psw=None, out=None, bag_begin=0, bag_count=None):
+    """Forward whose output is row-wise quantised (``pm_embbag_fwd_quantized``): one quantised row per pooled vector, in
+    the order of the fp32 layout.  Returns a uint8 tensor ``[*shape[:-1] as rows, row_bytes]`` -- ``(B, T, rb)`` for the
+    ``bd`` layout, ``(T, B, rb)`` for ``tbd``.  Requests the staged kernel does not take (ragged bags) are served by the
+    fp32 forward + ``pm_rows_quantize``: same bytes, one more pass."""
+    from . import quant
+    if len(set(ts.dims)) != 1:
+        raise ValueError("quantised output needs one common embedding dim")
+    D = ts.dims[0]
+    rb = quant.host_row_bytes(D, bitwidth)
+    if D % 8 or D > 512:
+        raise ValueError(f"quantised output needs an embedding dim that is a multiple of 8 and <= 512, got {D}")
+    qshape = (B, ts.T, rb) if ts.layout == "bd" else (ts.T, B, rb)
+    if out is None:
+        out = torch.empty(qshape, dtype=torch.uint8, device=ts.device)
+    elif out.dtype != torch.uint8 or out.numel() != B * ts.T * rb or not out.is_contiguous() or out.device != ts.device:
+        raise ValueError(f"out must be a contiguous uint8 tensor of {B * ts.T * rb} bytes on {ts.device}")
+    op = ts.request(indices, offsets, B, psw, bag_begin, bag_count)
+    L = _lib.load()
+    rc = L.pm_embbag_fwd_quantized(ctypes.byref(op), out.data_ptr(), int(bitwidth), _stream_ptr())
+    if rc == _lib.PM_ERR_UNSUPPORTED and (bag_begin, bag_count) in ((0, None), (0, B)):
+        full = _fwd(ts, indices, offsets, B, psw)
+        quant.quantize_rows(full, D, bitwidth, out=out)
+        return out
+    _lib.check(rc)
+    return out
+
+
 def _workspace(ts: _TableSet, op) -> torch.Tensor:
     """Scratch for the sort-based backward, cached on the table set (grown, never shrunk)."""
     need = _lib.load().pm_embbag_bwd_sorted_workspace(ctypes.byref(op), max(ts.rows))
@@ -454,6 +482,16 @@ class BatchedEmbeddingBagMI355(nn.Module):
         _require_device(self.weights, "BatchedEmbeddingBagMI355.weights")
         B = self._batch_of(offsets, indices) if batch is None else batch
         return _fwd(self._tables(), indices, offsets, B, per_sample_weights, out, bag_begin, bag_count, split_bags)
+
+    def lookup_quantized(self, indices, offsets, bitwidth: int, per_sample_weights=None, out=None, bag_begin=0,
+                         bag_count=None, batch: Optional[int] = None):
+        """Forward with a row-wise quantised output (``bitwidth`` 16 / 8 / 4 / 2): one quantised row per pooled vector,
+        uint8 ``(B, T, row_bytes)`` (``(T, B, row_bytes)`` for the ``tbd`` layout) -- the payload of a quantised
+        all-to-all (the reference's ``--bitwidth``), written by the lookup kernel itself.  ``param_amd.quant.
+        dequantize_rows`` restores fp32; the bytes equal ``quantize_rows(lookup(...))``."""
+        _require_device(self.weights, "BatchedEmbeddingBagMI355.weights")
+        B = self._batch_of(offsets, indices) if batch is None else batch
+        return _fwd_quantized(self._tables(), indices, offsets, B, bitwidth, per_sample_weights, out, bag_begin, bag_count)
 
     def forward(self, indices, offsets, per_sample_weights=None):
         if self.fused_update and torch.is_grad_enabled():

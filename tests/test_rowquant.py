@@ -119,3 +119,52 @@ def test_gpu_full_size_exchange_payload_round_trip_properties():
         quant.quantize_rows(x.half(), dim, 8)
     with pytest.raises(ValueError):
         quant.quantize_rows(x.reshape(-1)[:1000], 128, 8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", BITS)
+@pytest.mark.parametrize("layout", ["bd", "tbd"])
+def test_gpu_forward_with_quantised_output_equals_two_pass(bits, layout):
+    """pm_embbag_fwd_quantized: the lookup kernel's output burst writes the quantised rows itself -- bytes identical to
+    quantising the fp32 forward's output (and through it to the oracle), for fixed pooling (staged kernel), weighted and
+    unweighted, fp32 and bf16 tables, both output layouts and a batch slice; ragged requests fall back to two passes"""
+    from param_amd import BatchedEmbeddingBagMI355, quant
+    from param_amd.compute.python.split_table_batched_embeddings_ops import generate_batched_request
+    torch.manual_seed(bits)
+    for dtype, D, T, B, L, weighted in ((torch.float32, 128, 5, 300, 20, False), (torch.bfloat16, 64, 8, 64, 7, True),
+                                        (torch.float32, 256, 2, 1000, 3, False), (torch.float16, 32, 3, 77, 30, False)):
+        m = BatchedEmbeddingBagMI355([5000 + 10 * t for t in range(T)], D, dtype=dtype, device="cuda", layout=layout)
+        m.reset_parameters(seed=3)
+        idx, off, w = generate_batched_request(T, m.rows, B, [L] * T, alpha=1.05, weighted=weighted, device="cuda")
+        ref = m.lookup(idx, off, w)
+        want = orq.quantize_rows(ref.cpu().numpy().reshape(-1, D), bits)
+        got = m.lookup_quantized(idx, off, bits, w)
+        assert got.shape[-1] == orq.row_bytes(D, bits) and got.numel() == want.size
+        assert np.array_equal(got.cpu().numpy().reshape(want.shape), want), (dtype, D, layout)
+        assert torch.equal(quant.quantize_rows(ref, D, bits).view(-1), got.view(-1))
+        if layout == "bd":                                     # batch slice: only those bags' rows are written
+            buf = torch.full_like(got, 0xAB)
+            m.lookup_quantized(idx, off, bits, w, out=buf, bag_begin=10, bag_count=30)
+            assert torch.equal(buf[10:40], got[10:40]) and bool((buf[:10] == 0xAB).all()) and bool((buf[40:] == 0xAB).all())
+    # ragged request: not staged -> PM_ERR_UNSUPPORTED from the C entry, the module runs forward + quantise
+    m = BatchedEmbeddingBagMI355([3000] * 4, 128, device="cuda", layout=layout)
+    m.reset_parameters(seed=1)
+    idx, off, _ = generate_batched_request(4, m.rows, 200, [1, 40, 7, 13], alpha=0.0, device="cuda")
+    op = m._tables().request(idx, off, 200, None, 0, None)
+    L_ = _lib.load()
+    rc = L_.pm_embbag_fwd_quantized(ctypes.byref(op), ctypes.c_void_p(torch.empty(200 * 4 * 136, dtype=torch.uint8, device="cuda").data_ptr()),
+                                    bits, None)
+    got = m.lookup_quantized(idx, off, bits)
+    want = orq.quantize_rows(m.lookup(idx, off).cpu().numpy().reshape(-1, 128), bits)
+    assert np.array_equal(got.cpu().numpy().reshape(want.shape), want)
+    assert rc in (_lib.PM_OK, _lib.PM_ERR_UNSUPPORTED)
+    # the layout contract, checked on the device
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    assert L_.pm_embbag_check_ex(ctypes.byref(op), 1, ctypes.c_void_p(err.data_ptr()), None) == _lib.PM_OK and int(err.item()) == 0
+    mixed = BatchedEmbeddingBagMI355([100, 100], [64, 128], device="cuda")
+    idx2, off2, _ = generate_batched_request(2, mixed.rows, 16, [2, 2], alpha=0.0, device="cuda")
+    op2 = mixed._tables().request(idx2, off2, 16, None, 0, None)
+    assert L_.pm_embbag_check_ex(ctypes.byref(op2), 1, ctypes.c_void_p(err.data_ptr()), None) == _lib.PM_OK and int(err.item()) > 0
+    assert L_.pm_embbag_check_ex(ctypes.byref(op2), 0, ctypes.c_void_p(err.data_ptr()), None) == _lib.PM_OK and int(err.item()) == 0
+    with pytest.raises(ValueError, match="common embedding dim"):
+        mixed.lookup_quantized(idx2, off2, bits)
