@@ -88,6 +88,10 @@ def parse():
     p.add_argument("--atomic", action="store_true", help="also time the atomic backward kernel (slow: ~15 ms per step)")
     p.add_argument("--lookup-cus", type=int, default=0,
                    help="N>1: run lookup / backward on a HIP stream masked to this many CUs (0 = all 256), leaving the rest to RCCL")
+    p.add_argument("--a2a-bitwidth", type=int, default=32, choices=[32, 16, 8, 4, 2],
+                   help="N>1: quantise the pooled all-to-all to this many bits (the reference's --bitwidth; row-wise formats of "
+                        "param_amd.quant, written by the lookup kernel itself).  Default 32 = the reference's default, exact")
+    p.add_argument("--grad-bitwidth", type=int, default=32, choices=[32, 16, 8, 4, 2], help="N>1: the same for the gradient all-to-all")
     p.add_argument("--traffic-from-profile", action="store_true",
                    help="fill roofline.traffic from profiles/pmc_traffic.json (a committed rocprofv3 --pmc result, not this run)")
     p.add_argument("--only-headline", action="store_true",
@@ -386,7 +390,14 @@ def main():
         def hip_backward(g, i, o):
             model.scatter_add_(g, i, o, alpha=-1e-6, batch=B_glob)   # key sort + deterministic apply
 
-        ex = ShardedEmbeddingExchange(hip_lookup, hip_backward, world, rank, B_local, widths, dev)
+        rq = None
+        if a.a2a_bitwidth < 32 or a.grad_bitwidth < 32:
+            from param_amd.comms.pt.pipeline import RowQuant
+
+            fbits = a.a2a_bitwidth if a.a2a_bitwidth < 32 else 0
+            rq = RowQuant(D, fbits, a.grad_bitwidth if a.grad_bitwidth < 32 else 0,
+                          lookup_quantized=(lambda i, o, q: model.lookup_quantized(i, o, fbits, out=q, batch=B_glob)) if fbits else None)
+        ex = ShardedEmbeddingExchange(hip_lookup, hip_backward, world, rank, B_local, widths, dev, quant=rq)
         fwd_pending = [None, None]
         kstep = [0]
 
@@ -395,7 +406,7 @@ def main():
             s = kstep[0] % 2
             if fwd_pending[s] is not None:
                 fwd_pending[s].wait()
-            hip_lookup(i, o, ex.pooled[s])
+            ex._lookup(s, i, o)                      # fp32 rows, or the quantised payload straight from the lookup kernel
             fwd_pending[s] = ex.fwd_a2a(s)
             kstep[0] += 1
 
@@ -406,7 +417,7 @@ def main():
                     fwd_pending[s] = None
 
         def lookup_only(i=idx, o=off):
-            hip_lookup(i, o, ex.pooled[0])
+            ex._lookup(0, i, o)
 
     # Order of the measurements: the uniform-index launches (the roofline-defining run) come FIRST, the timed headline
     # steps right after them.  The first ~10 ms of load after the set-up phase ride a clock / power transient (kernel trace of
@@ -531,8 +542,16 @@ def main():
         alg_bw = a2a_bytes / a2a_s / 1e9
         result["all_to_all"] = {
             "bytes_per_rank": a2a_bytes, "avg_s": a2a_s, "algbw_GBps": alg_bw,
-            "busbw_GBps": alg_bw * (world - 1) / max(world, 1),  # pytorch_backend_utils.py:221-234
+            # pytorch_backend_utils.py:221-234; under --bitwidth the reference scales busBW by bitwidth / 32 (comms.py:1149)
+            "busbw_GBps": alg_bw * (world - 1) / max(world, 1) * (a.a2a_bitwidth / 32.0),
             "xgmi_bound_GBps": (world - 1) * 153.0}
+        if rq is not None:
+            wf, wb = ex.wire_bytes_per_rank()
+            result["all_to_all"].update({"bitwidth": a.a2a_bitwidth, "grad_bitwidth": a.grad_bitwidth,
+                                         "wire_bytes_per_rank": wf, "grad_wire_bytes_per_rank": wb,
+                                         "note": "bytes_per_rank / algbw keep the reference's fp32 memSize; wire bytes are what RCCL moves"})
+            result["config"]["a2a_bitwidth"] = a.a2a_bitwidth
+            result["config"]["grad_bitwidth"] = a.grad_bitwidth
         result["overlap"] = {"step_s": dev_s, "lookup_only_s": zipf_s, "all_to_all_only_s": a2a_s,
                              "overlap_eff": max(zipf_s, a2a_s) / dev_s, "serial_s": zipf_s + a2a_s,
                              "lookup_cus": a.lookup_cus or 256,
@@ -542,7 +561,7 @@ def main():
                 ex.bwd_a2a(0).wait()
 
             def compute_only():
-                hip_lookup(idx, off, ex.pooled[0])
+                ex._lookup(0, idx, off)
                 hip_backward(ex.grad[0], idx, off)
 
             for _ in range(3):

@@ -133,7 +133,8 @@ class ShardedEmbeddingExchange:
     the received embeddings themselves."""
 
     def __init__(self, lookup: Callable, backward: Callable, world: int, rank: int, local_batch: int,
-                 widths: Sequence[int], device, group=None, make_grad: Callable = None, slots: int = 3):
+                 widths: Sequence[int], device, group=None, make_grad: Callable = None, slots: int = 3,
+                 quant: "RowQuant | None" = None):
         self.lookup, self.backward, self.make_grad = lookup, backward, make_grad
         self.world, self.rank, self.local_batch, self.pg = world, rank, local_batch, group
         self.widths = [int(w) for w in widths]
@@ -150,15 +151,64 @@ class ShardedEmbeddingExchange:
         self._fwd_work = [None] * slots
         self._bwd_work = [None] * slots
         self._k = 0
+        # quantised exchange (the reference's --bitwidth): byte buffers beside the fp32 ones, splits in bytes
+        self.quant = quant
+        if quant is not None:
+            if any(w % quant.dim for w in self.widths):
+                raise ValueError(f"quantised exchange: every rank's width must be a whole number of {quant.dim}-element rows")
+            mkq = lambda nbytes: [torch.empty(nbytes, dtype=torch.uint8, device=device) for _ in range(slots)]  # noqa: E731
+            fb, gb = quant.row_bytes(quant.fwd_bits), quant.row_bytes(quant.bwd_bits)
+            rows = lambda elems: elems // quant.dim                                                             # noqa: E731
+            if quant.fwd_bits:
+                self.q_pooled, self.q_recv = mkq(rows(n * wme) * fb), mkq(rows(total) * fb)
+                self.qf_send = [rows(x) * fb for x in self.fwd_send_splits]
+                self.qf_recv = [rows(x) * fb for x in self.fwd_recv_splits]
+            if quant.bwd_bits:
+                self.q_grad_in, self.q_grad = mkq(rows(total) * gb), mkq(rows(n * wme) * gb)
+                self.qb_send = [rows(x) * gb for x in self.fwd_recv_splits]
+                self.qb_recv = [rows(x) * gb for x in self.fwd_send_splits]
 
     # -- pieces (also timed on their own by bench.py) ---------------------------------------------
+    def _lookup(self, slot: int, indices, offsets) -> None:
+        q = self.quant
+        if q is not None and q.fwd_bits:
+            if q.lookup_quantized is not None:           # the lookup kernel writes the quantised rows itself
+                q.lookup_quantized(indices, offsets, self.q_pooled[slot])
+            else:
+                self.lookup(indices, offsets, self.pooled[slot])
+                q.quantize(self.pooled[slot], q.fwd_bits, self.q_pooled[slot])
+        else:
+            self.lookup(indices, offsets, self.pooled[slot])
+
     def fwd_a2a(self, slot: int, async_op: bool = True):
+        if self.quant is not None and self.quant.fwd_bits:
+            return dist.all_to_all_single(self.q_recv[slot], self.q_pooled[slot], self.qf_recv, self.qf_send,
+                                          group=self.pg, async_op=async_op)
         return dist.all_to_all_single(self.recv[slot], self.pooled[slot].view(-1), self.fwd_recv_splits, self.fwd_send_splits,
                                       group=self.pg, async_op=async_op)
 
+    def _fwd_arrived(self, slot: int) -> None:
+        """after the forward exchange has been waited for: restore fp32 (quantised exchange), build the gradient to send"""
+        q = self.quant
+        if q is not None and q.fwd_bits:
+            q.dequantize(self.q_recv[slot], q.fwd_bits, self.recv[slot])
+        if self.make_grad is not None:
+            self.make_grad(self.recv[slot], self.grad_in[slot])
+        if q is not None and q.bwd_bits:
+            q.quantize(self.grad_in[slot], q.bwd_bits, self.q_grad_in[slot])
+
     def bwd_a2a(self, slot: int, async_op: bool = True):
+        if self.quant is not None and self.quant.bwd_bits:
+            return dist.all_to_all_single(self.q_grad[slot], self.q_grad_in[slot], self.qb_recv, self.qb_send,
+                                          group=self.pg, async_op=async_op)
         return dist.all_to_all_single(self.grad[slot].view(-1), self.grad_in[slot], self.fwd_send_splits, self.fwd_recv_splits,
                                       group=self.pg, async_op=async_op)
+
+    def _backward(self, slot: int) -> None:
+        q = self.quant
+        if q is not None and q.bwd_bits:
+            q.dequantize(self.q_grad[slot], q.bwd_bits, self.grad[slot].view(-1))
+        self.backward(self.grad[slot], *self._req[slot])
 
     def recv_block(self, slot: int, src: int) -> torch.Tensor:
         """[B_local, widths[src]] view of what rank ``src`` sent me in the forward exchange"""
@@ -166,27 +216,34 @@ class ShardedEmbeddingExchange:
         return self.recv[slot][o:o + self.fwd_recv_splits[src]].view(self.local_batch, self.widths[src])
 
     def bytes_per_rank(self) -> int:
-        """output-tensor bytes of ONE exchange per rank (the reference's ``memSize``); forward and backward are equal in
-        total over the ranks, not per rank, when the shards are uneven"""
+        """output-tensor bytes of ONE exchange per rank (the reference's ``memSize``, which stays the fp32 size under
+        ``--bitwidth``: the report scales busBW by bitwidth / 32 instead, comms.py:1149); forward and backward are equal
+        in total over the ranks, not per rank, when the shards are uneven"""
         return self.recv[0].numel() * 4
+
+    def wire_bytes_per_rank(self):
+        """bytes this rank RECEIVES per (forward, gradient) exchange as actually sent: quantised rows where enabled"""
+        q = self.quant
+        f = self.q_recv[0].numel() if q is not None and q.fwd_bits else self.recv[0].numel() * 4
+        b = self.q_grad[0].numel() if q is not None and q.bwd_bits else self.grad[0].numel() * 4
+        return f, b
 
     # -- the pipelined step ---------------------------------------------------------------------------
     def step(self, indices, offsets) -> None:
         k, s = self._k, self._k % self.slots
         # slot s was last used by batch k - slots, whose backward ran at step k - slots + 2 on this stream: free.
-        self.lookup(indices, offsets, self.pooled[s])
+        self._lookup(s, indices, offsets)
         self._req[s] = (indices, offsets)
         self._fwd_work[s] = self.fwd_a2a(s)                      # on the pg stream, after the lookup; under what follows
         if k >= 1:                                               # batch k-1: its pooled embeddings have arrived -> gradient back
             p = (k - 1) % self.slots
             self._fwd_work[p].wait()
-            if self.make_grad is not None:
-                self.make_grad(self.recv[p], self.grad_in[p])
+            self._fwd_arrived(p)
             self._bwd_work[p] = self.bwd_a2a(p)
         if k >= 2:                                               # batch k-2: its gradient is home -> fused backward
             q = (k - 2) % self.slots
             self._bwd_work[q].wait()
-            self.backward(self.grad[q], *self._req[q])
+            self._backward(q)
         self._k += 1
 
     def drain(self) -> None:
@@ -198,23 +255,47 @@ class ShardedEmbeddingExchange:
             p = b % self.slots
             if b == k - 1:
                 self._fwd_work[p].wait()
-                if self.make_grad is not None:
-                    self.make_grad(self.recv[p], self.grad_in[p])
+                self._fwd_arrived(p)
                 self._bwd_work[p] = self.bwd_a2a(p)
         for b in (k - 2, k - 1):
             if b < 0:
                 continue
             q = b % self.slots
             self._bwd_work[q].wait()
-            self.backward(self.grad[q], *self._req[q])
+            self._backward(q)
         self._k = 0
 
     def step_serial(self, indices, offsets) -> None:
         """the same batch with nothing overlapped: lookup, exchange, gradient exchange, backward, each waited for
         (what the reference does: barrier after every region, dlrm.py:119-123,1196-1290)"""
-        self.lookup(indices, offsets, self.pooled[0])
+        self._lookup(0, indices, offsets)
+        self._req[0] = (indices, offsets)
         self.fwd_a2a(0).wait()
-        if self.make_grad is not None:
-            self.make_grad(self.recv[0], self.grad_in[0])
+        self._fwd_arrived(0)
         self.bwd_a2a(0).wait()
-        self.backward(self.grad[0], indices, offsets)
+        self._backward(0)
+
+
+class RowQuant:
+    """How a :class:`ShardedEmbeddingExchange` quantises its payloads (the reference's ``--bitwidth`` for the pooled
+    all-to-all): rows of ``dim`` values, ``fwd_bits`` / ``bwd_bits`` in {0 (fp32), 16, 8, 4, 2} for the forward and the
+    gradient exchange.  ``quantize(src_f32, bits, out_u8)`` / ``dequantize(src_u8, bits, out_f32)`` default to the HIP row
+    quantisers (:mod:`param_amd.quant`, GPU tensors only); ``lookup_quantized(indices, offsets, out_u8)`` -- optional --
+    is a lookup that writes quantised rows itself (``BatchedEmbeddingBagMI355.lookup_quantized``), which makes the
+    forward payload free.  The gloo tests inject numpy stand-ins."""
+
+    def __init__(self, dim: int, fwd_bits: int = 0, bwd_bits: int = 0, quantize: Callable = None, dequantize: Callable = None,
+                 lookup_quantized: Callable = None):
+        self.dim, self.fwd_bits, self.bwd_bits = int(dim), int(fwd_bits), int(bwd_bits)
+        for b in (self.fwd_bits, self.bwd_bits):
+            if b not in (0, 16, 8, 4, 2):
+                raise ValueError(f"bit width must be 0 (fp32), 16, 8, 4 or 2, got {b}")
+        self.lookup_quantized = lookup_quantized
+        if quantize is None or dequantize is None:
+            from ... import quant as _q
+            quantize = quantize or (lambda src, bits, out: _q.quantize_rows(src, self.dim, bits, out=out))
+            dequantize = dequantize or (lambda src, bits, out: _q.dequantize_rows(src, self.dim, bits, out=out))
+        self.quantize, self.dequantize = quantize, dequantize
+
+    def row_bytes(self, bits: int) -> int:
+        return 0 if not bits else 2 * self.dim if bits == 16 else self.dim + 8 if bits == 8 else self.dim * bits // 8 + 4

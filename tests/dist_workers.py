@@ -613,3 +613,103 @@ class pytest_raises:
     def __exit__(self, et, ev, tb):
         assert et is not None and issubclass(et, self.exc) and self.match in str(ev), (et, ev)
         return True
+
+
+def sharded_exchange_quantized(rank, world, port):
+    """ShardedEmbeddingExchange with quantised payloads (forward 8-bit rows, gradient fp16; then 4-bit / fp32) on an uneven
+    split: the receive blocks hold restore(quantise(pooled)) row by row, the gradient arriving at the owner is
+    restore(quantise(gradient sent)), byte splits follow the table split.  numpy stand-ins for the HIP quantisers."""
+    import numpy as np
+
+    from oracle import rowquant as orq
+    from param_amd.comms.pt.pipeline import RowQuant, ShardedEmbeddingExchange, table_split
+
+    _env(rank, world, port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        D, rows, pools, B_local = 8, [40, 50, 60], [3, 1, 5], 4
+        split = table_split(len(rows), world)                      # [2, 1]
+        first = [sum(split[:r]) for r in range(world)]
+        widths = [split[r] * D for r in range(world)]
+        B_glob = world * B_local
+        tables = {t: torch.randn(rows[t], D, generator=torch.Generator().manual_seed(700 + t)) * (t + 1) for t in range(len(rows))}
+
+        def request(owner, k):
+            gg = torch.Generator().manual_seed(1000 * k + owner)
+            own = list(range(first[owner], first[owner] + split[owner]))
+            idx = torch.cat([torch.randint(0, rows[t], (B_glob * pools[t],), generator=gg) for t in own])
+            lens = torch.cat([torch.full((B_glob,), pools[t], dtype=torch.int64) for t in own])
+            off = torch.zeros(len(own) * B_glob + 1, dtype=torch.int64)
+            off[1:] = torch.cumsum(lens, 0)
+            return idx, off
+
+        def pooled_of(owner, k):
+            idx, off = request(owner, k)
+            own = list(range(first[owner], first[owner] + split[owner]))
+            cols = []
+            for i, t in enumerate(own):
+                s, e = int(off[i * B_glob]), int(off[(i + 1) * B_glob])
+                cols.append(torch.nn.functional.embedding_bag(idx[s:e], tables[t], off[i * B_glob:(i + 1) * B_glob] - s, mode="sum"))
+            return torch.cat(cols, dim=1)
+
+        def lookup(indices, offsets, out):
+            out.copy_(pooled_of(rank, lookup.k))
+
+        grads_home = []
+
+        def backward(grad, indices, offsets):
+            grads_home.append(grad.clone())
+
+        def quantize(src, bits, out):
+            out.copy_(torch.from_numpy(orq.quantize_rows(src.reshape(-1, D).numpy(), bits)).reshape(-1))
+
+        def dequantize(src, bits, out):
+            out.view(-1).copy_(torch.from_numpy(orq.dequantize_rows(src.numpy().reshape(-1, orq.row_bytes(D, bits)), D, bits)).reshape(-1))
+
+        rt = lambda x, bits: torch.from_numpy(orq.dequantize_rows(orq.quantize_rows(x.reshape(-1, D).numpy(), bits), D, bits)).reshape(x.shape)  # noqa: E731
+        for fwd_bits, bwd_bits in ((8, 16), (4, 0), (0, 2)):
+            calls = {"fused": 0}
+
+            def lookup_q(indices, offsets, out_q):                  # a lookup that writes quantised rows itself
+                calls["fused"] += 1
+                quantize(pooled_of(rank, lookup.k), fwd_bits, out_q)
+
+            q = RowQuant(D, fwd_bits, bwd_bits, quantize, dequantize, lookup_quantized=lookup_q if fwd_bits == 4 else None)
+            ex = ShardedEmbeddingExchange(lookup, backward, world, rank, B_local, widths, torch.device("cpu"),
+                                          make_grad=lambda recv, gin: gin.copy_(recv * float(rank + 2)), quant=q)
+            fb, gb = q.row_bytes(fwd_bits), q.row_bytes(bwd_bits)
+            if fwd_bits:
+                assert ex.qf_send == [B_local * split[rank] * fb] * world and ex.qf_recv == [B_local * split[r] * fb for r in range(world)]
+            if bwd_bits:
+                assert ex.qb_recv == [B_local * split[rank] * gb] * world
+            wf, wb = ex.wire_bytes_per_rank()
+            assert wf == (B_local * sum(split) * fb if fwd_bits else ex.bytes_per_rank())
+            assert wb == (B_glob * split[rank] * gb if bwd_bits else B_glob * widths[rank] * 4)
+            grads_home.clear()
+            steps = 4
+            for k in range(steps):
+                lookup.k = k
+                ex.step(*request(rank, k))
+                if k == 1:
+                    for src in range(world):
+                        exp = pooled_of(src, 0)[rank * B_local:(rank + 1) * B_local]
+                        exp = rt(exp, fwd_bits) if fwd_bits else exp
+                        assert torch.equal(ex.recv_block(0, src), exp), (fwd_bits, src)
+            ex.drain()
+            assert len(grads_home) == steps and calls["fused"] == (steps if fwd_bits == 4 else 0)
+            for k in range(steps):                                   # gradient the owner receives for batch k
+                mine = pooled_of(rank, k)
+                exp = torch.empty_like(mine)
+                for j in range(world):
+                    blk = mine[j * B_local:(j + 1) * B_local]
+                    blk = rt(blk, fwd_bits) if fwd_bits else blk     # what rank j received ...
+                    g = blk * float(j + 2)                            # ... its "dense part" ...
+                    exp[j * B_local:(j + 1) * B_local] = rt(g, bwd_bits) if bwd_bits else g     # ... and sent back
+                assert torch.equal(grads_home[k], exp), (fwd_bits, bwd_bits, k)
+            lookup.k = 9
+            ex.step_serial(*request(rank, 9))
+            assert len(grads_home) == steps + 1
+        with pytest_raises(ValueError, "whole number"):
+            ShardedEmbeddingExchange(lookup, backward, world, rank, B_local, [12, 8], torch.device("cpu"), quant=RowQuant(8, 8, 0, quantize, dequantize))
+    finally:
+        dist.destroy_process_group()
