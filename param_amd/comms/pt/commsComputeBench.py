@@ -60,6 +60,8 @@ class commsComputeBench(commsCollBench):
                 for t in (ca.comm_dev_time, ca.compute_dev_time):
                     if t:
                         t.reset()
+                ca.quant_time.reset()
+                ca.dequant_time.reset()
             start = time.monotonic()
             with paramStreamGuard(stream=bf.get_current_stream(device=ca.device), curDevice=ca.device,
                                   backendFuncs=bf, timer=ca.comm_dev_time, is_blocking=False):
@@ -103,6 +105,8 @@ class commsComputeBench(commsCollBench):
         compute_fn = bf.computeFunc[args.kernel]
         comm_fn = bf.collectiveFunc[commsParams.collective] if args.mode == "comms-compute" else None
         comms_utils.fixBeginSize(commsParams, ca.world_size)
+        if commsParams.bitwidth < 32 and comm_fn is not None:      # --bitwidth (reference commsComputeBench.py:395,727-735)
+            comms_utils.initQuantCommCtx(ca, commsParams)
         lookups = args.ntables * args.batch_size * args.bag_size * args.num_compute
         out = []
         for curSize in comms_utils.getSizes(commsParams.beginSize, commsParams.endSize, commsParams.stepFactor,
@@ -115,6 +119,9 @@ class commsComputeBench(commsCollBench):
                       "overlap_efficiency": (max(r.get("comm_dev_us", 0), r.get("compute_dev_us", 0)) / r["timeUS"]) if r["timeUS"] else 0})
             if r.get("compute_dev_us"):
                 r["lookups_per_s_compute_stream"] = lookups / (r["compute_dev_us"] * 1e-6)
+            if commsParams.bitwidth < 32 and comm_fn is not None:
+                r.update({"bitwidth": commsParams.bitwidth, "quant_us": ca.quant_time.getTimeUS() / ca.numIters,
+                          "dequant_us": ca.dequant_time.getTimeUS() / ca.numIters})
             if ca.global_rank == 0:
                 print("\tCOMMS-COMPUTE-RES-{}-{}  size {:>12}  iter {:>10.1f} us  comm(dev) {:>10.1f} us  compute(dev) {:>10.1f} us"
                       "  algBW {:>8.3f}  busBW {:>8.3f} GB/s".format(ca.collective, args.kernel, curSize, r["timeUS"],
@@ -122,6 +129,7 @@ class commsComputeBench(commsCollBench):
                                                                      r["algBW"], r["busBW"]))
             out.append(r)
             bf.clear_memory(ca)
+        comms_utils.clearQuantCommCtx(ca)
         return out
 
     def runBench(self, args):
