@@ -152,12 +152,15 @@ def test_gpu_forward_with_quantised_output_equals_two_pass(bits, layout):
     idx, off, _ = generate_batched_request(4, m.rows, 200, [1, 40, 7, 13], alpha=0.0, device="cuda")
     op = m._tables().request(idx, off, 200, None, 0, None)
     L_ = _lib.load()
-    rc = L_.pm_embbag_fwd_quantized(ctypes.byref(op), ctypes.c_void_p(torch.empty(200 * 4 * 136, dtype=torch.uint8, device="cuda").data_ptr()),
-                                    bits, None)
+    direct = torch.empty(200 * 4 * orq.row_bytes(128, bits), dtype=torch.uint8, device="cuda")
+    rc = L_.pm_embbag_fwd_quantized(ctypes.byref(op), ctypes.c_void_p(direct.data_ptr()), bits,
+                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     got = m.lookup_quantized(idx, off, bits)
     want = orq.quantize_rows(m.lookup(idx, off).cpu().numpy().reshape(-1, 128), bits)
     assert np.array_equal(got.cpu().numpy().reshape(want.shape), want)
     assert rc in (_lib.PM_OK, _lib.PM_ERR_UNSUPPORTED)
+    if rc == _lib.PM_OK:
+        assert np.array_equal(direct.cpu().numpy().reshape(want.shape), want)
     # the layout contract, checked on the device
     err = torch.zeros(1, dtype=torch.int32, device="cuda")
     assert L_.pm_embbag_check_ex(ctypes.byref(op), 1, ctypes.c_void_p(err.data_ptr()), None) == _lib.PM_OK and int(err.item()) == 0
