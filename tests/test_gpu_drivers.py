@@ -16,11 +16,27 @@ DEV = "cuda:0"
 
 
 def _port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """A TCP port for a rendezvous: below the kernel's ephemeral range (32768+), so it cannot collide with the local port
+    of some earlier store client's connection still in TIME_WAIT (seen as EADDRINUSE once in a long GPU suite run), never
+    handed out twice by this process, and bindable right now."""
+    import itertools
+    import os as _os
+
+    global _PORTS
+    try:
+        _PORTS
+    except NameError:
+        _PORTS = itertools.count(12000 + (_os.getpid() * 37) % 18000)
+    for p in _PORTS:
+        p = 12000 + (p - 12000) % 20000
+        s = socket.socket()
+        try:
+            s.bind(("127.0.0.1", p))
+        except OSError:
+            continue
+        finally:
+            s.close()
+        return p
 
 
 def test_compute_pt_driver_gpu_rows():
