@@ -217,8 +217,13 @@ int oracle_embbag_bwd_bf16(uint16_t* dst, float* scratch, int64_t rows, int32_t 
  * `rowwise_adagrad()`; the kernel it generates is `split_rowwise_adagrad_table_update_kernel`), as of the fbgemm_gpu
  * v0.5 - v1.0 line, written down from its documented formulas, NOT from a source or binary that could be run here.
  * PARITY UNPINNED for this routine (no reference output could be generated); the judge-visible consequence is stated in
- * DESIGN.md (sections 0 and 8).  What is pinned: the GPU kernel against THIS restatement (2e-5), and this restatement
- * against an fp64 numpy form of the same formulas (tests/test_gpu_parity.py::test_fused_rowwise_adagrad_vs_oracle).
+ * DESIGN.md (sections 0 and 8).  What is pinned: the GPU kernel against THIS restatement (2e-5), this restatement
+ * against an fp64 numpy form of the same formulas (tests/test_gpu_parity.py::test_fused_rowwise_adagrad_vs_oracle), and -- the
+ * one case a real implementation is available for -- both against torch.optim.Adagrad where row-wise Adagrad degenerates
+ * to the element-wise one (all columns of a row equal: tests/test_oracle.py::
+ * test_oracle_rowwise_adagrad_pinned_to_torch_adagrad_where_rowwise_is_elementwise and its GPU twin): that pins the state
+ * update, the square root / eps placement and the step; the row MEAN over unequal columns, the weight-decay modes and
+ * stochastic rounding remain pinned to formulas only.
  *   per touched row r (each row once per call, duplicates aggregated first = "exact"):
  *     G     = sum over the row's lookups, in lookup order, of psw[j] * grad[bag(j), :]     (fp32)
  *     m[r] += (sum_d G[d]^2) / dim

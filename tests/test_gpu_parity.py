@@ -977,3 +977,35 @@ def test_sorted_backward_more_than_2_31_lookups():
     del idx, grad
     m._ts = None
     torch.cuda.empty_cache()
+
+
+def test_fused_rowwise_adagrad_equals_torch_adagrad_where_rowwise_is_elementwise():
+    """f2, the part that CAN be pinned to a real implementation without fbgemm: with all columns of a row equal, exact row-wise
+    Adagrad is torch.optim.Adagrad per row (tests/test_oracle.py has the same check for the oracle).  Three fused steps on the
+    GPU, two tables, rows hit 0 .. many times per step, Zipf-like duplicates."""
+    from param_amd import BatchedEmbeddingBagMI355
+    from tests.test_oracle import _torch_adagrad_steps
+
+    rng = np.random.default_rng(21)
+    rows, D, B, L, lr, eps = [300, 50], 16, 64, 5, 0.05, 1e-6
+    m = BatchedEmbeddingBagMI355(rows, D, device=DEV, init="normal", seed=2, learning_rate=lr, optimizer="rowwise_adagrad", eps=eps)
+    cols = [rng.standard_normal(r).astype(np.float32) for r in rows]
+    for t, c in enumerate(cols):
+        m.table(t).copy_(torch.from_numpy(np.repeat(c[:, None], D, axis=1)))
+    sums = [[], []]
+    for step in range(3):
+        idx = torch.cat([torch.from_numpy(np.minimum(rng.zipf(1.4, B * L) - 1, r - 6).astype(np.int64)) for r in rows])   # last 5 rows unhit
+        off = torch.arange(2 * B + 1) * L
+        g_bag = (rng.integers(-8, 9, (B, 2)) / 4.0).astype(np.float32)          # dyadic: sums exact in any order
+        grad = torch.from_numpy(np.repeat(g_bag, D, axis=1))                     # [B, 2*D]: table t's columns all g_bag[:, t]
+        m.adagrad_step_(grad.to(DEV), idx.to(DEV), off.to(DEV))
+        for t, r in enumerate(rows):
+            G = np.zeros(r, np.float32)
+            np.add.at(G, idx.numpy()[t * B * L:(t + 1) * B * L], g_bag[np.repeat(np.arange(B), L), t])
+            sums[t].append(G)
+    for t, r in enumerate(rows):
+        w_t, s_t = _torch_adagrad_steps(cols[t], sums[t], lr, eps)
+        gw, gm = m.table(t).cpu().numpy(), m.momentum_table(t).cpu().numpy()
+        assert np.allclose(gm, s_t, rtol=1e-6, atol=0), t
+        assert np.allclose(gw, w_t[:, None], rtol=2e-6, atol=1e-7), t
+        assert np.array_equal(gw[-5:], np.repeat(cols[t][-5:, None], D, axis=1))

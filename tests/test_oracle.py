@@ -152,3 +152,44 @@ def test_oracle_rowwise_adagrad_weight_decay_modes(coracle):
         W64 = corr[:, None] * W0 - mult[:, None] * G
         assert np.allclose(W[touched], W64[touched], rtol=1e-5, atol=1e-6) and np.allclose(mom[touched], m64[touched], rtol=1e-6)
         assert np.array_equal(W[~touched], W0[~touched].astype(np.float32)) and np.array_equal(mom[~touched], m0[~touched].astype(np.float32))
+
+
+def _torch_adagrad_steps(w0, grads, lr, eps):
+    """torch.optim.Adagrad (a real third-party implementation) on a [R, 1] parameter: per row, state += g^2,
+    w -= lr * g / (sqrt(state) + eps) -- what row-wise Adagrad reduces to when every column of a row carries the same
+    gradient (the row mean of G^2 is then g^2)"""
+    import torch
+
+    p = torch.nn.Parameter(torch.from_numpy(w0.astype(np.float32)).reshape(-1, 1).clone())
+    opt = torch.optim.Adagrad([p], lr=lr, eps=eps, initial_accumulator_value=0.0, lr_decay=0.0, weight_decay=0.0)
+    for g in grads:
+        p.grad = torch.from_numpy(g.astype(np.float32)).reshape(-1, 1)
+        opt.step()
+    return p.detach().numpy().reshape(-1), opt.state[p]["sum"].numpy().reshape(-1)
+
+
+def test_oracle_rowwise_adagrad_pinned_to_torch_adagrad_where_rowwise_is_elementwise(coracle):
+    """A PARTIAL pin of the f2 oracle to a real implementation: fbgemm is absent, but with all columns of a row equal
+    (table and gradient) exact row-wise Adagrad IS torch.optim.Adagrad per row -- same state, same step.  Three steps, rows
+    hit 0 .. 5 times per step (the summed gradient is what the optimizer sees), unhit rows untouched.  This pins where the
+    square root, eps, the learning rate's sign and the accumulation sit; the row MEAN over unequal columns and the weight
+    decay modes stay checked against fp64 forms only (parity unpinned for those, as the oracle header says)."""
+    rng = np.random.default_rng(11)
+    R, D, B, L, lr, eps = 40, 8, 16, 3, 0.07, 1e-5
+    w_col = rng.standard_normal(R).astype(np.float32)
+    W = np.repeat(w_col[:, None], D, axis=1).copy()
+    mom = np.zeros(R, np.float32)
+    off = np.arange(B, dtype=np.int64) * L
+    per_step = []
+    for step in range(3):
+        idx = rng.integers(0, R - 5, B * L).astype(np.int64)          # the last 5 rows are never hit
+        g_bag = (rng.integers(-8, 9, B) / 4.0).astype(np.float32)     # dyadic: row sums are exact in fp32, any order
+        g = np.repeat(g_bag[:, None], D, axis=1).copy()
+        coracle.bwd_rowwise_adagrad(W, mom, idx, off, g, None, lr=lr, eps=eps)
+        G = np.zeros(R, np.float32)
+        np.add.at(G, idx, g_bag[np.repeat(np.arange(B), L)])
+        per_step.append(G)
+    w_t, s_t = _torch_adagrad_steps(w_col, per_step, lr, eps)
+    assert np.allclose(mom, s_t, rtol=1e-6, atol=0) and np.allclose(W, w_t[:, None], rtol=2e-6, atol=1e-7)
+    assert np.array_equal(W[-5:], np.repeat(w_col[-5:, None], D, axis=1)) and not mom[-5:].any()
+    assert all(np.array_equal(W[:, 0], W[:, d]) for d in range(1, D))
