@@ -17,7 +17,7 @@ PM_ABI_VERSION = 3
 PM_WD_NONE, PM_WD_L2, PM_WD_DECOUPLE = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libparam_amd.so")
+LIB_PATH = os.environ.get("PARAM_AMD_LIB") or os.path.join(_HERE, "libparam_amd.so")   # PARAM_AMD_LIB: kernel experiments only
 
 # every symbol include/param_amd.h declares (tests/test_capi_symbols.py parses the header
 # and checks this list and the loaded library against it)

@@ -40,7 +40,6 @@ namespace pm {
 namespace {
 
 constexpr int kSortTile = 1024;  // sorted positions per workgroup in step 3 (2048: main +53 us, fix-up -28 us, gpurun s7)
-constexpr int kBatch = 4;        // positions whose loads are issued together per lane group (8: 136 VGPRs, 3 waves/SIMD)
 
 struct ChunkRec;
 
