@@ -1,11 +1,16 @@
 #!/bin/bash
+# experiment: 8192-element sort tiles (512 threads) vs 4096 (256 threads)
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r2z_pytest.log 2>&1
-grep -E "passed|failed|error" gpurun_out/r2z_pytest.log | tail -3
-timeout 600 python bench.py --steps 20 --warmup 5 --workload criteo --no-cpu-baseline > gpurun_out/r2z_bench_criteo.json 2> gpurun_out/r2z_bench_criteo.err
+: > gpurun_out/r2z_rs512.jsonl
+for v in "" _rs512; do
+  echo "{\"lib\": \"$v\"}" >> gpurun_out/r2z_rs512.jsonl
+  PARAM_AMD_LIB=$PWD/param_amd/libparam_amd$v.so timeout 600 python tools/bwd_probe.py --configs "0,1,1,1" >> gpurun_out/r2z_rs512.jsonl 2>> gpurun_out/r2z.err
+done
+PARAM_AMD_LIB=$PWD/param_amd/libparam_amd_rs512.so timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "sorted_backward or full_size_zipf" 2>&1 | tail -3
 python - <<'P'
 import json
-d=json.loads(open("gpurun_out/r2z_bench_criteo.json").read().strip().splitlines()[-1])
-print(d["value"]/1e9, d["roofline"]["frac"], d.get("bwd_scatter_add",{}).get("avg_s_sort_plus_apply"))
+for ln in open("gpurun_out/r2z_rs512.jsonl"):
+    d=json.loads(ln)
+    print(d.get("lib") if "lib" in d else (d["indices"], round(d["sort_ms"],4), round(d["apply_ms"],3), round(d["total_ms"],3), round(d["alg_frac_total"],3)))
 P
