@@ -142,9 +142,16 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
 // own stable LSD radix sort of (key, uint32) pairs (radix_sort.hip); element count optionally read from device memory
 size_t rs_scratch_bytes(size_t n_max);
 int rs_num_passes(int begin_bit, int end_bit);   // result lands in the b buffers iff odd
+struct RsSource {            // first-pass input formed on the fly (sorted backward, per-table segments, fixed pooling)
+    const void* indices;     // the request's index array (int64 or int32)
+    int idx64;
+    int tshift;              // key = segment << tshift | index
+    uint32_t pooling;        // value = position inside the segment / pooling
+};
 template <typename K>
 hipError_t rs_sort_pairs(K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n_max, const uint32_t* d_count,
-                         int begin_bit, int end_bit, void* scratch, hipStream_t stream, size_t seg_len = 0);
+                         int begin_bit, int end_bit, void* scratch, hipStream_t stream, size_t seg_len = 0,
+                         const RsSource* src = nullptr);
 
 // rowquant.hip: row-wise quantisation of fp32 rows (bits 16 / 8 / 4 / 2), dim a multiple of 8
 int64_t rows_quantized_row_bytes(int dim, int bits);

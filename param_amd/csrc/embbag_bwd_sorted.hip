@@ -338,7 +338,7 @@ inline int bits_for(int64_t n_values) {  // bits needed to represent 0 .. n_valu
 //   in H launches.  Everything else (ragged bags, slices, odd sizes) sorts all key bits globally and applies in one launch.
 struct SortPlan {
     int key_bytes, rbits, hbits, tshift, kbits;
-    bool sliced, weighted, rocprim, segmented, in_b, xcd;
+    bool sliced, weighted, rocprim, segmented, in_b, xcd, fused_keys;
     int H;
     int64_t n, seg_len, phase_bags;
     int sort_end_bit;
@@ -372,6 +372,7 @@ SortPlan make_plan(const KParams& p, int64_t max_rows, int64_t fixed_pooling, in
     else if (g.segmented) g.sort_end_bit = g.rbits;              // per (table, phase) segment: rows only
     else g.sort_end_bit = table_major_order() ? g.kbits : g.rbits;
     g.in_b = g.rocprim || (rs_num_passes(0, g.sort_end_bit) % 2 == 1);
+    g.fused_keys = g.segmented && g.H == 1 && !g.weighted && !g.sliced && g.sort_end_bit > 0 && !env_is("PARAM_AMD_SORT_FUSED_KEYS", "0");
     return g;
 }
 
@@ -390,6 +391,14 @@ hipError_t sort_impl(const KParams& p, const SortPlan& g, SortWs& ws, hipStream_
     K* ka = reinterpret_cast<K*>(ws.keys_a);
     K* kb = reinterpret_cast<K*>(ws.keys_b);
     const int64_t s0 = p.bag_begin, s1 = p.bag_begin + p.bag_count;
+    // per-table segments of a fixed-pooling request, one phase, no weights: bag and table of a lookup follow from its
+    // position, so the first radix pass forms the pairs itself from the index array and no key-building kernel runs
+    // (33 us and 126 MB of the benchmark step's 190 us sort; PARAM_AMD_SORT_FUSED_KEYS=0 restores it)
+    if (g.fused_keys) {
+        const RsSource src{p.indices, p.idx64, g.tshift, static_cast<uint32_t>(g.seg_len / p.B)};
+        return rs_sort_pairs<K>(ka, kb, ws.vals_a, ws.vals_b, static_cast<size_t>(p.N), nullptr, 0, g.sort_end_bit, ws.temp, stream,
+                                static_cast<size_t>(g.seg_len), &src);
+    }
     if (g.weighted)
         hipLaunchKernelGGL((build_keys_kernel<K, true>), dim3(grid), dim3(kBlock), lds, stream, q, ka, ws.vals_a,
                            ws.bag_of, g.rbits, g.tshift, g.kbits, g.phase_bags, s0, s1);
@@ -501,10 +510,10 @@ std::string sort_plan_describe(const KParams& p, int64_t max_rows, int64_t fixed
     char buf[512];
     snprintf(buf, sizeof(buf),
              "sort=%s key_bytes=%d rbits=%d hbits=%d kbits=%d sort_bits=%d passes=%d segmented=%d seg_len=%lld phases=%d "
-             "apply_seg_tiles=%d xcd=%d sliced=%d weighted=%d result_in_b=%d",
+             "apply_seg_tiles=%d xcd=%d sliced=%d weighted=%d result_in_b=%d fused_keys=%d",
              g.rocprim ? "rocprim" : "own", g.key_bytes, g.rbits, g.hbits, g.kbits, g.sort_end_bit, passes, g.segmented ? 1 : 0,
              static_cast<long long>(g.segmented ? g.seg_len : 0), g.H, (g.xcd || g.H > 1) ? g.seg_tiles : 0, g.xcd ? 1 : 0,
-             g.sliced ? 1 : 0, g.weighted ? 1 : 0, g.in_b ? 1 : 0);
+             g.sliced ? 1 : 0, g.weighted ? 1 : 0, g.in_b ? 1 : 0, g.fused_keys ? 1 : 0);
     return buf;
 }
 

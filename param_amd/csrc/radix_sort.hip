@@ -48,9 +48,12 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
     return m;
 }
 
-template <typename K>
+// FROM_IDX (first pass of the sorted backward's per-table sort, fixed pooling): the keys are not read from memory but
+// formed from the request's index array -- the digit of the first pass is the low bits of the row id --, which saves
+// the key-building kernel and its 126 MB of traffic (RsSource below).
+template <typename K, bool FROM_IDX>
 __global__ void __launch_bounds__(kRsThreads) rs_hist_kernel(const K* keys, const uint32_t* d_count, uint32_t n_max,
-                                                             int shift, uint32_t mask, uint32_t* bh) {
+                                                             int shift, uint32_t mask, uint32_t* bh, const RsSource src) {
     __shared__ uint32_t h[kRsRadix];
     const uint32_t n = rs_count(d_count, n_max);
     const uint64_t tile0 = static_cast<uint64_t>(blockIdx.x) * kRsTile;
@@ -62,7 +65,9 @@ __global__ void __launch_bounds__(kRsThreads) rs_hist_kernel(const K* keys, cons
     for (int k = 0; k < kRsItems; ++k) {
         const uint64_t i = tile0 + static_cast<uint64_t>(k) * kRsThreads + threadIdx.x;
         const bool valid = i < n;
-        const uint32_t d = valid ? static_cast<uint32_t>(keys[i] >> shift) & mask : 0u;
+        uint32_t d = 0u;
+        if (valid) d = FROM_IDX ? (static_cast<uint32_t>(load_index(src.indices, static_cast<int64_t>(i), src.idx64)) >> shift) & mask
+                                : static_cast<uint32_t>(keys[i] >> shift) & mask;
         // A wave whose 64 keys share the digit (the top digits of a Zipf head, of small tables, of any nearly sorted
         // input) adds once; otherwise one LDS atomic per lane -- distinct digits do not conflict, and the eight-ballot
         // match that would merge the equal ones costs more than the conflicts of a mixed wave (24.8 -> ~10 us per pass).
@@ -150,11 +155,11 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_tmp)
     return base + incl - v;
 }
 
-template <typename K>
+template <typename K, bool FROM_IDX>
 __global__ void __launch_bounds__(kRsThreads) rs_scatter_kernel(const K* kin, const uint32_t* vin, K* kout, uint32_t* vout,
                                                                 const uint32_t* d_count, uint32_t n_max, int shift,
                                                                 uint32_t mask, const uint32_t* prefix, const uint32_t* total,
-                                                                uint32_t seg_tiles) {
+                                                                uint32_t seg_tiles, const RsSource src) {
     __shared__ K s_key[kRsTile];
     __shared__ uint32_t s_val[kRsTile];
     __shared__ uint32_t s_wcnt[kRsWaves][kRsRadix];   // per wave: running digit counts, later the wave's base inside the digit
@@ -176,8 +181,18 @@ __global__ void __launch_bounds__(kRsThreads) rs_scatter_kernel(const K* kin, co
     for (int r = 0; r < kRsItems; ++r) {
         const uint32_t pos = wave * kRsWaveChunk + r * kWave + lane;
         const bool valid = pos < cnt;
-        key[r] = valid ? kin[tile0 + pos] : static_cast<K>(0);
-        val[r] = valid ? vin[tile0 + pos] : 0u;
+        if (FROM_IDX) {
+            // key = (segment = table) << tshift | row; value = the lookup's bag inside its table (segments are whole tables of
+            // B bags with `pooling` lookups each)
+            const uint32_t seg = blockIdx.x / seg_tiles;
+            const uint32_t in_seg = (blockIdx.x % seg_tiles) * static_cast<uint32_t>(kRsTile) + pos;
+            key[r] = valid ? ((static_cast<K>(seg) << src.tshift) |
+                              static_cast<K>(load_index(src.indices, static_cast<int64_t>(tile0 + pos), src.idx64))) : static_cast<K>(0);
+            val[r] = valid ? in_seg / src.pooling : 0u;
+        } else {
+            key[r] = valid ? kin[tile0 + pos] : static_cast<K>(0);
+            val[r] = valid ? vin[tile0 + pos] : 0u;
+        }
     }
     __syncthreads();   // counters zeroed
     uint32_t* wcnt = s_wcnt[wave];
@@ -255,12 +270,18 @@ int rs_num_passes(int begin_bit, int end_bit) {
 // seg_len > 0: the array is a sequence of segments of seg_len elements (a multiple of the 4096-element tile, n_max a
 // multiple of seg_len, no d_count), each sorted on its own -- the backward's tables (x bag phases) when every bag has the
 // same number of lookups: the table bits then need no pass at all.
+// src != nullptr (segments only, begin_bit 0): the FIRST pass forms its pairs from the request's index array instead of
+// reading (keys_a, vals_a), which are then never touched -- key = segment << tshift | index, value = position in the
+// segment / pooling (the bag).
 template <typename K>
 hipError_t rs_sort_pairs(K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n_max, const uint32_t* d_count,
-                         int begin_bit, int end_bit, void* scratch, hipStream_t stream, size_t seg_len) {
+                         int begin_bit, int end_bit, void* scratch, hipStream_t stream, size_t seg_len, const RsSource* src) {
     if (n_max == 0) return hipSuccess;
     if (n_max > 0xffffffffull) return hipErrorInvalidValue;
     if (seg_len && (seg_len % kRsTile || n_max % seg_len || d_count)) return hipErrorInvalidValue;
+    if (src && (!seg_len || begin_bit != 0 || !src->indices || src->pooling == 0 || rs_num_passes(begin_bit, end_bit) == 0))
+        return hipErrorInvalidValue;
+    const RsSource none{nullptr, 0, 0, 1};
     const uint32_t seg_tiles = static_cast<uint32_t>(seg_len / kRsTile);
     const int passes = rs_num_passes(begin_bit, end_bit);
     const int bits = end_bit - begin_bit;
@@ -277,21 +298,29 @@ hipError_t rs_sort_pairs(K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_
         K* kout = (p % 2 == 0) ? keys_b : keys_a;
         const uint32_t* vin = (p % 2 == 0) ? vals_a : vals_b;
         uint32_t* vout = (p % 2 == 0) ? vals_b : vals_a;
-        hipLaunchKernelGGL((rs_hist_kernel<K>), dim3(grid), dim3(kRsThreads), 0, stream, kin, d_count, n32, shift, mask, bh);
+        const bool first_from_idx = src != nullptr && p == 0;
+        if (first_from_idx)
+            hipLaunchKernelGGL((rs_hist_kernel<K, true>), dim3(grid), dim3(kRsThreads), 0, stream, kin, d_count, n32, shift, mask, bh, *src);
+        else
+            hipLaunchKernelGGL((rs_hist_kernel<K, false>), dim3(grid), dim3(kRsThreads), 0, stream, kin, d_count, n32, shift, mask, bh, none);
         if (seg_tiles)
             hipLaunchKernelGGL(rs_scan_seg_kernel, dim3(grid / seg_tiles), dim3(kRsRadix), 0, stream, bh, total, seg_tiles);
         else
             hipLaunchKernelGGL(rs_scan_kernel, dim3(kRsRadix / kScanDigits), dim3(kScanThreads), 0, stream, bh, total, d_count, n32);
-        hipLaunchKernelGGL((rs_scatter_kernel<K>), dim3(grid), dim3(kRsThreads), 0, stream, kin, vin, kout, vout, d_count, n32,
-                           shift, mask, bh, total, seg_tiles);
+        if (first_from_idx)
+            hipLaunchKernelGGL((rs_scatter_kernel<K, true>), dim3(grid), dim3(kRsThreads), 0, stream, kin, vin, kout, vout, d_count, n32,
+                               shift, mask, bh, total, seg_tiles, *src);
+        else
+            hipLaunchKernelGGL((rs_scatter_kernel<K, false>), dim3(grid), dim3(kRsThreads), 0, stream, kin, vin, kout, vout, d_count, n32,
+                               shift, mask, bh, total, seg_tiles, none);
         shift += w;
     }
     return hipGetLastError();
 }
 
 template hipError_t rs_sort_pairs<uint32_t>(uint32_t*, uint32_t*, uint32_t*, uint32_t*, size_t, const uint32_t*, int, int,
-                                            void*, hipStream_t, size_t);
+                                            void*, hipStream_t, size_t, const RsSource*);
 template hipError_t rs_sort_pairs<uint64_t>(uint64_t*, uint64_t*, uint32_t*, uint32_t*, size_t, const uint32_t*, int, int,
-                                            void*, hipStream_t, size_t);
+                                            void*, hipStream_t, size_t, const RsSource*);
 
 }  // namespace pm

@@ -144,9 +144,11 @@ def test_sort_plan_decisions_on_the_host():
     assert bench["sort"] == "own" and bench["key_bytes"] == "4" and bench["rbits"] == "24" and bench["kbits"] == "30"
     assert bench["segmented"] == "1" and bench["seg_len"] == str(8192 * 20) and bench["passes"] == "3" and bench["sort_bits"] == "24"
     assert bench["apply_seg_tiles"] == "160" and bench["xcd"] == "1" and bench["phases"] == "1" and bench["result_in_b"] == "1"
+    assert bench["fused_keys"] == "1"                                 # no key-building kernel: the first radix pass reads the indices
+    assert _plan(L, 48, 8192, 20, 10_000_000, weighted=True)["fused_keys"] == "0"      # weights need the position as the value
     ragged = _plan(L, 48, 8192, 20, 10_000_000, fixed=False)          # no fixed-pooling claim: all key bits, global, linear tiles
     assert ragged["segmented"] == "0" and ragged["sort_bits"] == "30" and ragged["passes"] == "4" and ragged["xcd"] == "0"
-    assert ragged["apply_seg_tiles"] == "0" and ragged["result_in_b"] == "0"
+    assert ragged["apply_seg_tiles"] == "0" and ragged["result_in_b"] == "0" and ragged["fused_keys"] == "0"
     sliced = _plan(L, 48, 8192, 20, 10_000_000, slice_=(100, 50))     # batch slice: padding keys must sort last
     assert sliced["sliced"] == "1" and sliced["sort_bits"] == "31" and sliced["segmented"] == "0" and sliced["xcd"] == "0"
     odd = _plan(L, 5, 100, 7, 1000)                                   # fixed pooling, nothing tile-aligned
@@ -160,7 +162,7 @@ def test_sort_plan_decisions_on_the_host():
     assert L.pm_set_backward_tuning(-1, -1, -1, 2) == _lib.PM_OK
     two = _plan(L, 48, 8192, 20, 10_000_000, phases=2)
     assert two["phases"] == "2" and two["hbits"] == "1" and two["kbits"] == "31" and two["seg_len"] == str(4096 * 20)
-    assert two["apply_seg_tiles"] == "80" and two["key_bytes"] == "4"
+    assert two["apply_seg_tiles"] == "80" and two["key_bytes"] == "4" and two["fused_keys"] == "0"
     assert _plan(L, 48, 8192, 20, 10_000_000, phases=1)["phases"] == "1"
     # row order: only the row bits, no segments, no XCD mapping; rocPRIM: no segments either
     assert L.pm_set_backward_tuning(-1, 0, -1, -1) == _lib.PM_OK

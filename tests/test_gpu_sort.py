@@ -249,3 +249,34 @@ def test_random_fixed_pooling_requests_under_random_tuning(coracle, seed):
             assert (np.abs(got - truth) <= tol).all(), (seed, t, knobs, T, B, L, D, rows[t])
     finally:
         param_amd.set_backward_tuning()
+
+
+@pytest.mark.parametrize("idx_dtype", [torch.int64, torch.int32])
+def test_first_pass_reading_the_indices_equals_the_key_building_kernel(idx_dtype, monkeypatch):
+    """per-table segments, one phase, no weights: the first radix pass forms (key, bag) from the index array itself
+    (no build_keys launch).  Same sorted pairs, hence bit-identical tables, as with PARAM_AMD_SORT_FUSED_KEYS=0 -- for
+    both index types, table counts that are / are not multiples of 8, fp32 and bf16 tables, SGD and Adagrad."""
+    from param_amd import BatchedEmbeddingBagMI355, _lib
+    from param_amd.indices import tbe_request
+
+    for T, B, L, dtype, opt in ((5, 2048, 8, torch.float32, "sgd"), (8, 4096, 20, torch.bfloat16, "sgd"),
+                                (3, 1024, 4, torch.float32, "rowwise_adagrad")):
+        rows = [50_000 + 7 * t for t in range(T)]
+        idx, off = tbe_request(rows, B, L, alpha=1.05, device=DEV, seed=T, index_dtype=idx_dtype)
+        grad = torch.randn(B, T * 64, device=DEV)
+        results = []
+        for fused in ("1", "0"):
+            monkeypatch.setenv("PARAM_AMD_SORT_FUSED_KEYS", fused)
+            m = BatchedEmbeddingBagMI355(rows, 64, dtype=dtype, device=DEV, init="normal", seed=9, learning_rate=0.05, optimizer=opt)
+            plan = ctypes.create_string_buffer(512)
+            op = m._tables().request(idx, off, B, None, 0, None)
+            op.fixed_pooling = L
+            assert _lib.load().pm_embbag_sort_plan(ctypes.byref(op), max(rows), 1, plan, 512) == _lib.PM_OK
+            assert f"fused_keys={fused}".encode() in plan.value and b"segmented=1" in plan.value
+            if opt == "sgd":
+                m.scatter_add_(grad, idx, off, alpha=-0.05, batch=B)
+                results.append([m.table(t).clone() for t in range(T)])
+            else:
+                m.adagrad_step_(grad, idx, off, batch=B)
+                results.append([m.table(t).clone() for t in range(T)] + [m.momentum_table(t).clone() for t in range(T)])
+        assert all(torch.equal(a, b) for a, b in zip(*results)), (T, dtype, opt)
