@@ -488,7 +488,8 @@ class BatchedEmbeddingBagMI355(nn.Module):
         """Forward with a row-wise quantised output (``bitwidth`` 16 / 8 / 4 / 2): one quantised row per pooled vector,
         uint8 ``(B, T, row_bytes)`` (``(T, B, row_bytes)`` for the ``tbd`` layout) -- the payload of a quantised
         all-to-all (the reference's ``--bitwidth``), written by the lookup kernel itself.  ``param_amd.quant.
-        dequantize_rows`` restores fp32; the bytes equal ``quantize_rows(lookup(...))``."""
+        dequantize_rows`` restores fp32; the bytes equal ``quantize_rows(lookup(...))``.  Whole-batch requests the staged
+        kernel does not take (ragged bags) run as lookup + quantiser; a batch SLICE of such a request raises (PM_ERR_UNSUPPORTED)."""
         _require_device(self.weights, "BatchedEmbeddingBagMI355.weights")
         B = self._batch_of(offsets, indices) if batch is None else batch
         return _fwd_quantized(self._tables(), indices, offsets, B, bitwidth, per_sample_weights, out, bag_begin, bag_count)
