@@ -341,8 +341,11 @@ def main():
         else:
             fit = int((free - (40 << 30)) // (R * D * esize))  # headroom for outputs, gradients, sort scratch
             T_loc = min(a.tables, fit)
-            if T_loc >= 8:
-                T_loc = T_loc // 8 * 8  # keep the XCD-affine mapping (table t -> XCD t % 8)
+            if T_loc < a.tables and T_loc >= 8:
+                # capacity-limited (64 fp32 tables do not fit): round the count that fits down to a multiple of 8, which keeps
+                # the forward's table -> XCD mapping.  A workload that FITS keeps its table count (26 tables = BASELINE
+                # configs[3]: 133 GB) and the forward then runs with the plain block -> tile mapping.
+                T_loc = T_loc // 8 * 8
         split = [T_loc]
     else:
         split = table_split(a.tables, world)          # reference partition (dlrm.py:390-398); uneven when T % W != 0
@@ -443,7 +446,8 @@ def main():
     wl += f"Zipf alpha={a.alpha} (reference pmf, per-bag dedupe)"
     if world == 1 and T_loc < a.tables:
         wl += (f"; 1 GPU holds {T_loc} of {a.tables} tables ({T_loc * table_bytes / 1e9:.1f} GB): "
-               f"{a.tables} x {table_bytes / 1e9:.2f} GB exceeds 288 GB HBM")
+               f"{a.tables} x {table_bytes / 1e9:.2f} GB = {a.tables * table_bytes / 1e9:.1f} GB exceeds the {free / 1e9:.0f} GB of "
+               f"free HBM minus 40 GB of working space")
     if world > 1:
         wl += (f"; table-wise sharded {split} tables/GPU (dlrm.py:390-398), global batch {B_glob}, one pooled all-to-all per "
                f"step on the RCCL stream, 2 steps in flight (exchange of step k under the lookup of step k+1)")

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PM_ABI_VERSION 3
+#define PM_ABI_VERSION 4
 
 typedef void* pm_stream_t;
 
@@ -83,7 +83,9 @@ typedef struct pm_embbag_batch {
     const void* indices;          /* device [N] */
     const void* offsets;          /* device [T*B] or [T*B+1] */
     const float* per_sample_weights; /* device [N] or NULL */
-    int64_t fixed_pooling;        /* L > 0: the caller GUARANTEES every bag has exactly L lookups (offsets[i] == i * L,
+    int64_t fixed_pooling;        /* (ABI v4: only the sort_impl 1 / 2 alternatives read it; the default sort establishes every
+                                     table's pooling on the device by reading the offsets.)
+                                     L > 0: the caller GUARANTEES every bag has exactly L lookups (offsets[i] == i * L,
                                      num_indices == T * B * L) -- what every benchmark request of the reference looks like;
                                      0: bags may be ragged.  A hint that changes speed only: the sorted backward then knows
                                      where each table's lookups start without reading device memory (per-table sort segments,
@@ -175,6 +177,14 @@ int pm_embbag_sort_plan(const pm_embbag_batch* op, int64_t max_rows, int32_t pha
 int pm_embbag_bwd_sorted(const pm_embbag_batch* op, const float* grad, void* const* dst_tables,
                          int32_t dst_dtype, float alpha, int64_t max_rows, const void* workspace,
                          int64_t workspace_bytes, pm_stream_t stream);
+/*
+ * ABI v4, host-only, for tests and tools: where the last pm_embbag_sort_indices* on this workspace left its pairs.
+ * *keys / *vals: device pointers into the workspace (keys of *key_bytes bytes: table << *tshift | row; values: bag within
+ * the table, or the lookup position for weighted requests); *d_count: device uint32 holding the number of pairs (batch
+ * slices sort only their own lookups), or NULL when it is num_indices.  Valid until the next sort on the workspace.
+ */
+int pm_embbag_sorted_pairs(const pm_embbag_batch* op, int64_t max_rows, const void* workspace, const void** keys,
+                           const uint32_t** vals, const uint32_t** d_count, int32_t* key_bytes, int32_t* tshift);
 
 /*
  * Fused backward + exact row-wise Adagrad (the optimizer the reference configures for its TBE ops,
@@ -276,8 +286,12 @@ int pm_set_forward_tuning(int32_t stage_out);
 /*
  * Tuning knobs of the sorted backward (process-wide; -1 = default, which the environment can change:
  * PARAM_AMD_SORT=rocprim, PARAM_AMD_SORT_ORDER=row, PARAM_AMD_BWD_XCD=0, PARAM_AMD_BWD_PHASES=2):
- *   sort_impl   0 (default): the build's own radix sort (pm_radix_sort_pairs), 1: rocPRIM's radix_sort_pairs (kept
- *               as the measured alternative)
+ *   sort_impl   0 (default): the segmented sort of round 3 -- per-table segments, per-table pooling factors and (for batch
+ *               slices) the pair count are established ON THE DEVICE from the offsets, so ragged / multi-hot / sliced /
+ *               weighted requests take the same fast path as fixed-pooling ones and the fixed_pooling field of the request is
+ *               not needed (nor trusted); 1: rocPRIM's radix_sort_pairs; 2: round 2's own LSD sort with host-side plans
+ *               (pm_radix_sort_pairs; uses fixed_pooling) -- 1 and 2 are kept as measured alternatives and cross-checks.
+ *               order / max_phases below apply to 1 and 2 only; xcd_affine to all (sort_impl 0: XCD-contiguous tiles)
  *   order       1 (default): pairs ordered by (table, [bag phase,] row, position); 0: (row, table, position) -- only
  *               the row bits are sorted, the request being table-major already (one radix pass fewer, a slower apply)
  *   xcd_affine  1 (default; needs order 1 and a fixed-pooling request): the apply kernel's tiles of table t run on
@@ -290,6 +304,19 @@ int pm_set_forward_tuning(int32_t stage_out);
  * Settings are read when a request is SORTED; its apply follows what the sort recorded.
  */
 int pm_set_backward_tuning(int32_t sort_impl, int32_t order, int32_t xcd_affine, int32_t max_phases);
+
+/*
+ * ABI v4.  How the segmented key sort (sort_impl 0) orders a table's pairs (-1 = default; PARAM_AMD_SORT_MODE in the
+ * environment changes the default):
+ *   0  LSD passes over all row bits: (table, row, position) order, ceil(row bits / 8) global passes
+ *   1  ONE global partition pass on the low row digit, then every (table, digit) bucket is sorted by its remaining bits
+ *      inside LDS: (table, row & 255, row >> 8, position) order -- equal rows adjacent and in request order, which is all
+ *      the apply kernel needs; buckets stay balanced under any skew
+ *   2  the same with the partition on the TOP row digit: ascending rows; a skewed head makes its bucket large
+ * Speed only: every mode gives the same tables for rows looked up at most 256 times (longer runs: same value up to fp32
+ * association, as documented at pm_embbag_bwd_sorted).
+ */
+int pm_set_sort_tuning(int32_t mode);
 
 /*
  * Forward with a row-wise QUANTISED output: the pooled vector of (bag b, table t) is written as one quantised row

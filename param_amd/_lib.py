@@ -13,7 +13,7 @@ import threading
 
 PM_F32, PM_BF16, PM_F16, PM_I32, PM_I64 = 0, 1, 2, 10, 11
 PM_OK, PM_ERR_INVALID, PM_ERR_UNSUPPORTED, PM_ERR_HIP, PM_ERR_INDEX = 0, -1, -2, -3, -4
-PM_ABI_VERSION = 3
+PM_ABI_VERSION = 4
 PM_WD_NONE, PM_WD_L2, PM_WD_DECOUPLE = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = (
     "pm_embbag_sort_indices",
     "pm_embbag_sort_indices_ex",
     "pm_embbag_sort_plan",
+    "pm_embbag_sorted_pairs",
     "pm_embbag_fwd_quantized",
     "pm_embbag_check_ex",
     "pm_rows_quantized_bytes",
@@ -46,6 +47,7 @@ EXPORTED_SYMBOLS = (
     "pm_set_tuning",
     "pm_set_forward_tuning",
     "pm_set_backward_tuning",
+    "pm_set_sort_tuning",
     "pm_radix_sort_scratch_bytes",
     "pm_radix_sort_pairs",
 )
@@ -167,6 +169,11 @@ def load() -> ctypes.CDLL:
         L.pm_set_forward_tuning.argtypes = [i32]
         L.pm_set_backward_tuning.restype = ctypes.c_int
         L.pm_set_backward_tuning.argtypes = [i32, i32, i32, i32]
+        L.pm_embbag_sorted_pairs.restype = ctypes.c_int
+        L.pm_embbag_sorted_pairs.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, vp, ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                             ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32)]
+        L.pm_set_sort_tuning.restype = ctypes.c_int
+        L.pm_set_sort_tuning.argtypes = [i32]
         L.pm_radix_sort_scratch_bytes.restype = ctypes.c_int64
         L.pm_radix_sort_scratch_bytes.argtypes = [i64]
         L.pm_radix_sort_pairs.restype = ctypes.c_int
@@ -192,6 +199,27 @@ def set_forward_tuning(stage_out: int = -1) -> None:
 
 
 def set_backward_tuning(sort_impl: int = -1, order: int = -1, xcd_affine: int = -1, max_phases: int = -1) -> None:
-    """sorted-backward knobs (``pm_set_backward_tuning``): sort_impl 0 own / 1 rocPRIM, order 1 (table, row) / 0 (row,
-    table), xcd_affine 1 / 0, max_phases 2 / 1; -1 = default.  Read when a request is sorted; its apply follows the sort."""
+    """sorted-backward knobs (``pm_set_backward_tuning``): sort_impl 0 segmented sort (segments / pooling established on the
+    device) / 1 rocPRIM / 2 round 2's own LSD sort with host-side plans, order 1 (table, row) / 0 (row, table) and
+    max_phases 2 / 1 for sort_impl 1 and 2, xcd_affine 1 / 0; -1 = default.  Read when a request is sorted; its apply follows."""
+    global _sort_impl
     check(load().pm_set_backward_tuning(sort_impl, order, xcd_affine, max_phases))
+    _sort_impl = sort_impl
+
+
+_sort_impl = -1
+
+
+def needs_pooling_hint() -> bool:
+    """True when the selected key sort is one of the alternatives that read ``pm_embbag_batch.fixed_pooling`` (sort_impl 1 /
+    2, by knob or ``PARAM_AMD_SORT``); the default segmented sort establishes pooling on the device and the Python layer then
+    neither computes nor caches a verdict about the offsets' contents"""
+    if _sort_impl >= 0:
+        return _sort_impl != 0
+    return os.environ.get("PARAM_AMD_SORT", "") in ("rocprim", "legacy")
+
+
+def set_sort_tuning(mode: int = -1) -> None:
+    """``pm_set_sort_tuning``: segmented sort mode 0 LSD passes / 1 low-digit partition + bucket-local LDS sort / 2 top-digit
+    partition + local sort; -1 = default"""
+    check(load().pm_set_sort_tuning(mode))

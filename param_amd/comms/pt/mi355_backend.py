@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import logging
 import os
+from itertools import cycle
 from time import sleep
 
 import numpy as np
@@ -133,8 +134,10 @@ class MI355XBackend(backendFunctions):
         out.view(-1).copy_(d.reshape(-1))
         return out
 
-    def _wants_quant_a2a(self, collectiveArgs, ip, op, pair) -> bool:
-        """the reference's test (pytorch_dist_backend.py:262-272): armed, float32, at or above the threshold, not pair mode"""
+    def _wants_quant_a2a(self, collectiveArgs, ip, op, pair, threshold: bool = True) -> bool:
+        """the reference's test (pytorch_dist_backend.py:262-272): armed, float32, at or above the threshold, not pair mode.
+        ``threshold=False``: the list-form all_to_all, which the reference quantises whenever the flag is set (:211); only
+        float32 payloads have a row-wise format, so the dtype test stays."""
         bits = getattr(collectiveArgs, "all2all_qcomm", None)
         if not bits or int(bits) >= 32 or pair:
             return False
@@ -142,6 +145,8 @@ class MI355XBackend(backendFunctions):
         ops = op if isinstance(op, (list, tuple)) else [op]
         if any(t.dtype != torch.float32 for t in ips):
             return False
+        if not threshold:
+            return True
         thr = getattr(collectiveArgs, "quant_threshold", 0)
         return sum(t.numel() for t in ops) >= thr or sum(t.numel() for t in ips) >= thr
 
@@ -182,7 +187,14 @@ class MI355XBackend(backendFunctions):
 
         def restore():
             if out_list is None:
-                self._dequantize_rows(q_out, dim, bits, op.reshape(-1)[:sum(osp)])
+                if op.is_contiguous():
+                    self._dequantize_rows(q_out, dim, bits, op.view(-1)[:sum(osp)])
+                else:   # reshape() of a non-contiguous tensor is a copy: restore into a flat buffer, then write back
+                    flat = torch.empty(sum(osp), dtype=op.dtype, device=op.device)
+                    self._dequantize_rows(q_out, dim, bits, flat)
+                    full = op.reshape(-1)
+                    full[:sum(osp)] = flat
+                    op.copy_(full.view(op.shape))
             else:
                 o = 0
                 for t, nb in zip(out_list, qo):
@@ -261,11 +273,13 @@ class MI355XBackend(backendFunctions):
         ``extend_distributed`` package for this branch, ``pytorch_dist_backend.py:214``) it is the pipelined
         lookup -> pooled all-to-all instead."""
         ip, op = self._io(collectiveArgs, pair, pairIdx)
+        # branch order of the reference (pytorch_dist_backend.py:211-214): quantisation first -- for the list form it is
+        # armed by the flag alone, no size threshold (:262-272 has one only for all_to_allv) --, then the batched lookup
+        if self._wants_quant_a2a(collectiveArgs, ip, op, pair, threshold=False):
+            return self._quantized_all_to_all(collectiveArgs, ip, op, None, None, retFlag)
         if (not pair and collectiveArgs.num_emb_tables_batched > 0 and collectiveArgs.emb is not None
                 and (self.use_ext_dist or self.fused_lookup_a2a)):
             return self.lookup_all_to_all(collectiveArgs, retFlag)
-        if self._wants_quant_a2a(collectiveArgs, ip, op, pair):
-            return self._quantized_all_to_all(collectiveArgs, ip, op, None, None, retFlag)
         if isinstance(op, (list, tuple)):
             if dist.get_backend(self._group(collectiveArgs)) == "gloo":
                 # gloo has no list-form alltoall (reference survey probe): flatten to the single-tensor form
@@ -684,6 +698,7 @@ class MI355XBackend(backendFunctions):
                                     device_id=self.get_device() if (eager_mode and self._is_gpu()) else None)
         self.groups = {0: self.get_default_group()}
         self.num_pgs = 1
+        self.round_robin_group = cycle(list(self.groups.values()))     # reference :1200
 
     def initialize_groups(self, groupRanks=None, backend="nccl", force_new_group=False):
         groups = {}
@@ -695,6 +710,7 @@ class MI355XBackend(backendFunctions):
         if groups:
             self.groups = groups
         self.num_pgs = len(self.groups)
+        self.round_robin_group = cycle(list(self.groups.values()))     # reference :1251: get_next_group() walks the groups
 
     def benchmark_comms(self, benchTime, commsParams) -> None:
         if getattr(commsParams, "init_only", False):

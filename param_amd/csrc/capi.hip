@@ -184,10 +184,16 @@ int pm_set_forward_tuning(int32_t stage_out) {
 }
 
 int pm_set_backward_tuning(int32_t sort_impl, int32_t order, int32_t xcd_affine, int32_t max_phases) {
-    if (sort_impl < -1 || sort_impl > 1 || order < -1 || order > 1 || xcd_affine < -1 || xcd_affine > 1)
-        return fail(PM_ERR_INVALID, "sort_impl / order / xcd_affine must be -1, 0 or 1");
+    if (sort_impl < -1 || sort_impl > 2 || order < -1 || order > 1 || xcd_affine < -1 || xcd_affine > 1)
+        return fail(PM_ERR_INVALID, "sort_impl must be -1 .. 2, order / xcd_affine -1, 0 or 1");
     if (max_phases != -1 && max_phases != 1 && max_phases != 2) return fail(PM_ERR_INVALID, "max_phases must be -1, 1 or 2");
     pm::set_backward_tuning(sort_impl, order, xcd_affine, max_phases);
+    return PM_OK;
+}
+
+int pm_set_sort_tuning(int32_t mode) {
+    if (mode < -1 || mode > 2) return fail(PM_ERR_INVALID, "mode must be -1, 0, 1 or 2");
+    pm::set_sort_tuning(mode);
     return PM_OK;
 }
 
@@ -372,6 +378,21 @@ int pm_embbag_sort_plan(const pm_embbag_batch* op, int64_t max_rows, int32_t pha
     if ((rc = sorted_args_ok(op, max_rows)) != PM_OK) return rc;
     const std::string d = pm::sort_plan_describe(p, max_rows, op->fixed_pooling, phases);
     snprintf(out, static_cast<size_t>(out_bytes), "%s", d.c_str());
+    return PM_OK;
+}
+
+int pm_embbag_sorted_pairs(const pm_embbag_batch* op, int64_t max_rows, const void* workspace, const void** keys,
+                           const uint32_t** vals, const uint32_t** d_count, int32_t* key_bytes, int32_t* tshift) {
+    pm::KParams p;
+    int rc = make_params(op, op ? op->weight_dtype : -1, p);
+    if (rc != PM_OK) return rc;
+    if ((rc = sorted_args_ok(op, max_rows)) != PM_OK) return rc;
+    if (!workspace || !keys || !vals || !d_count || !key_bytes || !tshift) return fail(PM_ERR_INVALID, "NULL argument");
+    int kb = 0, ts = 0;
+    if (pm::sorted_pairs_info(p, max_rows, op->max_dim, workspace, keys, vals, d_count, &kb, &ts) != 0)
+        return fail(PM_ERR_INVALID, "no sort has been recorded for this workspace");
+    *key_bytes = kb;
+    *tshift = ts;
     return PM_OK;
 }
 

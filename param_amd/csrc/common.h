@@ -135,6 +135,8 @@ hipError_t sorted_workspace_bytes(const KParams& p, int64_t max_rows, int max_di
 hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, int64_t fixed_pooling, int phases, void* workspace,
                         hipStream_t stream);
 int bwd_sorted_plan_check(const KParams& p, int64_t max_rows, const void* workspace, bool adagrad);
+int sorted_pairs_info(const KParams& p, int64_t max_rows, int max_dim, const void* workspace, const void** keys, const uint32_t** vals,
+                      const uint32_t** d_count, int* key_bytes, int* tshift);
 std::string sort_plan_describe(const KParams& p, int64_t max_rows, int64_t fixed_pooling, int phases);
 hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, int max_dim, const void* workspace,
                             float* const* momentum, const pm_rowwise_adagrad* opt, hipStream_t stream);
@@ -153,11 +155,44 @@ hipError_t rs_sort_pairs(K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_
                          int begin_bit, int end_bit, void* scratch, hipStream_t stream, size_t seg_len = 0,
                          const RsSource* src = nullptr);
 
+// seg_sort.hip: the sorted backward's key sort over per-table segments established on the device
+constexpr int kSegSortMaxTables = 1024;
+struct SegDesc {             // one per table, written by the sort's prep kernels (device memory, inside the sort scratch)
+    uint32_t in_start;       // first lookup of the (sliced) table in the request's index array
+    uint32_t count;          // lookups of the (sliced) table
+    uint32_t out_start;      // first position of the table's pairs in the sorted arrays (compact: sum of the counts before)
+    uint32_t pooling;        // > 0: every bag of the (sliced) table has exactly this many lookups -- established by reading the offsets
+    uint32_t tile_base;      // first 4096-element radix tile of the segment
+    uint32_t ntiles;
+    uint32_t rbits;          // bits of this table's row ids
+    uint32_t pad;
+};
+struct SegSortRequest {
+    const void* indices;
+    const void* offsets;
+    const int64_t* rows;     // device [T]
+    int idx64;
+    int T;
+    int64_t B, N, bag_begin, bag_count;
+    int tshift;              // key = table << tshift | row
+    int rbits_max;           // bits_for(max_rows): the number of global passes of mode 0
+    bool weighted;           // values = lookup positions (+ bag_of), every table through the key-building kernel
+};
+size_t seg_sort_scratch_bytes(size_t n_max, int T);
+int seg_sort_passes(int mode, int rbits_max);
+bool seg_sort_result_in_b(int mode, int rbits_max);
+const SegDesc* seg_sort_desc(const void* scratch, size_t n_max, int T);
+const uint32_t* seg_sort_count(const void* scratch, size_t n_max, int T);   // device uint32: pairs in the sorted arrays
+template <typename K>
+hipError_t seg_sort_pairs(const SegSortRequest& rq, int mode, K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t* bag_of,
+                          void* scratch, hipStream_t stream);
+
 // rowquant.hip: row-wise quantisation of fp32 rows (bits 16 / 8 / 4 / 2), dim a multiple of 8
 int64_t rows_quantized_row_bytes(int dim, int bits);
 hipError_t launch_rows_quantize(const float* src, int64_t n_rows, int dim, int bits, void* dst, hipStream_t stream);
 hipError_t launch_rows_dequantize(const void* src, int64_t n_rows, int dim, int bits, float* dst, hipStream_t stream);
 void set_backward_tuning(int sort_impl, int order, int xcd, int max_phases);   // -1 = default (environment)
+void set_sort_tuning(int mode);                                                // segmented sort: -1 default, 0 / 1 / 2
 
 // DLRM input redistribution (dlrm_regroup.hip)
 hipError_t launch_dlrm_regroup(const int64_t* lengths, const int64_t* indices, int W, int F, int64_t B,

@@ -39,6 +39,7 @@
 namespace pm {
 namespace {
 
+constexpr int kDefaultSortMode = 0;
 constexpr int kSortTile = 1024;  // sorted positions per workgroup in step 3 (2048: main +53 us, fix-up -28 us, gpurun s7)
 
 struct ChunkRec;
@@ -74,7 +75,8 @@ struct SortedParams {
     int32_t seg_tiles;       // > 0: the sorted array is T * H equal segments of this many tiles (fixed pooling)
     int32_t H;               // bag phases (1 or 2): segments are (table, phase), one apply launch per phase
     int32_t phase;           // phase this launch applies
-    int32_t xcd;             // 1: XCD-affine block -> tile mapping (needs seg_tiles)
+    int32_t xcd;             // 1: XCD-affine block -> tile mapping (needs seg_tiles); 2: XCD-contiguous (any request)
+    const uint32_t* d_n;     // not NULL: the number of sorted pairs lives on the device (<= n), written by the segmented sort
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -126,14 +128,18 @@ __global__ void __launch_bounds__(kBlock) build_keys_kernel(const KParams p, K* 
 // once per call, so it should not displace the gradient rows that ARE re-read from L2)
 // cache policy of the destination-row accesses (SortedParams::nt_rows, pm_set_tuning nt_loads): 0 default, 1 non-temporal
 // (nt), 2 system scope (volatile: sc0 sc1 -- misses the non-coherent caches on the way in, writes through on the way out)
+// 3 / 4: plain / non-temporal load, agent-scope (sc1) store -- the store writes through and DROPS the line from the XCD's L2
+// (MI355X_MICROARCH.md, store flavours), so a row occupies L2 only between its load and its store and the re-read gradient
+// rows keep the capacity
 __device__ __forceinline__ u32x4 raw16_load(const char* p, int pol) {
     const PM_GLOBAL u32x4* q = as_global<u32x4>(p);   // global, not flat (common.h)
     if (pol == 2) return *reinterpret_cast<const volatile PM_GLOBAL u32x4*>(q);
-    return pol == 1 ? __builtin_nontemporal_load(q) : *q;
+    return (pol == 1 || pol == 4) ? __builtin_nontemporal_load(q) : *q;
 }
 __device__ __forceinline__ void raw16_store(char* p, const u32x4 v, int pol) {
     PM_GLOBAL u32x4* q = as_global<u32x4>(p);
     if (pol == 2) *reinterpret_cast<volatile PM_GLOBAL u32x4*>(q) = v;
+    else if (pol >= 3) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(q), "v"(v) : "memory");
     else if (pol == 1) __builtin_nontemporal_store(v, q);
     else *q = v;
 }
@@ -287,7 +293,23 @@ int knob(std::atomic<int>& k, int env_default) {
     }
     return v;
 }
-bool use_rocprim_sort() { return knob(g_sort_impl, env_is("PARAM_AMD_SORT", "rocprim")) == 1; }
+// sort_impl: 0 (default) the segmented sort of round 3 (seg_sort.hip: per-table segments established on the device);
+//            1 rocPRIM radix_sort_pairs (PARAM_AMD_SORT=rocprim); 2 round 2's own LSD sort with host-side plans
+//            (PARAM_AMD_SORT=legacy) -- both kept as measured alternatives and as independent checks of the new path
+int sort_impl_knob() { return knob(g_sort_impl, env_is("PARAM_AMD_SORT", "rocprim") ? 1 : env_is("PARAM_AMD_SORT", "legacy") ? 2 : 0); }
+bool use_rocprim_sort() { return sort_impl_knob() == 1; }
+// how the segmented sort orders a table's pairs (pm_set_sort_tuning, PARAM_AMD_SORT_MODE): 0 LSD passes over all row bits
+// (ascending rows), 1 one partition pass on the low row digit + bucket-local sort in LDS, 2 the same on the top digit
+std::atomic<int> g_sort_mode{-1};
+int sort_mode_knob() {
+    int v = g_sort_mode.load();
+    if (v < 0) {
+        const char* e = getenv("PARAM_AMD_SORT_MODE");
+        v = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : kDefaultSortMode;
+        g_sort_mode.store(v);
+    }
+    return v;
+}
 bool table_major_order() { return knob(g_sort_order, env_is("PARAM_AMD_SORT_ORDER", "row") ? 0 : 1) == 1; }
 bool want_xcd() { return knob(g_bwd_xcd, env_is("PARAM_AMD_BWD_XCD", "0") ? 0 : 1) == 1; }
 //   max_phases 1 (default): one apply launch; 2: a phases = 2 sort lays a fixed-pooling request out for the two-phase
@@ -296,13 +318,17 @@ bool want_xcd() { return knob(g_bwd_xcd, env_is("PARAM_AMD_BWD_XCD", "0") ? 0 : 
 //              L2 -- 1 KB of row traffic streams through for every 512 B gradient row)              PARAM_AMD_BWD_PHASES=2
 int max_phases() { return knob(g_max_phases, env_is("PARAM_AMD_BWD_PHASES", "2") ? 2 : 1); }
 
-hipError_t ws_layout(void* base, int64_t n, int key_bytes, int kbits_sort, bool weighted, int max_dim, SortWs& ws) {
+hipError_t ws_layout(void* base, int64_t n, int T, int key_bytes, int kbits_sort, bool weighted, int max_dim, SortWs& ws) {
     size_t tb = 0;
     hipError_t rc = key_bytes == 4 ? rocprim_temp_bytes<uint32_t>(n, kbits_sort > 32 ? 32 : kbits_sort, tb)
                                    : rocprim_temp_bytes<uint64_t>(n, kbits_sort, tb);
     if (rc != hipSuccess) return rc;
     const size_t own = rs_scratch_bytes(static_cast<size_t>(n));
     if (own > tb) tb = own;
+    if (T <= kSegSortMaxTables) {
+        const size_t seg = seg_sort_scratch_bytes(static_cast<size_t>(n), T);
+        if (seg > tb) tb = seg;
+    }
     char* p = reinterpret_cast<char*>(base);
     size_t off = 0;
     auto take = [&](size_t bytes) { char* q = p ? p + off : nullptr; off += align256(bytes); return q; };
@@ -344,6 +370,13 @@ struct SortPlan {
     int sort_end_bit;
     int32_t seg_tiles;   // apply tiles (kSortTile) per segment, 0 = no segment structure
     int32_t T;
+    bool v2;             // sorted by seg_sort.hip: segments, pooling and the pair count live on the device
+    int mode;            // seg_sort mode (0 LSD passes, 1 / 2 partition + bucket-local sort)
+    // what the sort was issued for: the apply must follow with the same request on the same workspace
+    const void* indices;
+    const void* offsets;
+    int64_t B, bag_begin, bag_count;
+    uint64_t stamp;
 };
 
 SortPlan make_plan(const KParams& p, int64_t max_rows, int64_t fixed_pooling, int phases) {
@@ -354,6 +387,31 @@ SortPlan make_plan(const KParams& p, int64_t max_rows, int64_t fixed_pooling, in
     g.sliced = !(p.bag_begin == 0 && p.bag_count == p.B);
     g.weighted = p.psw != nullptr;
     g.rocprim = use_rocprim_sort();
+    g.indices = p.indices;
+    g.offsets = p.offsets;
+    g.B = p.B;
+    g.bag_begin = p.bag_begin;
+    g.bag_count = p.bag_count;
+    g.stamp = 0;
+    g.v2 = sort_impl_knob() == 0 && p.T <= kSegSortMaxTables;
+    g.mode = sort_mode_knob();
+    if (g.v2) {
+        // one plan for every request: the device establishes segments, per-table pooling and (for slices) the pair count
+        g.H = 1;
+        g.hbits = 0;
+        g.tshift = g.rbits;
+        g.kbits = g.tshift + bits_for(p.T);
+        g.key_bytes = (g.kbits + 1 <= 32) ? 4 : 8;      // one spare bit: the apply kernel's "no neighbour" sentinel
+        g.phase_bags = 0;
+        g.seg_len = 0;
+        g.seg_tiles = 0;
+        g.segmented = true;
+        g.xcd = want_xcd();
+        g.sort_end_bit = g.rbits;
+        g.in_b = seg_sort_result_in_b(g.mode, g.rbits);
+        g.fused_keys = !g.weighted;
+        return g;
+    }
     const bool fixed = fixed_pooling > 0 && !g.sliced && p.T >= 1 && p.B > 0 &&
                        fixed_pooling * p.B * static_cast<int64_t>(p.T) == p.N;
     g.H = 1;
@@ -378,6 +436,7 @@ SortPlan make_plan(const KParams& p, int64_t max_rows, int64_t fixed_pooling, in
 
 std::mutex g_plan_mutex;
 std::unordered_map<const void*, SortPlan> g_plans;   // workspace -> the plan of the last sort issued on it
+uint64_t g_plan_stamp = 0;
 
 template <typename K>
 hipError_t sort_impl(const KParams& p, const SortPlan& g, SortWs& ws, hipStream_t stream) {
@@ -390,6 +449,22 @@ hipError_t sort_impl(const KParams& p, const SortPlan& g, SortWs& ws, hipStream_
     const size_t lds = static_cast<size_t>(q.bags_per_block + 2) * sizeof(int64_t);
     K* ka = reinterpret_cast<K*>(ws.keys_a);
     K* kb = reinterpret_cast<K*>(ws.keys_b);
+    if (g.v2) {
+        SegSortRequest rq;
+        rq.indices = p.indices;
+        rq.offsets = p.offsets;
+        rq.rows = p.rows;
+        rq.idx64 = p.idx64;
+        rq.T = p.T;
+        rq.B = p.B;
+        rq.N = p.N;
+        rq.bag_begin = p.bag_begin;
+        rq.bag_count = p.bag_count;
+        rq.tshift = g.tshift;
+        rq.rbits_max = g.rbits;
+        rq.weighted = g.weighted;
+        return seg_sort_pairs<K>(rq, g.mode, ka, kb, ws.vals_a, ws.vals_b, ws.bag_of, ws.temp, stream);
+    }
     const int64_t s0 = p.bag_begin, s1 = p.bag_begin + p.bag_count;
     // per-table segments of a fixed-pooling request, one phase, no weights: bag and table of a lookup follow from its
     // position, so the first radix pass forms the pairs itself from the index array and no key-building kernel runs
@@ -422,7 +497,9 @@ hipError_t launch_apply_w(SortedParams sp, hipStream_t stream) {
     constexpr int NG = kBlock / G;
     constexpr int C = kSortTile / NG;
     int64_t grid = (sp.n + kSortTile - 1) / kSortTile;
-    if (sp.seg_tiles > 0)
+    if (sp.xcd == 2)
+        grid = static_cast<int64_t>(kXcds) * ((grid + kXcds - 1) / kXcds);
+    else if (sp.seg_tiles > 0)
         grid = (sp.xcd ? static_cast<int64_t>(kXcds) * ((sp.T + kXcds - 1) / kXcds) : static_cast<int64_t>(sp.T)) * sp.seg_tiles;
     const int64_t n_chunks = (sp.n + C - 1) / C;       // every chunk below this index wrote its record
     const int64_t fgrid = (n_chunks + NG - 1) / NG;
@@ -473,6 +550,8 @@ int ws_kbits_sort(const KParams& p, int64_t max_rows) { return bits_for(max_rows
 }  // namespace
 
 // ---- entry points used by capi.hip -----------------------------------------------------------
+void set_sort_tuning(int mode) { g_sort_mode.store(mode); }
+
 void set_backward_tuning(int sort_impl, int order, int xcd, int max_phases_) {
     g_sort_impl.store(sort_impl);
     g_sort_order.store(order);
@@ -482,7 +561,7 @@ void set_backward_tuning(int sort_impl, int order, int xcd, int max_phases_) {
 
 hipError_t sorted_workspace_bytes(const KParams& p, int64_t max_rows, int max_dim, size_t& bytes) {
     SortWs ws;
-    hipError_t rc = ws_layout(nullptr, p.N, ws_key_bytes(p, max_rows), ws_kbits_sort(p, max_rows), p.psw != nullptr, max_dim, ws);
+    hipError_t rc = ws_layout(nullptr, p.N, p.T, ws_key_bytes(p, max_rows), ws_kbits_sort(p, max_rows), p.psw != nullptr, max_dim, ws);
     bytes = ws.total;
     return rc;
 }
@@ -491,12 +570,21 @@ hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, int64_t
                         hipStream_t stream) {
     const SortPlan g = make_plan(p, max_rows, fixed_pooling, phases);
     SortWs ws;
-    hipError_t rc = ws_layout(workspace, p.N, ws_key_bytes(p, max_rows), ws_kbits_sort(p, max_rows), g.weighted, max_dim, ws);
+    hipError_t rc = ws_layout(workspace, p.N, p.T, ws_key_bytes(p, max_rows), ws_kbits_sort(p, max_rows), g.weighted, max_dim, ws);
     if (rc != hipSuccess) return rc;
     {
         std::lock_guard<std::mutex> lock(g_plan_mutex);
-        if (g_plans.size() >= 4096 && g_plans.find(workspace) == g_plans.end()) g_plans.clear();   // bound the record table
-        g_plans[workspace] = g;
+        // bound the record table: the OLDEST record goes (a clear() would also drop plans of workspaces that are sorted
+        // but not yet applied)
+        if (g_plans.size() >= 4096 && g_plans.find(workspace) == g_plans.end()) {
+            auto oldest = g_plans.begin();
+            for (auto it = g_plans.begin(); it != g_plans.end(); ++it)
+                if (it->second.stamp < oldest->second.stamp) oldest = it;
+            g_plans.erase(oldest);
+        }
+        SortPlan rec = g;
+        rec.stamp = ++g_plan_stamp;
+        g_plans[workspace] = rec;
     }
     // the key type follows the PLAN (a one-phase plan of a request whose two-phase key would need 33 bits still sorts
     // 4-byte keys); the buffers were sized for the wider of the two
@@ -506,8 +594,16 @@ hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, int64_t
 // human-readable form of the plan a sort of this request would use (host-only; tests and sweeps)
 std::string sort_plan_describe(const KParams& p, int64_t max_rows, int64_t fixed_pooling, int phases) {
     const SortPlan g = make_plan(p, max_rows, fixed_pooling, phases);
-    const int passes = g.rocprim ? -1 : rs_num_passes(0, g.sort_end_bit);
-    char buf[512];
+    const int passes = g.rocprim ? -1 : g.v2 ? seg_sort_passes(g.mode, g.rbits) : rs_num_passes(0, g.sort_end_bit);
+    char buf[640];
+    if (g.v2) {
+        snprintf(buf, sizeof(buf),
+                 "sort=seg mode=%d key_bytes=%d rbits=%d hbits=0 kbits=%d sort_bits=%d passes=%d local=%d segmented=1 segments=device "
+                 "pooling=device phases=1 xcd=%d sliced=%d weighted=%d result_in_b=%d fused_keys=%d",
+                 g.mode, g.key_bytes, g.rbits, g.kbits, g.rbits, passes, g.mode != 0 ? 1 : 0, g.xcd ? 1 : 0, g.sliced ? 1 : 0,
+                 g.weighted ? 1 : 0, g.in_b ? 1 : 0, g.fused_keys ? 1 : 0);
+        return buf;
+    }
     snprintf(buf, sizeof(buf),
              "sort=%s key_bytes=%d rbits=%d hbits=%d kbits=%d sort_bits=%d passes=%d segmented=%d seg_len=%lld phases=%d "
              "apply_seg_tiles=%d xcd=%d sliced=%d weighted=%d result_in_b=%d fused_keys=%d",
@@ -525,9 +621,32 @@ int bwd_sorted_plan_check(const KParams& p, int64_t max_rows, const void* worksp
     if (it == g_plans.end()) return 1;
     const SortPlan& g = it->second;
     if (g.n != p.N || g.T != p.T || g.rbits != bits_for(max_rows) || g.weighted != (p.psw != nullptr) ||
-        g.sliced != !(p.bag_begin == 0 && p.bag_count == p.B))
+        g.sliced != !(p.bag_begin == 0 && p.bag_count == p.B) || g.indices != p.indices || g.offsets != p.offsets || g.B != p.B ||
+        g.bag_begin != p.bag_begin || g.bag_count != p.bag_count)
         return 1;
     if (adagrad && g.H != 1) return 2;
+    return 0;
+}
+
+// where the last sort on this workspace left its pairs (device pointers into the workspace): tests and tools
+int sorted_pairs_info(const KParams& p, int64_t max_rows, int max_dim, const void* workspace, const void** keys, const uint32_t** vals,
+                      const uint32_t** d_count, int* key_bytes, int* tshift) {
+    SortPlan g;
+    {
+        std::lock_guard<std::mutex> lock(g_plan_mutex);
+        auto it = g_plans.find(workspace);
+        if (it == g_plans.end()) return 1;
+        g = it->second;
+    }
+    SortWs ws;
+    if (ws_layout(const_cast<void*>(workspace), p.N, p.T, ws_key_bytes(p, max_rows), ws_kbits_sort(p, max_rows), g.weighted, max_dim, ws) !=
+        hipSuccess)
+        return 1;
+    *keys = g.in_b ? ws.keys_b : ws.keys_a;
+    *vals = g.in_b ? ws.vals_b : ws.vals_a;
+    *d_count = g.v2 ? seg_sort_count(ws.temp, static_cast<size_t>(p.N), p.T) : nullptr;
+    *key_bytes = g.key_bytes;
+    *tshift = g.tshift;
     return 0;
 }
 
@@ -541,7 +660,7 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
         g = it->second;
     }
     SortWs ws;
-    hipError_t rc = ws_layout(const_cast<void*>(workspace), p.N, ws_key_bytes(p, max_rows), ws_kbits_sort(p, max_rows), g.weighted,
+    hipError_t rc = ws_layout(const_cast<void*>(workspace), p.N, p.T, ws_key_bytes(p, max_rows), ws_kbits_sort(p, max_rows), g.weighted,
                               max_dim, ws);
     if (rc != hipSuccess) return rc;
     if (p.T > kMaxTablesLds) return hipErrorInvalidValue;
@@ -573,10 +692,11 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
     sp.sr = (opt && opt->stochastic_rounding && dst_dtype != PM_F32) ? 1 : 0;
     sp.sr_seed = opt ? opt->seed : 0;
     sp.exact_run = kExactRun;
-    sp.seg_tiles = (g.xcd || g.H > 1) ? g.seg_tiles : 0;
+    sp.seg_tiles = (!g.v2 && (g.xcd || g.H > 1)) ? g.seg_tiles : 0;
     sp.H = g.H;
     sp.phase = 0;
-    sp.xcd = g.xcd ? 1 : 0;
+    sp.xcd = g.xcd ? (g.v2 ? 2 : 1) : 0;
+    sp.d_n = g.v2 ? seg_sort_count(ws.temp, static_cast<size_t>(p.N), p.T) : nullptr;
     if (sp.n == 0) return hipSuccess;
     return g.key_bytes == 4 ? launch_apply_k<uint32_t>(sp, dst_dtype, max_dim, stream)
                             : launch_apply_k<uint64_t>(sp, dst_dtype, max_dim, stream);

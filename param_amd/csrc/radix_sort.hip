@@ -15,6 +15,8 @@
 // can sort "however many elements a previous kernel produced" without a host round trip (the hybrid backward compacts
 // the duplicate lookups on the device).  The 63 MB of pairs of the benchmark step (7.86 M lookups) stay in the 256 MB
 // memory-side cache across passes; HBM is not what bounds this.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace pm {
@@ -289,10 +291,26 @@ hipError_t rs_sort_pairs(K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_
     uint32_t* total = bh + rs_tiles(n_max) * kRsRadix;
     const unsigned grid = static_cast<unsigned>(rs_tiles(n_max));
     const uint32_t n32 = static_cast<uint32_t>(n_max);
-    int shift = begin_bit;
+    // digit widths as even as possible: 30 bits -> 8, 8, 7, 7
+    int sh[16], wd[16];
+    for (int p = 0, s = begin_bit; p < passes; ++p) {
+        wd[p] = (bits - (s - begin_bit) + (passes - p) - 1) / (passes - p);
+        sh[p] = s;
+        s += wd[p];
+    }
+    // experiment (PARAM_AMD_EXP_DIGIT_ROT=1): the lowest digit is sorted LAST, i.e. it becomes the most significant one --
+    // equal keys still end up adjacent and in input order, but neighbours in the output are no longer neighbours in key
+    // space (measures what the ascending-row order is worth to the apply kernel's address translation)
+    const char* rot_env = getenv("PARAM_AMD_EXP_DIGIT_ROT");   // read per call: a probe flips it between sorts
+    const bool rot = rot_env && rot_env[0] == '1';
+    if (rot && passes > 1) {
+        const int s0 = sh[0], w0 = wd[0];
+        for (int p = 0; p + 1 < passes; ++p) { sh[p] = sh[p + 1]; wd[p] = wd[p + 1]; }
+        sh[passes - 1] = s0;
+        wd[passes - 1] = w0;
+    }
     for (int p = 0; p < passes; ++p) {
-        // digit widths as even as possible: 30 bits -> 8, 8, 7, 7
-        const int w = (bits - (shift - begin_bit) + (passes - p) - 1) / (passes - p);
+        const int shift = sh[p], w = wd[p];
         const uint32_t mask = (1u << w) - 1u;
         const K* kin = (p % 2 == 0) ? keys_a : keys_b;
         K* kout = (p % 2 == 0) ? keys_b : keys_a;
@@ -313,7 +331,6 @@ hipError_t rs_sort_pairs(K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_
         else
             hipLaunchKernelGGL((rs_scatter_kernel<K, false>), dim3(grid), dim3(kRsThreads), 0, stream, kin, vin, kout, vout, d_count, n32,
                                shift, mask, bh, total, seg_tiles, none);
-        shift += w;
     }
     return hipGetLastError();
 }

@@ -134,7 +134,10 @@ class _TableSet:
             return int(claim) if claim > 0 and tb * int(claim) == n else 0
         if tb == 0 or n == 0 or n % tb:
             return 0
-        key = (offsets.data_ptr(), offsets.numel(), offsets.dtype, n, B)
+        # the verdict is a property of the tensor's CONTENTS: the key carries torch's in-place version counter, so an
+        # ``offsets.copy_(...)`` into a persistent buffer (same pointer, same total, now ragged) is looked at again.  Writers
+        # that bypass torch (a raw-pointer kernel) must pass ``pooling=``.
+        key = (offsets.data_ptr(), offsets.numel(), offsets.dtype, offsets._version, n, B)
         if key != self._pool_key:
             L = n // tb
             ramp = torch.arange(tb, dtype=offsets.dtype, device=offsets.device) * L
@@ -237,10 +240,40 @@ def _sort_indices(ts: _TableSet, indices, offsets, B, psw=None, bag_begin=0, bag
     so it can be issued early / on another stream; ``_bwd(..., presorted=True)`` consumes it.  ``phases=2`` (scatter-add /
     SGD apply) lets the apply run in two bag phases where the request allows; the fused row-wise Adagrad needs ``phases=1``."""
     op = ts.request(indices, offsets, B, psw, bag_begin, bag_count)
-    op.fixed_pooling = ts.fixed_pooling(indices, offsets, B, pooling)
+    op.fixed_pooling = ts.fixed_pooling(indices, offsets, B, pooling) if _lib.needs_pooling_hint() else 0
     ws = _workspace(ts, op)
     _lib.check(_lib.load().pm_embbag_sort_indices_ex(ctypes.byref(op), max(ts.rows), phases, ws.data_ptr(), ws.numel(),
                                                      _stream_ptr()))
+
+
+def sort_plan(ts: _TableSet, indices, offsets, B, psw=None, bag_begin=0, bag_count=None, phases: int = 1,
+              pooling: Optional[int] = None) -> str:
+    """one-line description of the layout the sort would choose for this request (``pm_embbag_sort_plan``; host-only)"""
+    op = ts.request(indices, offsets, B, psw, bag_begin, bag_count)
+    op.fixed_pooling = 0 if pooling is None else int(pooling)
+    buf = ctypes.create_string_buffer(1024)
+    _lib.check(_lib.load().pm_embbag_sort_plan(ctypes.byref(op), max(ts.rows), phases, buf, 1024))
+    return buf.value.decode()
+
+
+def sorted_pairs(ts: _TableSet, indices, offsets, B, psw=None, bag_begin=0, bag_count=None):
+    """(keys, values, tshift) of the last ``_sort_indices`` on this table set's workspace, as torch tensors copied off the
+    workspace (``pm_embbag_sorted_pairs``) -- for tests and tools; synchronises."""
+    op = ts.request(indices, offsets, B, psw, bag_begin, bag_count)
+    ws = _workspace(ts, op)
+    vp = ctypes.c_void_p
+    keys, vals, cnt, kb, tsh = vp(), vp(), vp(), ctypes.c_int32(), ctypes.c_int32()
+    _lib.check(_lib.load().pm_embbag_sorted_pairs(ctypes.byref(op), max(ts.rows), ws.data_ptr(), ctypes.byref(keys), ctypes.byref(vals),
+                                                  ctypes.byref(cnt), ctypes.byref(kb), ctypes.byref(tsh)))
+    torch.cuda.synchronize()
+    base = ws.data_ptr()
+    n = indices.numel()
+    if cnt.value:
+        n = int(ws[cnt.value - base:cnt.value - base + 4].view(torch.int32)[0].item()) & 0xffffffff
+    kdt = torch.int32 if kb.value == 4 else torch.int64
+    k = ws[keys.value - base:keys.value - base + n * kb.value].view(kdt).clone()
+    v = ws[vals.value - base:vals.value - base + n * 4].view(torch.int32).clone()
+    return k, v, tsh.value
 
 
 def _bwd(ts: _TableSet, grad, indices, offsets, B, dst_ptrs_dev, dst_dtype, alpha, psw=None,
@@ -262,7 +295,7 @@ def _bwd(ts: _TableSet, grad, indices, offsets, B, dst_ptrs_dev, dst_dtype, alph
         raise ValueError('method must be "sorted" or "atomic"')
     ws = _workspace(ts, op)
     if not presorted:
-        op.fixed_pooling = ts.fixed_pooling(indices, offsets, B, pooling)
+        op.fixed_pooling = ts.fixed_pooling(indices, offsets, B, pooling) if _lib.needs_pooling_hint() else 0
         _lib.check(L.pm_embbag_sort_indices_ex(ctypes.byref(op), max(ts.rows), 2, ws.data_ptr(), ws.numel(), _stream_ptr()))
     _lib.check(L.pm_embbag_bwd_sorted(ctypes.byref(op), grad.data_ptr(), dst_ptrs_dev.data_ptr(), _WDTYPE[dst_dtype],
                                       float(alpha), max(ts.rows), ws.data_ptr(), ws.numel(), _stream_ptr()))
@@ -298,7 +331,7 @@ def _adagrad(ts: _TableSet, grad, indices, offsets, B, mom_ptrs_dev, lr: float, 
     L = _lib.load()
     ws = _workspace(ts, op)
     if not presorted:
-        op.fixed_pooling = ts.fixed_pooling(indices, offsets, B, pooling)
+        op.fixed_pooling = ts.fixed_pooling(indices, offsets, B, pooling) if _lib.needs_pooling_hint() else 0
         _lib.check(L.pm_embbag_sort_indices_ex(ctypes.byref(op), max(ts.rows), 1, ws.data_ptr(), ws.numel(), _stream_ptr()))
     opt = _lib.pm_rowwise_adagrad(float(lr), float(eps), float(weight_decay), _WD_MODES[weight_decay_mode],
                                   1 if stochastic_rounding else 0, 0, int(seed) & (2**64 - 1))
@@ -463,7 +496,7 @@ class BatchedEmbeddingBagMI355(nn.Module):
             # both readings fit every length.  TBE's [B+1] form ends with the number of indices; an nn.EmbeddingBag-style
             # [B] tensor does not (its last bag would silently be dropped): look once per request (one small D2H read,
             # remembered for the tensors of a benchmark loop); pass batch= to skip the question altogether.
-            key = (offsets.data_ptr(), n, None if indices is None else indices.numel())
+            key = (offsets.data_ptr(), offsets._version, n, None if indices is None else indices.numel())
             if getattr(self, "_b1_key", None) != key:
                 closed = indices is not None and int(offsets[-1]) == indices.numel()
                 self._b1_key, self._b1_val = key, (n - 1 if closed else n)

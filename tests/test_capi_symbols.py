@@ -55,7 +55,7 @@ def test_argument_validation_without_gpu():
     assert b"bag_begin" in L.pm_last_error()
     assert L.pm_set_tuning(3, 0, -1, -1) == _lib.PM_ERR_INVALID
     assert L.pm_set_tuning(0, 0, -1, -1) == _lib.PM_OK
-    assert L.pm_set_backward_tuning(2, 0, 0, -1) == _lib.PM_ERR_INVALID and L.pm_set_backward_tuning(-1, -1, -1, -1) == _lib.PM_OK
+    assert L.pm_set_backward_tuning(3, 0, 0, -1) == _lib.PM_ERR_INVALID and L.pm_set_sort_tuning(3) == _lib.PM_ERR_INVALID and L.pm_set_sort_tuning(-1) == _lib.PM_OK and L.pm_set_backward_tuning(-1, -1, -1, -1) == _lib.PM_OK
     in_b = ctypes.c_int32(-1)
     assert L.pm_radix_sort_pairs(None, None, None, None, 0, None, 4, 0, 24, 0, None, 0, ctypes.byref(in_b), None) == _lib.PM_OK
     assert in_b.value == 1                                        # 3 passes: the result would be in the b buffers
@@ -139,7 +139,24 @@ def _plan(L, T, B, Lp, max_rows, phases=1, fixed=True, slice_=None, weighted=Fal
 def test_sort_plan_decisions_on_the_host():
     """which layout the sorted backward picks for a request is a host-side decision (make_plan): pinned here without a GPU"""
     L = _lib.load()
-    assert L.pm_set_backward_tuning(-1, -1, -1, -1) == _lib.PM_OK
+    assert L.pm_set_backward_tuning(-1, -1, -1, -1) == _lib.PM_OK and L.pm_set_sort_tuning(-1) == _lib.PM_OK
+    # default (round 3): ONE plan for every request -- segments, per-table pooling and the pair count are device-side
+    for kw in ({}, {"fixed": False}, {"slice_": (100, 50)}, {"weighted": True}):
+        seg = _plan(L, 48, 8192, 20, 10_000_000, **kw)
+        assert seg["sort"] == "seg" and seg["segmented"] == "1" and seg["segments"] == "device" and seg["pooling"] == "device"
+        assert seg["xcd"] == "1" and seg["key_bytes"] == "4" and seg["rbits"] == "24" and seg["kbits"] == "30" and seg["sort_bits"] == "24"
+        assert seg["fused_keys"] == ("0" if kw.get("weighted") else "1")
+    assert _plan(L, 26, 8192, 8, 40_000_000)["rbits"] == "26"
+    for mode, passes, in_b in ((0, "3", "1"), (1, "1", "1"), (2, "1", "1")):
+        assert L.pm_set_sort_tuning(mode) == _lib.PM_OK
+        seg = _plan(L, 48, 8192, 20, 10_000_000)
+        assert seg["mode"] == str(mode) and seg["passes"] == passes and seg["result_in_b"] == in_b and seg["local"] == ("0" if mode == 0 else "1")
+    assert L.pm_set_sort_tuning(0) == _lib.PM_OK
+    assert _plan(L, 26, 8192, 8, 40_000_000)["passes"] == "4" and _plan(L, 26, 8192, 8, 40_000_000)["result_in_b"] == "0"
+    assert _plan(L, 1024, 64, 64, 1 << 30)["key_bytes"] == "8"
+    assert L.pm_set_sort_tuning(-1) == _lib.PM_OK
+    # round 2's host-side plans (sort_impl 2), kept as the measured alternative
+    assert L.pm_set_backward_tuning(2, -1, -1, -1) == _lib.PM_OK
     bench = _plan(L, 48, 8192, 20, 10_000_000)                       # the benchmark step
     assert bench["sort"] == "own" and bench["key_bytes"] == "4" and bench["rbits"] == "24" and bench["kbits"] == "30"
     assert bench["segmented"] == "1" and bench["seg_len"] == str(8192 * 20) and bench["passes"] == "3" and bench["sort_bits"] == "24"
@@ -159,13 +176,13 @@ def test_sort_plan_decisions_on_the_host():
     assert wide["key_bytes"] == "8" and wide["kbits"] == "40"
     # two bag phases only on request AND with the knob: default max_phases = 1
     assert _plan(L, 48, 8192, 20, 10_000_000, phases=2)["phases"] == "1"
-    assert L.pm_set_backward_tuning(-1, -1, -1, 2) == _lib.PM_OK
+    assert L.pm_set_backward_tuning(2, -1, -1, 2) == _lib.PM_OK
     two = _plan(L, 48, 8192, 20, 10_000_000, phases=2)
     assert two["phases"] == "2" and two["hbits"] == "1" and two["kbits"] == "31" and two["seg_len"] == str(4096 * 20)
     assert two["apply_seg_tiles"] == "80" and two["key_bytes"] == "4" and two["fused_keys"] == "0"
     assert _plan(L, 48, 8192, 20, 10_000_000, phases=1)["phases"] == "1"
     # row order: only the row bits, no segments, no XCD mapping; rocPRIM: no segments either
-    assert L.pm_set_backward_tuning(-1, 0, -1, -1) == _lib.PM_OK
+    assert L.pm_set_backward_tuning(2, 0, -1, -1) == _lib.PM_OK
     row = _plan(L, 48, 8192, 20, 10_000_000)
     assert row["sort_bits"] == "24" and row["segmented"] == "0" and row["xcd"] == "0"
     assert L.pm_set_backward_tuning(1, -1, -1, -1) == _lib.PM_OK

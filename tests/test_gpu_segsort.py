@@ -1,0 +1,244 @@
+"""The segmented key sort of the sorted backward (param_amd/csrc/seg_sort.hip; ``pytest -m gpu``).
+
+Every request is sorted through the C ABI (``pm_embbag_sort_indices_ex``) and the sorted pairs are read back from the
+workspace (``pm_embbag_sorted_pairs``) and compared, element for element, with numpy's stable order of the same keys:
+  mode 0 / 2   (table, row, position)
+  mode 1       (table, row & 255, row >> 8, position)
+values = the lookup's bag inside its table (its position in the request for weighted requests).  Covered: per-table
+segments from the offsets (fixed pooling, per-table pooling, ragged incl. empty bags and empty tables), batch slices (compact
+output, device-side count), weights, int32 indices, 8-byte keys, tables with fewer than 8 key bits, and buckets of every
+size class of the bucket-local sort (registers / one workgroup per CU / external single-workgroup sort).
+Then the whole backward on the same kinds of request against the C oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu_and_lib():
+    import param_amd
+
+    assert torch.cuda.is_available(), "gpu-marked tests need a ROCm device"
+    param_amd.load_library()
+    yield
+    param_amd.set_backward_tuning()
+    param_amd.set_sort_tuning()
+
+
+def _request(rng, rows, B, lens_of_table, hot=None, idx_dtype=np.int64):
+    """indices / offsets of a TBE request; hot: per table either None or (fraction, candidate rows)"""
+    lens = np.concatenate([np.asarray(lens_of_table(t), dtype=np.int64) for t in range(len(rows))])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    parts = []
+    for t, r in enumerate(rows):
+        n = int(lens[t * B:(t + 1) * B].sum())
+        idx = rng.integers(0, r, n)
+        if hot is not None and hot[t] is not None:
+            frac, cand = hot[t]
+            pick = rng.random(n) < frac
+            idx[pick] = rng.choice(cand, int(pick.sum()))
+        parts.append(idx)
+    return np.concatenate(parts).astype(idx_dtype), off.astype(idx_dtype)
+
+
+def _expected(idx, off, T, B, mode, tshift, b0=0, nb=None, weighted=False):
+    nb = B if nb is None else nb
+    keys, vals = [], []
+    for t in range(T):
+        s, e = int(off[t * B + b0]), int(off[t * B + b0 + nb])
+        row = idx[s:e].astype(np.int64)
+        pos = np.arange(s, e)
+        bag = np.searchsorted(off[t * B:(t + 1) * B + 1], pos, side="right") - 1
+        order = np.lexsort((pos, row >> 8, row & 255)) if mode == 1 else np.lexsort((pos, row))
+        keys.append((np.int64(t) << np.int64(tshift)) | row[order])
+        vals.append((pos if weighted else bag)[order])
+    return np.concatenate(keys), np.concatenate(vals)
+
+
+def _sorted(m, idx, off, B, psw=None, b0=0, nb=None):
+    from param_amd.embedding_bag import _sort_indices, sorted_pairs
+
+    ts = m._tables()
+    _sort_indices(ts, idx, off, B, psw, b0, nb)
+    k, v, tshift = sorted_pairs(ts, idx, off, B, psw, b0, nb)
+    k = k.cpu().numpy()
+    k = (k.astype(np.int64) & 0xffffffff) if k.dtype == np.int32 else k.astype(np.int64)
+    return k, v.cpu().numpy().astype(np.int64) & 0xffffffff, tshift
+
+
+CASES = {
+    # rows, B, lens(t), hot
+    "fixed": dict(rows=[70000, 300, 3, 1_000_000, 5000], B=2048, lens=lambda t: np.full(2048, 8)),
+    "per_table_pooling": dict(rows=[70000, 300, 3, 1_000_000, 5000], B=1024, lens=lambda t: np.full(1024, [3, 1, 20, 7, 2][t])),
+    "ragged": dict(rows=[70000, 300, 3, 1_000_000, 5000], B=512, lens=None),
+    "empty_table": dict(rows=[1000, 50, 99999], B=256, lens=lambda t: np.full(256, [5, 0, 9][t])),
+    # one (table, digit) bucket of ~20 K pairs: the external single-workgroup sort; others of 2-10 K: one workgroup per CU
+    "skew_low_digit": dict(rows=[100_000, 100_000], B=4096, lens=lambda t: np.full(4096, 16),
+                           hot=[(0.3, 7 + 256 * np.arange(200)), (0.06, 9 + 256 * np.arange(300))]),
+    "skew_top_digit": dict(rows=[100_000, 1_000_000], B=4096, lens=lambda t: np.full(4096, 16),
+                           hot=[(0.4, np.arange(256)), (0.08, np.arange(3000))]),
+    "hot_rows": dict(rows=[1 << 20, 4000], B=4096, lens=lambda t: np.full(4096, 12), hot=[(0.5, np.array([5, 77, 1 << 19])), None]),
+}
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("idt", [torch.int64, torch.int32])
+def test_sorted_pairs_equal_numpys_stable_order(case, mode, idt):
+    import param_amd
+    from param_amd import BatchedEmbeddingBagMI355
+
+    if idt == torch.int32 and case not in ("fixed", "ragged", "skew_low_digit"):
+        pytest.skip("int32 indices: three representative cases")
+    c = CASES[case]
+    rng = np.random.default_rng(sum(map(ord, case)) + mode)
+    rows, B = c["rows"], c["B"]
+    T = len(rows)
+    if c["lens"] is None:
+        def lens(t):
+            ln = rng.integers(0, 13, B)
+            ln[0] = 0
+            ln[-1] = 0
+            ln[B // 2] = 700
+            return ln
+    else:
+        lens = c["lens"]
+    idx, off = _request(rng, rows, B, lens, c.get("hot"))
+    param_amd.set_sort_tuning(mode)
+    m = BatchedEmbeddingBagMI355(rows, 8, device=DEV, init=None, fused_update=False)
+    it, ot = torch.from_numpy(idx).to(DEV).to(idt), torch.from_numpy(off).to(DEV).to(idt)
+    k, v, tshift = _sorted(m, it, ot, B)
+    ek, ev = _expected(idx, off, T, B, mode, tshift)
+    assert k.shape == ek.shape
+    assert np.array_equal(k, ek), (case, mode, int(np.argmax(k != ek)))
+    assert np.array_equal(v, ev), (case, mode, int(np.argmax(v != ev)))
+    # a batch slice sorts only its own lookups (compact, device-side count)
+    b0, nb = B // 4, B // 2 + 3
+    k, v, tshift = _sorted(m, it, ot, B, None, b0, nb)
+    ek, ev = _expected(idx, off, T, B, mode, tshift, b0, nb)
+    assert k.shape == ek.shape and np.array_equal(k, ek) and np.array_equal(v, ev), (case, mode, "slice")
+    # weighted: values are request positions
+    psw = torch.rand(idx.size, device=DEV)
+    k, v, tshift = _sorted(m, it, ot, B, psw)
+    ek, ev = _expected(idx, off, T, B, mode, tshift, weighted=True)
+    assert np.array_equal(k, ek) and np.array_equal(v, ev), (case, mode, "weighted")
+    param_amd.set_sort_tuning()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_eight_byte_keys_and_many_tables(mode):
+    """2^30-row table next to small ones (33 key bits -> 8-byte keys; 30 row bits: 4 global passes / 3 local rounds) and a
+    request of 300 tiny tables"""
+    import param_amd
+    from param_amd import BatchedEmbeddingBagMI355
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < (40 << 30):
+        pytest.skip("needs ~20 GiB")
+    param_amd.set_sort_tuning(mode)
+    rng = np.random.default_rng(5 + mode)
+    rows, B = [1 << 30, 1000, 5000, 77, 300], 512
+    idx, off = _request(rng, rows, B, lambda t: np.full(B, 6), hot=[(0.3, np.array([(1 << 30) - 1, 12345, 1 << 29])), None, None, None, None])
+    m = BatchedEmbeddingBagMI355(rows, 4, device=DEV, init=None, fused_update=False)
+    k, v, tshift = _sorted(m, torch.from_numpy(idx).to(DEV), torch.from_numpy(off).to(DEV), B)
+    ek, ev = _expected(idx, off, len(rows), B, mode, tshift)
+    assert tshift == 30 and np.array_equal(k, ek) and np.array_equal(v, ev)
+    del m
+    rows = [int(r) for r in rng.integers(1, 400, 300)]
+    B = 64
+    idx, off = _request(rng, rows, B, lambda t: rng.integers(0, 5, B))
+    m = BatchedEmbeddingBagMI355(rows, 4, device=DEV, init=None, fused_update=False)
+    k, v, tshift = _sorted(m, torch.from_numpy(idx).to(DEV), torch.from_numpy(off).to(DEV), B)
+    ek, ev = _expected(idx, off, len(rows), B, mode, tshift)
+    assert np.array_equal(k, ek) and np.array_equal(v, ev)
+    param_amd.set_sort_tuning()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("case", ["per_table_pooling", "ragged", "skew_low_digit", "skew_top_digit"])
+def test_backward_through_the_segmented_sort_vs_oracle(coracle, case, mode):
+    """scatter-add of whole requests (and of a batch slice) against the sequential C oracle: bit-exact on rows looked up
+    <= 256 times, 1e-5 of an fp64 sum beyond; sort plan says segmented / XCD for every kind of request"""
+    import param_amd
+    from param_amd import BatchedEmbeddingBagMI355
+    from param_amd.embedding_bag import sort_plan
+
+    c = CASES[case]
+    rng = np.random.default_rng(77 + mode)
+    rows, B, D = c["rows"], c["B"], 32
+    T = len(rows)
+    if c["lens"] is None:
+        lens = lambda t: rng.integers(0, 13, B)   # noqa: E731
+    else:
+        lens = c["lens"]
+    idx, off = _request(rng, rows, B, lens, c.get("hot"))
+    param_amd.set_sort_tuning(mode)
+    m = BatchedEmbeddingBagMI355(rows, D, device=DEV, init="normal", seed=3, fused_update=False)
+    it, ot = torch.from_numpy(idx).to(DEV), torch.from_numpy(off).to(DEV)
+    plan = sort_plan(m._tables(), it, ot, B)
+    assert "sort=seg" in plan and "segmented=1" in plan and "xcd=1" in plan and f"mode={mode}" in plan, plan
+    grad = rng.standard_normal((B, T * D)).astype(np.float32)
+    for b0, nb in ((0, B), (B // 3, B // 2)):
+        W0 = [m.table(t).cpu().numpy().copy() for t in range(T)]
+        m.scatter_add_(torch.from_numpy(grad).to(DEV), it, ot, alpha=0.25, batch=B, bag_begin=b0, bag_count=nb)
+        for t in range(T):
+            s, e = int(off[t * B + b0]), int(off[t * B + b0 + nb])
+            loc = off[t * B + b0:t * B + b0 + nb] - s
+            gt = np.ascontiguousarray(grad[b0:b0 + nb, t * D:(t + 1) * D])
+            exp = coracle.bwd_f32(W0[t].copy(), idx[s:e], loc, gt, None, alpha=0.25)
+            got = m.table(t).cpu().numpy()
+            cnt = np.bincount(idx[s:e], minlength=rows[t])
+            cold = cnt <= 256
+            assert np.array_equal(got[cold], exp[cold]), (case, mode, t, b0)
+            lens_t = np.diff(np.concatenate([loc, [e - s]]))
+            contrib = 0.25 * gt.astype(np.float64)[np.repeat(np.arange(nb), lens_t)]
+            truth, mag = W0[t].astype(np.float64), np.abs(W0[t]).astype(np.float64)
+            np.add.at(truth, idx[s:e], contrib)
+            np.add.at(mag, idx[s:e], np.abs(contrib))
+            tol = np.maximum(1e-5, (256 + cnt[:, None] / 32) * 2.0 ** -24) * mag + 1e-30
+            assert (np.abs(got - truth) <= tol).all(), (case, mode, t, b0)
+    param_amd.set_sort_tuning()
+
+
+def test_offsets_refilled_in_place_are_looked_at_again(coracle):
+    """the stale-verdict hazard of round 2: a fixed-pooling request, then ``offsets.copy_(ragged, same total)`` into the SAME
+    tensor.  The default sort reads the offsets on the device (no verdict to go stale); the round-2 sort (sort_impl 2) takes
+    the verdict from the Python-side cache, whose key now carries the tensor's version counter.  Both must give the oracle's
+    gradient for the ragged request."""
+    import param_amd
+    from param_amd import BatchedEmbeddingBagMI355
+
+    rng = np.random.default_rng(3)
+    rows, B, L, D = [5000, 300, 70000], 256, 8, 16
+    T = len(rows)
+    n = T * B * L
+    idx = np.concatenate([rng.integers(0, r, B * L) for r in rows]).astype(np.int64)
+    fixed_off = (np.arange(T * B + 1) * L).astype(np.int64)
+    # ragged with the same total AND the same per-table totals (so even a per-table divisibility test cannot tell)
+    lens = np.full(T * B, L)
+    for t in range(T):
+        a = rng.permutation(B)[: B // 2 * 2].reshape(-1, 2) + t * B
+        d = rng.integers(1, L, a.shape[0])
+        lens[a[:, 0]] += d
+        lens[a[:, 1]] -= d
+    ragged_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    assert ragged_off[-1] == n and (lens >= 0).all() and not np.array_equal(ragged_off, fixed_off)
+    grad = rng.standard_normal((B, T * D)).astype(np.float32)
+    for impl in (0, 2):
+        param_amd.set_backward_tuning(sort_impl=impl)
+        m = BatchedEmbeddingBagMI355(rows, D, device=DEV, init=None, fused_update=False)
+        it, g = torch.from_numpy(idx).to(DEV), torch.from_numpy(grad).to(DEV)
+        off_buf = torch.from_numpy(fixed_off).to(DEV)              # the persistent buffer of a training loop
+        for step, off_np in enumerate((fixed_off, ragged_off, fixed_off, ragged_off)):
+            off_buf.copy_(torch.from_numpy(off_np))
+            dws = m.dense_grad(g, it, off_buf, batch=B)
+            for t in range(T):
+                s, e = off_np[t * B], off_np[(t + 1) * B]
+                exp = coracle.bwd_f32(np.zeros((rows[t], D), np.float32), idx[s:e], off_np[t * B:(t + 1) * B] - s,
+                                      np.ascontiguousarray(grad[:, t * D:(t + 1) * D]))
+                assert np.array_equal(dws[t].cpu().numpy(), exp), (impl, step, t)
+    param_amd.set_backward_tuning()

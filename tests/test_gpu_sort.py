@@ -115,8 +115,9 @@ def test_radix_sort_segmented():
             assert np.array_equal(vo[sl], ev + np.uint32(s_ * seg)), (seg, s_)
 
 
-@pytest.mark.parametrize("sort_impl,order,xcd,phases", [(0, 0, 0, 1), (0, 1, 0, 1), (0, 1, 1, 1), (0, 1, 1, 2), (0, 1, 0, 2), (1, 0, 0, 1),
-                                                        (1, 1, 1, 1), (1, 1, 1, 2)])
+@pytest.mark.parametrize("sort_impl,order,xcd,phases", [(0, 1, 0, 1), (0, 1, 1, 1),                                       # segmented sort (default)
+                                                        (2, 0, 0, 1), (2, 1, 0, 1), (2, 1, 1, 1), (2, 1, 1, 2), (2, 1, 0, 2),   # round 2's own sort
+                                                        (1, 0, 0, 1), (1, 1, 1, 1), (1, 1, 1, 2)])                               # rocPRIM
 def test_sorted_backward_under_every_tuning(coracle, sort_impl, order, xcd, phases):
     """8 tables x 1024 bags x 16 lookups (per-table lookups = 16 tiles of 1024: the XCD-affine mapping engages), Zipf
     duplicates incl. rows past the exact-run limit: every (own | rocPRIM) x (row | table order) x XCD-mapping setting
@@ -165,7 +166,7 @@ def test_two_phase_apply_engages_and_adagrad_refuses_it(coracle):
     from param_amd.embedding_bag import _sort_indices
 
     T, R, D, B, L = 4, 5000, 64, 512, 8          # (B / 2) * L = 2048: two apply tiles per (table, phase) segment
-    param_amd.set_backward_tuning(max_phases=2)  # the two-phase layout is opt-in (default: one apply launch)
+    param_amd.set_backward_tuning(sort_impl=2, max_phases=2)  # round 2's sort; the two-phase layout is opt-in there
     g = torch.Generator().manual_seed(4)
     idx = torch.randint(0, R, (T * B * L,), generator=g)
     idx[: 3 * L] = 7                             # one row looked up in bags 0..2 (lower half) ...
@@ -220,8 +221,10 @@ def test_random_fixed_pooling_requests_under_random_tuning(coracle, seed):
     D = int(rng.choice([16, 64, 128]))
     rows = [int(rng.choice([3, 100, 5000, 70000])) for _ in range(T)]
     weighted = rng.random() < 0.3
-    knobs = (int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(1, 3)))
+    knobs = (int(rng.integers(0, 3)), int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(1, 3)))
+    mode = int(rng.integers(0, 3))
     param_amd.set_backward_tuning(*knobs)
+    param_amd.set_sort_tuning(mode)
     try:
         m = BatchedEmbeddingBagMI355(rows, D, device=DEV, init="normal", seed=seed, fused_update=False)
         idx = np.concatenate([rng.integers(0, r, B * L) for r in rows]).astype(np.int64)
@@ -239,16 +242,17 @@ def test_random_fixed_pooling_requests_under_random_tuning(coracle, seed):
             got = m.table(t).cpu().numpy()
             cnt = np.bincount(idx[s:e], minlength=rows[t])
             cold = cnt <= 256
-            assert np.array_equal(got[cold], exp[cold]), (seed, t, knobs, T, B, L, D, rows[t])
+            assert np.array_equal(got[cold], exp[cold]), (seed, t, knobs, mode, T, B, L, D, rows[t])
             contrib = 0.25 * gt.astype(np.float64)[np.repeat(np.arange(B), L)] * (1.0 if pw is None else pw.astype(np.float64)[:, None])
             truth = W0[t].astype(np.float64)
             mag = np.abs(W0[t]).astype(np.float64)
             np.add.at(truth, idx[s:e], contrib)
             np.add.at(mag, idx[s:e], np.abs(contrib))
             tol = np.maximum(1e-5, (256 + cnt[:, None] / 32) * 2.0 ** -24) * mag + 1e-30
-            assert (np.abs(got - truth) <= tol).all(), (seed, t, knobs, T, B, L, D, rows[t])
+            assert (np.abs(got - truth) <= tol).all(), (seed, t, knobs, mode, T, B, L, D, rows[t])
     finally:
         param_amd.set_backward_tuning()
+        param_amd.set_sort_tuning()
 
 
 @pytest.mark.parametrize("idx_dtype", [torch.int64, torch.int32])
@@ -256,9 +260,11 @@ def test_first_pass_reading_the_indices_equals_the_key_building_kernel(idx_dtype
     """per-table segments, one phase, no weights: the first radix pass forms (key, bag) from the index array itself
     (no build_keys launch).  Same sorted pairs, hence bit-identical tables, as with PARAM_AMD_SORT_FUSED_KEYS=0 -- for
     both index types, table counts that are / are not multiples of 8, fp32 and bf16 tables, SGD and Adagrad."""
+    import param_amd
     from param_amd import BatchedEmbeddingBagMI355, _lib
     from param_amd.indices import tbe_request
 
+    param_amd.set_backward_tuning(sort_impl=2)       # round 2's sort (the default sort decides this per table on the device)
     for T, B, L, dtype, opt in ((5, 2048, 8, torch.float32, "sgd"), (8, 4096, 20, torch.bfloat16, "sgd"),
                                 (3, 1024, 4, torch.float32, "rowwise_adagrad")):
         rows = [50_000 + 7 * t for t in range(T)]
@@ -280,3 +286,4 @@ def test_first_pass_reading_the_indices_equals_the_key_building_kernel(idx_dtype
                 m.adagrad_step_(grad, idx, off, batch=B)
                 results.append([m.table(t).clone() for t in range(T)] + [m.momentum_table(t).clone() for t in range(T)])
         assert all(torch.equal(a, b) for a, b in zip(*results)), (T, dtype, opt)
+    param_amd.set_backward_tuning()
