@@ -9,21 +9,25 @@
 // train/comms/pt/pytorch_dist_backend.py:854-857, train/compute/python/workloads/pytorch/
 // split_table_batched_embeddings_ops.py:318-324); request layout :93-135,191-208.
 //
-// Kernels (256 threads, gfx950, no inter-workgroup communication inside a kernel -- kernel boundaries are the only
-// synchronisation, as in radix_sort.hip):
+// Kernels (gfx950, no inter-workgroup communication inside a kernel -- kernel boundaries are the only synchronisation, as
+// in radix_sort.hip):
 //   seg_prep_tables_kernel   one workgroup per table: segment start / count from the offsets, pooling factor if every bag
 //                            of the (sliced) table has the same length, key bits of the table from rows[t]
-//   seg_prep_scan_kernel     one workgroup: output start and first tile of every segment, tile -> segment map, header
+//   seg_prep_scan_kernel     one workgroup: output start and first tile of every segment, one 32-byte descriptor per tile
 //   seg_build_keys_kernel    only for tables WITHOUT a pooling factor (ragged, weighted): (key, bag) per lookup at request
 //                            positions (binary search over LDS-staged offsets); workgroups of other tables exit at once
-//   seg_hist / seg_scan / seg_scatter   one radix pass over every segment's 4096-element tiles: per-tile digit counts,
-//                            per-segment exclusive prefix (+ absolute bucket starts), stable scatter
-//   seg_local_sort_kernel    MODE 1 / 2: after ONE partition pass every (table, digit) bucket is sorted by its remaining
-//                            key bits inside LDS (<= 2048 elements: 8 per thread in registers; <= 10240: 40 per thread,
-//                            one workgroup per CU; larger: a single-workgroup external sort through the spare buffers)
+//   seg_hist / seg_scan / seg_scatter   one radix pass over 4096-element tiles: per-tile digit counts, per-segment
+//                            exclusive prefix (+ absolute bucket starts), stable scatter
+//   MODE 1 / 2 (one global partition pass, then buckets):
+//   seg_local_kernel         every (table, digit) bucket of up to 4096 pairs is sorted by its remaining key bits inside LDS:
+//                            up to 1024 pairs by ONE WAVE (four buckets per workgroup, no workgroup barrier), up to 4096 by
+//                            the workgroup; larger buckets were put on a list by the scan kernel ...
+//   seg_l2_prep_kernel + the pass kernels again   ... and become the segments of a second-level LSD sort over their
+//                            remaining bits (persistent grids: a request without such buckets pays a few empty launches)
 // MODE 0 runs ceil(rbits / 8) global LSD passes (ascending (table, row, position) order, like round 2's segmented sort);
-// MODE 1 partitions on the LOW row digit (balanced buckets under any skew; order (table, row & 255, row >> 8, position));
-// MODE 2 partitions on the TOP row digit (ascending order; a skewed head makes its bucket large).
+// MODE 1 partitions on the LOW row digit (order (table, row & 255, row >> 8, position): buckets balanced under any skew, but
+//        neighbours in the sorted array are not neighbours in the table -- the apply kernel pays for that under skew);
+// MODE 2 partitions on the TOP row digit (ascending order; a skewed head makes its bucket a second-level segment).
 // Equal keys end up adjacent and in request order in every mode -- all the apply kernel needs.
 #include <cstdlib>
 
@@ -35,41 +39,61 @@ namespace {
 constexpr int kT = 256;                 // threads per workgroup
 constexpr int kWaves = kT / kWave;      // 4
 constexpr int kTile = 4096;             // elements per radix tile (16 per thread)
-constexpr int kTileItems = kTile / kT;
+constexpr int kTileItems = kTile / kT;  // 16
 constexpr int kRadix = 256;
-constexpr int kSmallItems = 8;          // bucket-local sort, small class: <= 2048 elements, registers
-constexpr int kBigItems = 40;           // big class: <= 10240 elements, one workgroup per CU (85 KB of LDS)
-constexpr uint32_t kSmallCap = kSmallItems * kT;
-constexpr uint32_t kBigCap = kBigItems * kT;
+constexpr uint32_t kWaveCap = 1024;     // bucket-local sort by one wave: 16 pairs per lane
+constexpr uint32_t kLocalCap = kTile;   // ... by one workgroup; larger buckets go to the second level
+constexpr int kL2Grid = 512;            // persistent grid of the second-level passes
+constexpr int kBuildBags = 1024;        // bags per workgroup of the key-building kernel
 
 struct SegHeader {
-    uint32_t n_total;   // elements in all segments (= length of the sorted arrays)
-    uint32_t n_tiles;   // radix tiles in all segments
-    uint32_t n_big;     // buckets in the big list
-    uint32_t n_huge;    // buckets in the huge list
+    uint32_t n_total;    // pairs in all segments (= length of the sorted arrays)
+    uint32_t n_tiles;    // radix tiles of the first level
+    uint32_t n_l2;       // buckets on the second-level list (= second-level segments)
+    uint32_t n_tiles2;   // radix tiles of the second level
     uint32_t pad[12];
 };
+
+// one per radix tile: a pass kernel's workgroup learns everything about its tile from one 32-byte load
+struct TileDesc {
+    uint32_t seg;        // segment (level 1: table; level 2: index into the second-level list)
+    uint32_t cnt;        // elements of the tile
+    uint32_t in_base;    // level 1: request position of the tile's first element
+    uint32_t out_base;   // position of the tile's first element in the sorted arrays
+    uint32_t first;      // position of the tile's first element inside its segment
+    uint32_t pooling;    // level 1: the segment's pooling factor (0: keys were built)
+    uint32_t rbits;      // bits to sort in this segment | (first bit << 8)
+    uint32_t magic;      // floor(2^32 / pooling) + 1: x / pooling = mulhi(x, magic), one step too high at most (fast_div)
+};
+
+// x / d for a d whose magic = floor(2^32 / d) + 1 is at hand: the multiply-high estimate is the quotient or one more
+__device__ __forceinline__ uint32_t fast_div(uint32_t x, uint32_t d, uint32_t magic) {
+    uint32_t q = d == 1 ? x : __umulhi(x, magic);
+    if (static_cast<uint64_t>(q) * d > x) --q;
+    return q;
+}
 
 __device__ __forceinline__ int bits_for_dev(uint64_t n_values) {   // bits needed to represent 0 .. n_values - 1
     return n_values <= 1 ? 0 : 64 - __builtin_clzll(n_values - 1);
 }
 
-// digit of pass `pass` for a table whose rows need `rbits` bits: (shift, width).  mode 0: LSD, 8 bits per pass from bit 0.
-// mode 1: pass 0 = the low digit.  mode 2: pass 0 = the top digit.  A width of 0 makes the pass a stable copy.
-__device__ __forceinline__ void pass_digit(int mode, int pass, int rbits, int& shift, uint32_t& mask) {
+// digit of pass `pass` for a segment that sorts `bits` bits starting at bit `bit0`: (shift, mask).  mode 0 / 1: LSD, 8 bits per
+// pass from bit0 (mode 1 runs pass 0 only).  mode 2: pass 0 = the top digit.  A width of 0 makes the pass a stable copy.
+__device__ __forceinline__ void pass_digit(int mode, int pass, uint32_t rbits_packed, int& shift, uint32_t& mask) {
+    const int bits = static_cast<int>(rbits_packed & 255u), bit0 = static_cast<int>(rbits_packed >> 8);
     int w;
     if (mode == 2) {
-        w = rbits < 8 ? rbits : 8;
-        shift = rbits - w;
+        w = bits < 8 ? bits : 8;
+        shift = bit0 + bits - w;
     } else {
-        shift = 8 * pass;
-        w = rbits - shift;
+        shift = bit0 + 8 * pass;
+        w = bits - 8 * pass;
         w = w < 0 ? 0 : (w > 8 ? 8 : w);
         if (w == 0) shift = 0;
     }
     mask = (1u << w) - 1u;
 }
-// bits the bucket-local sort still has to order: [lo, hi)
+// bits a (table, digit) bucket still has to order after the partition pass: [lo, hi)
 __device__ __forceinline__ void local_bits(int mode, int rbits, int& lo, int& hi) {
     if (mode == 2) { lo = 0; hi = rbits - 8; }
     else { lo = 8; hi = rbits; }
@@ -104,11 +128,18 @@ __device__ __forceinline__ uint32_t block_excl_scan256(uint32_t v, uint32_t* s_t
     return base + incl - v;
 }
 
+// the lanes of a wave hand LDS data to each other: LDS operations of one wave execute in order, the compiler must keep them so
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
-// prep 1: one workgroup per table
-__global__ void __launch_bounds__(kT) seg_prep_tables_kernel(const void* offsets, int idx64, const int64_t* rows, int T, int64_t B,
-                                                             int64_t N, int64_t bag_begin, int64_t bag_count, int force_ragged,
-                                                             SegDesc* desc) {
+// prep 1: one workgroup (1024 threads) per table
+__global__ void __launch_bounds__(1024) seg_prep_tables_kernel(const void* offsets, int idx64, const int64_t* rows, int T, int64_t B,
+                                                               int64_t N, int64_t bag_begin, int64_t bag_count, int force_ragged,
+                                                               SegDesc* desc) {
     const int t = blockIdx.x;
     const int64_t TB = static_cast<int64_t>(T) * B;
     const int64_t g0 = static_cast<int64_t>(t) * B + bag_begin;
@@ -119,8 +150,18 @@ __global__ void __launch_bounds__(kT) seg_prep_tables_kernel(const void* offsets
     const int64_t L = (bag_count > 0 && cnt > 0 && cnt % bag_count == 0) ? cnt / bag_count : 0;
     int bad = (L == 0 || force_ragged) ? 1 : 0;
     if (!bad) {
-        for (int64_t i = threadIdx.x; i < bag_count; i += kT)
-            if (off_at(g0 + i) != s + i * L) bad = 1;
+        // every bag of the (sliced) table must start where a pooling factor of L puts it; 8 independent loads per round trip
+        for (int64_t i0 = threadIdx.x; i0 < bag_count; i0 += 8 * 1024) {
+            int64_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t i = i0 + u * 1024;
+                v[u] = i < bag_count ? off_at(g0 + i) : s + i * L;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (v[u] != s + (i0 + u * 1024) * L) bad = 1;
+        }
     }
     bad = __syncthreads_or(bad);
     if (threadIdx.x == 0) {
@@ -137,24 +178,29 @@ __global__ void __launch_bounds__(kT) seg_prep_tables_kernel(const void* offsets
     }
 }
 
-// prep 2: one workgroup of 1024 threads (T <= 1024): exclusive scans over the tables, tile -> segment map, header
-__global__ void __launch_bounds__(1024) seg_prep_scan_kernel(SegDesc* desc, int T, SegHeader* hdr, uint32_t* tile_seg) {
-    __shared__ uint32_t s_cnt[1024], s_til[1024], s_tb[1025];
+// inclusive scan of two values per thread over 1024 threads in LDS (Hillis-Steele: one launch per sort, nothing cleverer needed)
+__device__ __forceinline__ void scan2_1024(uint32_t* s_a, uint32_t* s_b) {
+    const int t = threadIdx.x;
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t a = t >= off ? s_a[t - off] : 0u;
+        const uint32_t b = t >= off ? s_b[t - off] : 0u;
+        __syncthreads();
+        s_a[t] += a;
+        s_b[t] += b;
+        __syncthreads();
+    }
+}
+
+// prep 2: one workgroup of 1024 threads (T <= 1024): exclusive scans over the tables, tile descriptors, header
+__global__ void __launch_bounds__(1024) seg_prep_scan_kernel(SegDesc* desc, int T, SegHeader* hdr, TileDesc* tiles, uint32_t tiles_cap) {
+    __shared__ uint32_t s_cnt[1024], s_til[1024], s_tb[1025], s_out[1024];
     const int t = threadIdx.x;
     const uint32_t c = t < T ? desc[t].count : 0u;
     const uint32_t nt = t < T ? desc[t].ntiles : 0u;
     s_cnt[t] = c;
     s_til[t] = nt;
     __syncthreads();
-    // Hillis-Steele inclusive scans in LDS (one launch per sort, 1024 values: not worth anything cleverer)
-    for (int off = 1; off < 1024; off <<= 1) {
-        const uint32_t a = t >= off ? s_cnt[t - off] : 0u;
-        const uint32_t b = t >= off ? s_til[t - off] : 0u;
-        __syncthreads();
-        s_cnt[t] += a;
-        s_til[t] += b;
-        __syncthreads();
-    }
+    scan2_1024(s_cnt, s_til);
     const uint32_t out_start = s_cnt[t] - c, tile_base = s_til[t] - nt;
     const uint32_t n_total = s_cnt[1023], n_tiles = s_til[1023];
     __syncthreads();
@@ -162,32 +208,45 @@ __global__ void __launch_bounds__(1024) seg_prep_scan_kernel(SegDesc* desc, int 
         desc[t].out_start = out_start;
         desc[t].tile_base = tile_base;
         s_tb[t] = tile_base;
+        s_out[t] = out_start;
     }
     if (t == 0) {
         s_tb[T] = n_tiles;
         hdr->n_total = n_total;
         hdr->n_tiles = n_tiles;
-        hdr->n_big = 0;
-        hdr->n_huge = 0;
+        hdr->n_l2 = 0;
+        hdr->n_tiles2 = 0;
     }
     __syncthreads();
-    for (uint32_t g = t; g < n_tiles; g += 1024) {
-        int lo = 0, hi = T;             // largest t with s_tb[t] <= g (segments without tiles repeat their neighbour's base)
+    const uint32_t n_write = n_tiles < tiles_cap ? n_tiles : tiles_cap;
+    for (uint32_t g = t; g < n_write; g += 1024) {
+        int lo = 0, hi = T;         // largest t with s_tb[t] <= g (segments without tiles repeat their neighbour's base)
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
             if (s_tb[mid] <= g) lo = mid; else hi = mid;
         }
-        tile_seg[g] = static_cast<uint32_t>(lo);
+        const SegDesc d = desc[lo];   // fields of prep 1 only: this kernel's own writes to other entries may not be visible yet
+        const uint32_t first = (g - s_tb[lo]) * static_cast<uint32_t>(kTile);
+        TileDesc td;
+        td.seg = static_cast<uint32_t>(lo);
+        td.cnt = (d.count - first) < static_cast<uint32_t>(kTile) ? d.count - first : static_cast<uint32_t>(kTile);
+        td.in_base = d.in_start + first;
+        td.out_base = s_out[lo] + first;
+        td.first = first;
+        td.pooling = d.pooling;
+        td.rbits = d.rbits;
+        td.magic = d.pooling > 1 ? static_cast<uint32_t>(0x100000000ull / d.pooling) + 1u : 0u;
+        tiles[g] = td;
     }
 }
 
 // keys / values at request positions for the tables that have no pooling factor (and, WEIGHTED, for all: the value is the
-// lookup's position, its bag goes to bag_of).  grid (bag tiles of 256, T).
+// lookup's position, its bag goes to bag_of).  grid (bag tiles of 1024, T).
 template <typename K, bool WEIGHTED>
 __global__ void __launch_bounds__(kT) seg_build_keys_kernel(const void* indices, const void* offsets, int idx64, int T, int64_t B,
                                                             int64_t N, int64_t bag_begin, int64_t bag_count, const SegDesc* desc,
                                                             int tshift, K* keys, uint32_t* vals, uint32_t* bag_of) {
-    constexpr int kBags = 256;
+    constexpr int kBags = kBuildBags;
     __shared__ int64_t s_off[kBags + 1];
     const int t = blockIdx.y;
     if (!WEIGHTED && desc[t].pooling > 0) return;
@@ -218,92 +277,96 @@ __global__ void __launch_bounds__(kT) seg_build_keys_kernel(const void* indices,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// What a pass reads: pass 0 the request (index array, or the built keys of tables without a pooling factor) at request
-// positions; later passes the previous pass's output at output positions.
+// What a pass reads: pass 0 of level 1 the request (index array, or the built keys of tables without a pooling factor) at
+// request positions; every other pass the previous pass's output at output positions.
 template <typename K>
 struct PassSrc {
-    const void* indices;    // pass 0
+    const void* indices;    // level 1, pass 0
     int idx64;
-    const K* keys;          // pass 0: built keys (request positions); later: previous output
+    const K* keys;          // level 1, pass 0: built keys (request positions); otherwise: the previous output
     const uint32_t* vals;
-    int first;              // 1: pass 0
+    int first;              // 1: level 1, pass 0
     int tshift;
     uint32_t bag_begin;
 };
 
+// tiles are taken g = blockIdx.x, + gridDim.x, ... < *n_tiles: level 1 launches one workgroup per possible tile, level 2 a
+// persistent grid (the tile count of level 2 is known only on the device, and is zero for most requests)
 template <typename K>
-__global__ void __launch_bounds__(kT) seg_hist_kernel(const SegHeader* hdr, const SegDesc* desc, const uint32_t* tile_seg,
-                                                      const PassSrc<K> src, int mode, int pass, uint32_t* bh) {
+__global__ void __launch_bounds__(kT) seg_hist_kernel(const TileDesc* tiles, const uint32_t* n_tiles, const PassSrc<K> src, int mode, int pass,
+                                                      uint32_t* bh) {
     __shared__ uint32_t h[kRadix];
-    const uint32_t g = blockIdx.x;
-    if (g >= hdr->n_tiles) return;
-    const uint32_t t = tile_seg[g];
-    const SegDesc d = desc[t];
-    const uint32_t first = (g - d.tile_base) * static_cast<uint32_t>(kTile);
-    const uint32_t cnt = (d.count - first) < static_cast<uint32_t>(kTile) ? d.count - first : static_cast<uint32_t>(kTile);
-    int shift;
-    uint32_t mask;
-    pass_digit(mode, pass, static_cast<int>(d.rbits), shift, mask);
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const int lane = threadIdx.x % kWave;
-    const uint64_t base = static_cast<uint64_t>(src.first ? d.in_start : d.out_start) + first;
+    // the first descriptor is fetched together with the tile count, not after it (grids never exceed the descriptor arrays):
+    // a workgroup's start-up is a chain of dependent loads, and every link costs a memory latency that nothing hides
+    TileDesc td = tiles[blockIdx.x];
+    const uint32_t nt = *n_tiles;
+    for (uint32_t g = blockIdx.x; g < nt; g += gridDim.x) {
+        if (g != blockIdx.x) td = tiles[g];
+        const uint32_t cnt = td.cnt;
+        int shift;
+        uint32_t mask;
+        pass_digit(mode, pass, td.rbits, shift, mask);
+        h[threadIdx.x] = 0;
+        __syncthreads();
+        const int lane = threadIdx.x % kWave;
+        const uint64_t base = src.first ? td.in_base : td.out_base;
 #pragma unroll 4
-    for (int k = 0; k < kTileItems; ++k) {
-        const uint32_t i = static_cast<uint32_t>(k) * kT + threadIdx.x;
-        const bool valid = i < cnt;
-        uint32_t dg = 0u;
-        if (valid) {
-            // the row digit of pass 0 can always be taken from the index array (built keys carry the same row bits)
-            const uint64_t row = src.first ? static_cast<uint64_t>(load_index(src.indices, static_cast<int64_t>(base + i), src.idx64))
-                                           : static_cast<uint64_t>(src.keys[base + i]);
-            dg = static_cast<uint32_t>(row >> shift) & mask;
+        for (int k = 0; k < kTileItems; ++k) {
+            const uint32_t i = static_cast<uint32_t>(k) * kT + threadIdx.x;
+            const bool valid = i < cnt;
+            uint32_t dg = 0u;
+            if (valid) {
+                // the row digit of pass 0 can always be taken from the index array (built keys carry the same row bits)
+                const uint64_t row = src.first ? static_cast<uint64_t>(load_index(src.indices, static_cast<int64_t>(base + i), src.idx64))
+                                               : static_cast<uint64_t>(src.keys[base + i]);
+                dg = static_cast<uint32_t>(row >> shift) & mask;
+            }
+            // a wave whose keys share the digit adds once (top digits of a skewed head, small tables); else one LDS atomic per lane
+            const uint64_t vmask = __ballot(valid);
+            const uint32_t firstd = __builtin_amdgcn_readfirstlane(dg);
+            const bool uniform = __ballot(valid && dg != firstd) == 0 && (vmask & 1ull);
+            if (uniform) {
+                if (lane == 0) atomicAdd(&h[firstd], static_cast<uint32_t>(__popcll(vmask)));
+            } else if (valid) {
+                atomicAdd(&h[dg], 1u);
+            }
         }
-        // a wave whose keys share the digit adds once (top digits of a skewed head, small tables); else one LDS atomic per lane
-        const uint64_t vmask = __ballot(valid);
-        const uint32_t firstd = __builtin_amdgcn_readfirstlane(dg);
-        const bool uniform = __ballot(valid && dg != firstd) == 0 && (vmask & 1ull);
-        if (uniform) {
-            if (lane == 0) atomicAdd(&h[firstd], static_cast<uint32_t>(__popcll(vmask)));
-        } else if (valid) {
-            atomicAdd(&h[dg], 1u);
-        }
+        __syncthreads();
+        bh[static_cast<uint64_t>(g) * kRadix + threadIdx.x] = h[threadIdx.x];
+        __syncthreads();
     }
-    __syncthreads();
-    bh[static_cast<uint64_t>(g) * kRadix + threadIdx.x] = h[threadIdx.x];
 }
 
 // per segment: exclusive prefix of the tile counts per digit (in place), absolute start and size of every (segment, digit)
-// bucket; classify != 0 (bucket-local sort follows): buckets too large for the small class go to the big / huge lists.
-__global__ void __launch_bounds__(kRadix) seg_scan_kernel(SegHeader* hdr, const SegDesc* desc, uint32_t* bh, uint32_t* bstart,
-                                                          uint32_t* bcnt, int classify, int mode, uint32_t* big_list,
-                                                          uint32_t* huge_list) {
+// bucket; classify != 0 (level 1 of modes 1 / 2): buckets too large for the local sort go to the second-level list.
+__global__ void __launch_bounds__(kRadix) seg_scan_kernel(SegHeader* hdr, const SegDesc* desc, const uint32_t* n_seg_dev, uint32_t n_seg_host,
+                                                          uint32_t* bh, uint32_t* bstart, uint32_t* bcnt, int classify, int mode,
+                                                          uint32_t* l2_list) {
     __shared__ uint32_t s_tmp[kWaves];
     const int d = threadIdx.x;
-    const uint32_t t = blockIdx.x;
-    const SegDesc sd = desc[t];
-    const uint64_t r0 = sd.tile_base;
-    uint32_t run = 0;
-    for (uint32_t r = 0; r < sd.ntiles; r += 8) {
-        uint32_t v[8];
+    const uint32_t n_seg = n_seg_dev ? *n_seg_dev : n_seg_host;
+    for (uint32_t t = blockIdx.x; t < n_seg; t += gridDim.x) {
+        const SegDesc sd = desc[t];
+        const uint64_t r0 = sd.tile_base;
+        uint32_t run = 0;
+        for (uint32_t r = 0; r < sd.ntiles; r += 8) {
+            uint32_t v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (r + u < sd.ntiles) ? bh[(r0 + r + u) * kRadix + d] : 0u;
+            for (int u = 0; u < 8; ++u) v[u] = (r + u < sd.ntiles) ? bh[(r0 + r + u) * kRadix + d] : 0u;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (r + u < sd.ntiles) bh[(r0 + r + u) * kRadix + d] = run;
-            run += v[u];
+            for (int u = 0; u < 8; ++u) {
+                if (r + u < sd.ntiles) bh[(r0 + r + u) * kRadix + d] = run;
+                run += v[u];
+            }
         }
-    }
-    const uint32_t start = sd.out_start + block_excl_scan256(run, s_tmp);
-    const uint32_t b = t * kRadix + d;
-    bstart[b] = start;
-    bcnt[b] = run;
-    if (classify && run > kSmallCap) {
-        int lo, hi;
-        local_bits(mode, static_cast<int>(sd.rbits), lo, hi);
-        if (hi > lo) {
-            if (run <= kBigCap) big_list[atomicAdd(&hdr->n_big, 1u)] = b;
-            else huge_list[atomicAdd(&hdr->n_huge, 1u)] = b;
+        const uint32_t start = sd.out_start + block_excl_scan256(run, s_tmp);
+        const uint32_t b = t * kRadix + d;
+        bstart[b] = start;
+        bcnt[b] = run;
+        if (classify && run > kLocalCap) {
+            int lo, hi;
+            local_bits(mode, static_cast<int>(sd.rbits), lo, hi);
+            if (hi > lo) l2_list[atomicAdd(&hdr->n_l2, 1u)] = b;
         }
     }
 }
@@ -365,29 +428,19 @@ __device__ __forceinline__ void tile_stage_by_digit(const K (&key)[ITEMS], const
     __syncthreads();
 }
 
+// one tile of a scatter pass (inlined into both kernels below: the LDS arrays keep their address space)
 template <typename K>
-__global__ void __launch_bounds__(kT) seg_scatter_kernel(const SegHeader* hdr, const SegDesc* desc, const uint32_t* tile_seg,
-                                                         const PassSrc<K> src, int mode, int pass, const uint32_t* prefix,
-                                                         const uint32_t* bstart, K* kout, uint32_t* vout) {
-    __shared__ K s_key[kTile];
-    __shared__ uint32_t s_val[kTile];
-    __shared__ uint32_t s_wcnt[kWaves * kRadix];
-    __shared__ uint32_t s_dstart[kRadix];
-    __shared__ uint32_t s_gbase[kRadix];
-    __shared__ uint32_t s_tmp[kWaves];
-    const uint32_t g = blockIdx.x;
-    if (g >= hdr->n_tiles) return;
-    const uint32_t t = tile_seg[g];
-    const SegDesc d = desc[t];
-    const uint32_t first = (g - d.tile_base) * static_cast<uint32_t>(kTile);
-    const uint32_t cnt = (d.count - first) < static_cast<uint32_t>(kTile) ? d.count - first : static_cast<uint32_t>(kTile);
-    int shift;
-    uint32_t mask;
-    pass_digit(mode, pass, static_cast<int>(d.rbits), shift, mask);
+__device__ __forceinline__ void scatter_tile(const TileDesc td, uint32_t g, const PassSrc<K>& src, int mode, int pass, const uint32_t* prefix,
+                                             const uint32_t* bstart, K* kout, uint32_t* vout, K* s_key, uint32_t* s_val, uint32_t* s_wcnt,
+                                             uint32_t* s_dstart, uint32_t* s_gbase, uint32_t* s_tmp, uint32_t lane_zero) {
     const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
     constexpr uint32_t chunk = kTile / kWaves;
-    const uint64_t base = static_cast<uint64_t>(src.first ? d.in_start : d.out_start) + first;
-    const bool from_idx = src.first && d.pooling > 0;     // keys formed from the index array, bag = position / pooling
+    const uint32_t t = td.seg, cnt = td.cnt, first = td.first;
+    int shift;
+    uint32_t mask;
+    pass_digit(mode, pass, td.rbits, shift, mask);
+    const uint64_t base = (src.first ? td.in_base : td.out_base) + lane_zero;
+    const bool from_idx = src.first && td.pooling > 0;    // keys formed from the index array, bag = position / pooling
     s_gbase[threadIdx.x] = bstart[t * kRadix + threadIdx.x] + prefix[static_cast<uint64_t>(g) * kRadix + threadIdx.x];
     K key[kTileItems];
     uint32_t val[kTileItems];
@@ -400,7 +453,7 @@ __global__ void __launch_bounds__(kT) seg_scatter_kernel(const SegHeader* hdr, c
         if (valid) {
             if (from_idx) {
                 key[r] = (static_cast<K>(t) << src.tshift) | static_cast<K>(load_index(src.indices, static_cast<int64_t>(base + pos), src.idx64));
-                val[r] = src.bag_begin + (first + pos) / d.pooling;
+                val[r] = src.bag_begin + fast_div(first + pos, td.pooling, td.magic);
             } else {
                 key[r] = src.keys[base + pos];
                 val[r] = src.vals[base + pos];
@@ -421,9 +474,45 @@ __global__ void __launch_bounds__(kT) seg_scatter_kernel(const SegHeader* hdr, c
     }
 }
 
+// level 1: one workgroup per possible tile (114 VGPRs: the four workgroups per CU that the 38 KB of LDS allow)
+template <typename K>
+__global__ void __launch_bounds__(kT) seg_scatter_kernel(const TileDesc* tiles, const uint32_t* n_tiles, const PassSrc<K> src, int mode, int pass,
+                                                         const uint32_t* prefix, const uint32_t* bstart, K* kout, uint32_t* vout) {
+    __shared__ K s_key[kTile];
+    __shared__ uint32_t s_val[kTile];
+    __shared__ uint32_t s_wcnt[kWaves * kRadix];
+    __shared__ uint32_t s_dstart[kRadix];
+    __shared__ uint32_t s_gbase[kRadix];
+    __shared__ uint32_t s_tmp[kWaves];
+    const TileDesc td = tiles[blockIdx.x];      // together with the tile count (see seg_hist_kernel)
+    if (blockIdx.x >= *n_tiles) return;
+    scatter_tile<K>(td, blockIdx.x, src, mode, pass, prefix, bstart, kout, vout, s_key, s_val, s_wcnt, s_dstart, s_gbase, s_tmp, 0u);
+}
+
+// level 2: persistent grid.  (A plain loop around the tile body lets the compiler hoist every lane-dependent address out of
+// it -- 179 VGPRs, two workgroups per CU --; the body's addresses therefore hang on a zero the compiler cannot see through.)
+template <typename K>
+__global__ void __launch_bounds__(kT) seg_scatter_loop_kernel(const TileDesc* tiles, const uint32_t* n_tiles, const PassSrc<K> src, int mode,
+                                                              int pass, const uint32_t* prefix, const uint32_t* bstart, K* kout, uint32_t* vout) {
+    __shared__ K s_key[kTile];
+    __shared__ uint32_t s_val[kTile];
+    __shared__ uint32_t s_wcnt[kWaves * kRadix];
+    __shared__ uint32_t s_dstart[kRadix];
+    __shared__ uint32_t s_gbase[kRadix];
+    __shared__ uint32_t s_tmp[kWaves];
+    const uint32_t nt = *n_tiles;
+#pragma clang loop unroll(disable)
+    for (uint32_t g = blockIdx.x; g < nt; g += gridDim.x) {
+        uint32_t lane_zero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+        scatter_tile<K>(tiles[g], g, src, mode, pass, prefix, bstart, kout, vout, s_key, s_val, s_wcnt, s_dstart, s_gbase, s_tmp, lane_zero);
+        __syncthreads();   // s_gbase / the staged tile are rewritten by the next tile
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
-// bucket-local sort (in place in the b buffers): the bucket's pairs are loaded into registers, ordered by their remaining
-// key bits with stable 8-bit rounds through LDS, and written back as one contiguous run.
+// bucket-local sort, workgroup form (in place in the b buffers): the bucket's pairs are loaded into registers, ordered by
+// their remaining key bits with stable 8-bit rounds through LDS, and written back as one contiguous run.
 template <typename K, int ITEMS>
 __device__ __forceinline__ void local_sort_bucket(K* kb, uint32_t* vb, uint32_t start, uint32_t n, int lo, int hi, K* s_key,
                                                   uint32_t* s_val, uint32_t* s_wcnt, uint32_t* s_dstart, uint32_t* s_tmp) {
@@ -461,135 +550,215 @@ __device__ __forceinline__ void local_sort_bucket(K* kb, uint32_t* vb, uint32_t 
         kb[start + q] = s_key[q];
         vb[start + q] = s_val[q];
     }
-    __syncthreads();             // the LDS tile is reused by the next bucket of a looping workgroup
+    __syncthreads();             // the LDS tile is reused by the next bucket
 }
 
-// a bucket too large for LDS: one workgroup sorts it by its remaining bits with stable 8-bit passes streamed through
-// global memory, ping-pong between the bucket's range of the b buffers and the same range of the (by now unused) a buffers
+// ... wave form: one wave sorts one bucket of up to 1024 pairs with its own slice of the LDS arrays and no workgroup barrier
+// (the four waves of a workgroup work on four different buckets: a 640-pair bucket -- the uniform benchmark's -- is a few
+// wave-steps of work, and four workgroup barriers per round cost more than the work)
 template <typename K>
-__device__ void huge_sort_bucket(K* kb, uint32_t* vb, K* ka, uint32_t* va, uint32_t start, uint32_t n, int lo, int hi, K* s_key,
-                                 uint32_t* s_val, uint32_t* s_wcnt, uint32_t* s_dstart, uint32_t* s_tmp, uint32_t* s_cnt,
-                                 uint32_t* s_base) {
-    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
-    constexpr int ITEMS = kTileItems;
-    constexpr uint32_t chunk = kTile / kWaves;
-    K* sk = kb + start;
-    uint32_t* sv = vb + start;
-    K* dk = ka + start;
-    uint32_t* dv = va + start;
-    bool in_b = true;
-    for (int shift = lo; shift < hi; shift += 8) {
+__device__ __forceinline__ void wave_sort_bucket(K* kb, uint32_t* vb, uint32_t start, uint32_t n, int lo, int hi, K* w_key, uint32_t* w_val,
+                                                 uint32_t* wcnt) {
+    constexpr int ITEMS = kWaveCap / kWave;   // 16
+    const int lane = threadIdx.x % kWave;
+    K key[ITEMS];
+    uint32_t val[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const uint32_t pos = static_cast<uint32_t>(r) * kWave + lane;
+        key[r] = pos < n ? kb[start + pos] : static_cast<K>(0);
+        val[r] = pos < n ? vb[start + pos] : 0u;
+    }
+    const int rounds = (hi - lo + 7) / 8;
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int shift = lo + 8 * rd;
         const int w = (hi - shift) < 8 ? (hi - shift) : 8;
         const uint32_t mask = (1u << w) - 1u;
-        s_cnt[threadIdx.x] = 0;
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += kT) atomicAdd(&s_cnt[static_cast<uint32_t>(sk[i] >> shift) & mask], 1u);
-        __syncthreads();
-        s_base[threadIdx.x] = block_excl_scan256(s_cnt[threadIdx.x], s_tmp);
-        __syncthreads();
-        for (uint32_t c0 = 0; c0 < n; c0 += kTile) {
-            const uint32_t cnt = (n - c0) < static_cast<uint32_t>(kTile) ? n - c0 : static_cast<uint32_t>(kTile);
-            K key[ITEMS];
-            uint32_t val[ITEMS];
+#pragma unroll
+        for (int i = 0; i < kRadix / kWave; ++i) wcnt[i * kWave + lane] = 0;
+        wave_lds_fence();
+        uint32_t rank[ITEMS];
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            rank[r] = 0;
+            if (static_cast<uint32_t>(r) * kWave < n) {     // wave-uniform
+                const bool valid = static_cast<uint32_t>(r) * kWave + lane < n;
+                const uint32_t d = static_cast<uint32_t>(key[r] >> shift) & mask;
+                const uint64_t m = match_digit8(d, valid);
+                const uint32_t below = static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+                const uint32_t base = valid ? wcnt[d] : 0u;
+                rank[r] = base + below;
+                if (valid && below == 0) wcnt[d] = base + static_cast<uint32_t>(__popcll(m));
+                wave_lds_fence();
+            }
+        }
+        // exclusive scan of the 256 digit counts by the wave: lane l owns digits 4l .. 4l+3
+        {
+            uint32_t c[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c[i] = wcnt[4 * lane + i];
+            const uint32_t sum = c[0] + c[1] + c[2] + c[3];
+            uint32_t incl = sum;
+#pragma unroll
+            for (int off = 1; off < kWave; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off, kWave);
+                if (lane >= off) incl += up;
+            }
+            uint32_t run = incl - sum;
+            wave_lds_fence();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wcnt[4 * lane + i] = run;
+                run += c[i];
+            }
+            wave_lds_fence();
+        }
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            if (static_cast<uint32_t>(r) * kWave + lane < n) {
+                const uint32_t d = static_cast<uint32_t>(key[r] >> shift) & mask;
+                const uint32_t q = wcnt[d] + rank[r];
+                w_key[q] = key[r];
+                w_val[q] = val[r];
+            }
+        }
+        wave_lds_fence();
+        if (rd + 1 < rounds) {
 #pragma unroll
             for (int r = 0; r < ITEMS; ++r) {
-                const uint32_t pos = wave * chunk + r * kWave + lane;
-                key[r] = pos < cnt ? sk[c0 + pos] : static_cast<K>(0);
-                val[r] = pos < cnt ? sv[c0 + pos] : 0u;
+                const uint32_t pos = static_cast<uint32_t>(r) * kWave + lane;
+                if (pos < n) {
+                    key[r] = w_key[pos];
+                    val[r] = w_val[pos];
+                }
             }
-            tile_stage_by_digit<K, ITEMS>(key, val, cnt, chunk, shift, mask, s_key, s_val, s_wcnt, s_dstart, s_tmp);
-            for (uint32_t q = threadIdx.x; q < cnt; q += kT) {
-                const K kk = s_key[q];
-                const uint32_t dg = static_cast<uint32_t>(kk >> shift) & mask;
-                const uint32_t o = s_base[dg] + (q - s_dstart[dg]);
-                dk[o] = kk;
-                dv[o] = s_val[q];
-            }
-            __syncthreads();
-            {   // the digit's running output position moves on by what this chunk held of it
-                const int d = threadIdx.x;
-                const uint32_t next = d + 1 < kRadix ? s_dstart[d + 1] : cnt;
-                s_base[d] += next - s_dstart[d];
-            }
-            __syncthreads();
-        }
-        // the pass's stores must be visible to the next pass's loads by the other waves of this workgroup, whose CU may
-        // still hold lines of this range in its vector L1 from an earlier pass: agent-scope release + acquire (write-back,
-        // L1 invalidate; MI355X_MICROARCH.md, inter-workgroup visibility) -- a few microseconds on a slow path
-        __threadfence();
-        __syncthreads();
-        K* tk = sk; sk = dk; dk = tk;
-        uint32_t* tv = sv; sv = dv; dv = tv;
-        in_b = !in_b;
-    }
-    if (!in_b) {   // the sorted run sits in the a buffers: bring it home
-        for (uint32_t i = threadIdx.x; i < n; i += kT) {
-            dk[i] = sk[i];
-            dv[i] = sv[i];
+            wave_lds_fence();
         }
     }
-    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const uint32_t pos = static_cast<uint32_t>(r) * kWave + lane;
+        if (pos < n) {
+            kb[start + pos] = w_key[pos];
+            vb[start + pos] = w_val[pos];
+        }
+    }
 }
 
-// SMALL: one workgroup per (table, digit) bucket, grid T * 256; buckets above the small cap are left to the big launch
+// one workgroup per FOUR consecutive (table, digit) buckets: buckets of up to 1024 pairs are taken by one wave each, then
+// those of up to 4096 by the whole workgroup; larger ones are second-level segments (seg_scan_kernel listed them)
 template <typename K>
-__global__ void __launch_bounds__(kT) seg_local_small_kernel(const SegDesc* desc, const uint32_t* bstart, const uint32_t* bcnt, int mode,
-                                                             K* kb, uint32_t* vb) {
-    __shared__ K s_key[kSmallCap];
-    __shared__ uint32_t s_val[kSmallCap];
+__global__ void __launch_bounds__(kT) seg_local_kernel(const SegDesc* desc, const uint32_t* bstart, const uint32_t* bcnt, uint32_t n_buckets,
+                                                       int mode, K* kb, uint32_t* vb) {
+    __shared__ K s_key[kTile];
+    __shared__ uint32_t s_val[kTile];
     __shared__ uint32_t s_wcnt[kWaves * kRadix];
     __shared__ uint32_t s_dstart[kRadix];
     __shared__ uint32_t s_tmp[kWaves];
-    const uint32_t b = blockIdx.x;
-    const uint32_t n = bcnt[b];
-    if (n < 2 || n > kSmallCap) return;
+    const int wave = threadIdx.x / kWave;
+    const uint32_t b0 = blockIdx.x * kWaves;
+    uint32_t n4[kWaves];
+    bool any_wg = false;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+        n4[w] = (b0 + w < n_buckets) ? bcnt[b0 + w] : 0u;
+        any_wg = any_wg || (n4[w] > kWaveCap && n4[w] <= kLocalCap);
+    }
     int lo, hi;
-    local_bits(mode, static_cast<int>(desc[b / kRadix].rbits), lo, hi);
+    local_bits(mode, static_cast<int>(desc[b0 / kRadix].rbits), lo, hi);     // the four buckets belong to one table (256 % 4 == 0)
     if (hi <= lo) return;
-    local_sort_bucket<K, kSmallItems>(kb, vb, bstart[b], n, lo, hi, s_key, s_val, s_wcnt, s_dstart, s_tmp);
+    {
+        const uint32_t n = n4[0] * (wave == 0) + n4[1] * (wave == 1) + n4[2] * (wave == 2) + n4[3] * (wave == 3);
+        if (n >= 2 && n <= kWaveCap)
+            wave_sort_bucket<K>(kb, vb, bstart[b0 + wave], n, lo, hi, s_key + wave * kWaveCap, s_val + wave * kWaveCap, s_wcnt + wave * kRadix);
+    }
+    if (!any_wg) return;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+        if (n4[w] > kWaveCap && n4[w] <= kLocalCap)
+            local_sort_bucket<K, kTileItems>(kb, vb, bstart[b0 + w], n4[w], lo, hi, s_key, s_val, s_wcnt, s_dstart, s_tmp);
+    }
 }
 
-// BIG + HUGE: a fixed grid walks the two lists the scan kernel made
-template <typename K>
-__global__ void __launch_bounds__(kT) seg_local_big_kernel(const SegHeader* hdr, const SegDesc* desc, const uint32_t* bstart,
-                                                           const uint32_t* bcnt, const uint32_t* big_list, const uint32_t* huge_list,
-                                                           int mode, K* kb, uint32_t* vb, K* ka, uint32_t* va) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    K* s_key = reinterpret_cast<K*>(smem);
-    uint32_t* s_val = reinterpret_cast<uint32_t*>(smem + sizeof(K) * kBigCap);
-    uint32_t* s_wcnt = s_val + kBigCap;
-    uint32_t* s_dstart = s_wcnt + kWaves * kRadix;
-    uint32_t* s_tmp = s_dstart + kRadix;
-    uint32_t* s_cnt = s_tmp + kWaves;
-    uint32_t* s_base = s_cnt + kRadix;
-    const uint32_t n_big = hdr->n_big, n_huge = hdr->n_huge;
-    // huge buckets first: they are the long poles
-    for (uint32_t i = blockIdx.x; i < n_huge; i += gridDim.x) {
-        const uint32_t b = huge_list[i];
-        int lo, hi;
-        local_bits(mode, static_cast<int>(desc[b / kRadix].rbits), lo, hi);
-        huge_sort_bucket<K>(kb, vb, ka, va, bstart[b], bcnt[b], lo, hi, s_key, s_val, s_wcnt, s_dstart, s_tmp, s_cnt, s_base);
+// second level: the listed buckets become segments (in place in the b buffers) of an LSD sort over their remaining bits
+__global__ void __launch_bounds__(1024) seg_l2_prep_kernel(SegHeader* hdr, const SegDesc* desc, const uint32_t* bstart, const uint32_t* bcnt,
+                                                           const uint32_t* l2_list, int mode, SegDesc* desc2, uint32_t seg2_cap, TileDesc* tiles2,
+                                                           uint32_t tiles2_cap) {
+    __shared__ uint32_t s_til[1024], s_dummy[1024];
+    __shared__ uint32_t s_carry;
+    const int t = threadIdx.x;
+    uint32_t n2 = hdr->n_l2;
+    if (n2 > seg2_cap) n2 = seg2_cap;          // cannot happen (every listed bucket holds > 4096 pairs); keeps the writes in bounds
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < n2; c0 += 1024) {
+        const uint32_t i = c0 + t;
+        uint32_t b = 0, cnt = 0, nt = 0;
+        if (i < n2) {
+            b = l2_list[i];
+            cnt = bcnt[b];
+            nt = (cnt + kTile - 1) / kTile;
+        }
+        s_til[t] = nt;
+        s_dummy[t] = 0;
+        __syncthreads();
+        scan2_1024(s_til, s_dummy);
+        const uint32_t tile_base = s_carry + s_til[t] - nt;
+        if (i < n2) {
+            int lo, hi;
+            local_bits(mode, static_cast<int>(desc[b / kRadix].rbits), lo, hi);
+            const uint32_t start = bstart[b];
+            SegDesc d;
+            d.in_start = start;
+            d.count = cnt;
+            d.out_start = start;
+            d.pooling = 0;
+            d.tile_base = tile_base;
+            d.ntiles = nt;
+            d.rbits = static_cast<uint32_t>(hi - lo) | (static_cast<uint32_t>(lo) << 8);
+            d.pad = b;
+            desc2[i] = d;
+            for (uint32_t k = 0; k < nt && tile_base + k < tiles2_cap; ++k) {
+                TileDesc td;
+                td.seg = i;
+                td.first = k * static_cast<uint32_t>(kTile);
+                td.cnt = (cnt - td.first) < static_cast<uint32_t>(kTile) ? cnt - td.first : static_cast<uint32_t>(kTile);
+                td.in_base = td.out_base = start + td.first;
+                td.pooling = 0;
+                td.rbits = d.rbits;
+                td.magic = 0;
+                tiles2[tile_base + k] = td;
+            }
+        }
+        __syncthreads();
+        if (t == 1023) s_carry += s_til[1023];
+        __syncthreads();
     }
-    for (uint32_t i = blockIdx.x; i < n_big; i += gridDim.x) {
-        const uint32_t b = big_list[i];
-        int lo, hi;
-        local_bits(mode, static_cast<int>(desc[b / kRadix].rbits), lo, hi);
-        local_sort_bucket<K, kBigItems>(kb, vb, bstart[b], bcnt[b], lo, hi, s_key, s_val, s_wcnt, s_dstart, s_tmp);
-    }
+    if (t == 0) hdr->n_tiles2 = s_carry < tiles2_cap ? s_carry : tiles2_cap;
 }
 
 inline size_t a256(size_t x) { return (x + 255) / 256 * 256; }
 inline size_t tiles_max(size_t n, int T) { return n / kTile + static_cast<size_t>(T) + 1; }
+inline size_t seg2_max(size_t n) { return n / kTile + 1; }                 // every second-level segment holds more than a tile
+inline size_t tiles2_max(size_t n) {
+    const size_t t2 = n / kTile + seg2_max(n) + 1;
+    return t2 < static_cast<size_t>(kL2Grid) ? static_cast<size_t>(kL2Grid) : t2;   // the persistent grid reads tiles2[blockIdx.x] before it knows the count
+}
 
 struct Scratch {
     SegHeader* hdr;
     SegDesc* desc;
-    uint32_t* tile_seg;
+    TileDesc* tiles;
     uint32_t* bh;
     uint32_t* bstart;
     uint32_t* bcnt;
-    uint32_t* big_list;
-    uint32_t* huge_list;
+    uint32_t* l2_list;
+    SegDesc* desc2;
+    TileDesc* tiles2;
+    uint32_t* bh2;
+    uint32_t* bstart2;
+    uint32_t* bcnt2;
     size_t total;
 };
 
@@ -598,15 +767,19 @@ Scratch scratch_layout(void* base, size_t n, int T) {
     char* p = reinterpret_cast<char*>(base);
     size_t off = 0;
     auto take = [&](size_t bytes) { char* q = p ? p + off : nullptr; off += a256(bytes); return q; };
-    const size_t tm = tiles_max(n, T), nb = static_cast<size_t>(T) * kRadix;
+    const size_t tm = tiles_max(n, T), nb = static_cast<size_t>(T) * kRadix, s2 = seg2_max(n), t2 = tiles2_max(n);
     s.hdr = reinterpret_cast<SegHeader*>(take(sizeof(SegHeader)));
     s.desc = reinterpret_cast<SegDesc*>(take(sizeof(SegDesc) * static_cast<size_t>(T)));
-    s.tile_seg = reinterpret_cast<uint32_t*>(take(4 * tm));
+    s.tiles = reinterpret_cast<TileDesc*>(take(sizeof(TileDesc) * tm));
     s.bh = reinterpret_cast<uint32_t*>(take(4 * tm * kRadix));
     s.bstart = reinterpret_cast<uint32_t*>(take(4 * nb));
     s.bcnt = reinterpret_cast<uint32_t*>(take(4 * nb));
-    s.big_list = reinterpret_cast<uint32_t*>(take(4 * nb));
-    s.huge_list = reinterpret_cast<uint32_t*>(take(4 * nb));
+    s.l2_list = reinterpret_cast<uint32_t*>(take(4 * nb));
+    s.desc2 = reinterpret_cast<SegDesc*>(take(sizeof(SegDesc) * s2));
+    s.tiles2 = reinterpret_cast<TileDesc*>(take(sizeof(TileDesc) * t2));
+    s.bh2 = reinterpret_cast<uint32_t*>(take(4 * t2 * kRadix));
+    s.bstart2 = reinterpret_cast<uint32_t*>(take(4 * s2 * kRadix));
+    s.bcnt2 = reinterpret_cast<uint32_t*>(take(4 * s2 * kRadix));
     s.total = off;
     return s;
 }
@@ -631,11 +804,11 @@ hipError_t seg_sort_pairs(const SegSortRequest& rq, int mode, K* keys_a, K* keys
     const size_t n = static_cast<size_t>(rq.N);
     const Scratch s = scratch_layout(scratch, n, rq.T);
     const unsigned tm = static_cast<unsigned>(tiles_max(n, rq.T));
-    hipLaunchKernelGGL(seg_prep_tables_kernel, dim3(rq.T), dim3(kT), 0, stream, rq.offsets, rq.idx64, rq.rows, rq.T, rq.B, rq.N,
+    hipLaunchKernelGGL(seg_prep_tables_kernel, dim3(rq.T), dim3(1024), 0, stream, rq.offsets, rq.idx64, rq.rows, rq.T, rq.B, rq.N,
                        rq.bag_begin, rq.bag_count, rq.weighted ? 1 : 0, s.desc);
-    hipLaunchKernelGGL(seg_prep_scan_kernel, dim3(1), dim3(1024), 0, stream, s.desc, rq.T, s.hdr, s.tile_seg);
+    hipLaunchKernelGGL(seg_prep_scan_kernel, dim3(1), dim3(1024), 0, stream, s.desc, rq.T, s.hdr, s.tiles, tm);
     if (rq.bag_count > 0) {
-        const dim3 gk(static_cast<unsigned>((rq.bag_count + 255) / 256), static_cast<unsigned>(rq.T));
+        const dim3 gk(static_cast<unsigned>((rq.bag_count + kBuildBags - 1) / kBuildBags), static_cast<unsigned>(rq.T));
         if (rq.weighted)
             hipLaunchKernelGGL((seg_build_keys_kernel<K, true>), gk, dim3(kT), 0, stream, rq.indices, rq.offsets, rq.idx64, rq.T, rq.B, rq.N,
                                rq.bag_begin, rq.bag_count, s.desc, rq.tshift, keys_a, vals_a, bag_of);
@@ -644,38 +817,47 @@ hipError_t seg_sort_pairs(const SegSortRequest& rq, int mode, K* keys_a, K* keys
                                rq.bag_begin, rq.bag_count, s.desc, rq.tshift, keys_a, vals_a, bag_of);
     }
     // pass 0 reads the request (or the built keys in the a buffers) and writes the b buffers; later passes alternate, so the
-    // sorted pairs end in the b buffers iff the pass count is odd (seg_sort_result_in_b).  The local modes run one global
-    // pass and then work in place in b, with the a buffers as the huge buckets' spare space.
+    // sorted pairs end in the b buffers iff the pass count is odd (seg_sort_result_in_b).  Modes 1 / 2 run one global pass and
+    // then work in place in b; the a buffers are the second level's spare space.
     const int total = seg_sort_passes(mode, rq.rbits_max);
+    PassSrc<K> src;
+    src.indices = rq.indices;
+    src.idx64 = rq.idx64;
+    src.tshift = rq.tshift;
+    src.bag_begin = static_cast<uint32_t>(rq.bag_begin);
     for (int p = 0; p < total; ++p) {
-        PassSrc<K> src;
-        src.indices = rq.indices;
-        src.idx64 = rq.idx64;
         src.first = p == 0 ? 1 : 0;
-        src.tshift = rq.tshift;
-        src.bag_begin = static_cast<uint32_t>(rq.bag_begin);
         src.keys = p == 0 ? keys_a : (p % 2 == 1 ? keys_b : keys_a);
         src.vals = p == 0 ? vals_a : (p % 2 == 1 ? vals_b : vals_a);
         K* kout = (p % 2 == 0) ? keys_b : keys_a;
         uint32_t* vout = (p % 2 == 0) ? vals_b : vals_a;
-        hipLaunchKernelGGL((seg_hist_kernel<K>), dim3(tm), dim3(kT), 0, stream, s.hdr, s.desc, s.tile_seg, src, mode, p, s.bh);
-        hipLaunchKernelGGL(seg_scan_kernel, dim3(rq.T), dim3(kRadix), 0, stream, s.hdr, s.desc, s.bh, s.bstart, s.bcnt,
-                           (mode != 0 && p == 0) ? 1 : 0, mode, s.big_list, s.huge_list);
-        hipLaunchKernelGGL((seg_scatter_kernel<K>), dim3(tm), dim3(kT), 0, stream, s.hdr, s.desc, s.tile_seg, src, mode, p, s.bh, s.bstart,
-                           kout, vout);
+        hipLaunchKernelGGL((seg_hist_kernel<K>), dim3(tm), dim3(kT), 0, stream, s.tiles, &s.hdr->n_tiles, src, mode, p, s.bh);
+        hipLaunchKernelGGL(seg_scan_kernel, dim3(rq.T), dim3(kRadix), 0, stream, s.hdr, s.desc, static_cast<const uint32_t*>(nullptr),
+                           static_cast<uint32_t>(rq.T), s.bh, s.bstart, s.bcnt, (mode != 0 && p == 0) ? 1 : 0, mode, s.l2_list);
+        hipLaunchKernelGGL((seg_scatter_kernel<K>), dim3(tm), dim3(kT), 0, stream, s.tiles, &s.hdr->n_tiles, src, mode, p, s.bh, s.bstart, kout,
+                           vout);
     }
-    if (mode != 0) {
-        hipLaunchKernelGGL((seg_local_small_kernel<K>), dim3(static_cast<unsigned>(rq.T) * kRadix), dim3(kT), 0, stream, s.desc, s.bstart,
-                           s.bcnt, mode, keys_b, vals_b);
-        const size_t lds = sizeof(K) * kBigCap + 4 * (kBigCap + kWaves * kRadix + kRadix + kWaves + kRadix + kRadix);
-        static bool attr_set[2] = {false, false};
-        if (!attr_set[sizeof(K) == 8]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&seg_local_big_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      static_cast<int>(lds));
-            attr_set[sizeof(K) == 8] = true;
+    if (mode != 0 && rq.rbits_max > 8) {
+        const uint32_t nb = static_cast<uint32_t>(rq.T) * kRadix;
+        hipLaunchKernelGGL((seg_local_kernel<K>), dim3((nb + kWaves - 1) / kWaves), dim3(kT), 0, stream, s.desc, s.bstart, s.bcnt, nb, mode,
+                           keys_b, vals_b);
+        // second level: LSD over the remaining bits of the listed buckets, b -> a -> b (an odd pass count gets a copy pass)
+        hipLaunchKernelGGL(seg_l2_prep_kernel, dim3(1), dim3(1024), 0, stream, s.hdr, s.desc, s.bstart, s.bcnt, s.l2_list, mode, s.desc2,
+                           static_cast<uint32_t>(seg2_max(n)), s.tiles2, static_cast<uint32_t>(tiles2_max(n)));
+        int p2 = (rq.rbits_max - 8 + 7) / 8;
+        if (p2 % 2) ++p2;
+        src.first = 0;
+        for (int q = 0; q < p2; ++q) {
+            src.keys = (q % 2 == 0) ? keys_b : keys_a;
+            src.vals = (q % 2 == 0) ? vals_b : vals_a;
+            K* kout = (q % 2 == 0) ? keys_a : keys_b;
+            uint32_t* vout = (q % 2 == 0) ? vals_a : vals_b;
+            hipLaunchKernelGGL((seg_hist_kernel<K>), dim3(kL2Grid), dim3(kT), 0, stream, s.tiles2, &s.hdr->n_tiles2, src, 0, q, s.bh2);
+            hipLaunchKernelGGL(seg_scan_kernel, dim3(kL2Grid / 2), dim3(kRadix), 0, stream, s.hdr, s.desc2, &s.hdr->n_l2, 0u, s.bh2, s.bstart2,
+                               s.bcnt2, 0, 0, static_cast<uint32_t*>(nullptr));
+            hipLaunchKernelGGL((seg_scatter_loop_kernel<K>), dim3(kL2Grid), dim3(kT), 0, stream, s.tiles2, &s.hdr->n_tiles2, src, 0, q, s.bh2,
+                               s.bstart2, kout, vout);
         }
-        hipLaunchKernelGGL((seg_local_big_kernel<K>), dim3(256), dim3(kT), lds, stream, s.hdr, s.desc, s.bstart, s.bcnt, s.big_list,
-                           s.huge_list, mode, keys_b, vals_b, keys_a, vals_a);
     }
     return hipGetLastError();
 }

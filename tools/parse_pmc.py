@@ -56,6 +56,10 @@ def label_rows(rows):
             out["bwd_fixup_uniform" if n_fix <= reps else "bwd_fixup_zipf"].append(val)
         elif "radix_sort" in name and "onesweep" in name:
             out["bwd_sort_pass_rocprim"].append(val)
+        elif "seg_scatter_kernel" in name:
+            out["bwd_sort_scatter_pass_seg"].append(val)
+        elif "seg_hist_kernel" in name:
+            out["bwd_sort_hist_pass_seg"].append(val)
         elif "rs_scatter_kernel" in name:
             out["bwd_sort_scatter_pass"].append(val)
         elif "rs_hist_kernel" in name:

@@ -21,6 +21,8 @@ ap.add_argument("--rows", type=int, default=10_000_000)
 ap.add_argument("--dtype", default="fp32")
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--policies", default="0,1,3,4")
+ap.add_argument("--runs", default="legacy,rot,seg0,seg1,seg2", help="which sorts to run")
+ap.add_argument("--requests", default="uniform,zipf1.05")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 T, R, D, B, L = a.tables, a.rows, 128, 8192, 20
@@ -29,6 +31,8 @@ es = 4 if a.dtype == "fp32" else 2
 m = param_amd.BatchedEmbeddingBagMI355([R] * T, D, dtype=dt, device=dev, init="normal", seed=1, fused_update=False)
 grad = torch.randn((B, T * D), device=dev)
 reqs = {"uniform": tbe_request([R] * T, B, L, 0.0, device=dev, seed=2), "zipf1.05": tbe_request([R] * T, B, L, 1.05, device=dev, seed=1)}
+reqs = {k: v for k, v in reqs.items() if k in a.requests.split(",")}
+runs = a.runs.split(",")
 bwd_bytes = T * B * L * (2 * D * es + 8) + T * B * (D * 4 + 8)
 
 
@@ -57,18 +61,32 @@ def run(tag, pol):
 
 
 pols = [int(x) for x in a.policies.split(",")]
+# ~50 ms of the same work before anything is timed: the first block after the set-up phase rides a clock / power transient
+for idx, off in reqs.values():
+    for _ in range(15):
+        m.scatter_add_(grad, idx, off, alpha=-1e-6, batch=B)
+torch.cuda.synchronize()
 # round 2's sort (host-side plan, fixed pooling): ascending rows vs lowest digit sorted last
 param_amd.set_backward_tuning(sort_impl=2)
 for rot in ("0", "1"):
+    if ("legacy", "rot")[int(rot)] not in runs:
+        continue
     os.environ["PARAM_AMD_EXP_DIGIT_ROT"] = rot
     for pol in (pols if rot == "0" else pols[:1]):
         run({"sort": "legacy", "digit_rot": int(rot)}, pol)
 os.environ["PARAM_AMD_EXP_DIGIT_ROT"] = "0"
+if "ph2" in runs:     # round 2's two-phase apply (lower / upper half of the bags in two launches), now with the sc1 row stores
+    param_amd.set_backward_tuning(sort_impl=2, max_phases=2)
+    for pol in pols:
+        run({"sort": "legacy", "phases": 2}, pol)
 # the segmented sort: LSD passes / low-digit partition + local / top-digit partition + local
 param_amd.set_backward_tuning(sort_impl=0)
 for mode in (0, 1, 2):
+    if f"seg{mode}" not in runs:
+        continue
     param_amd.set_sort_tuning(mode)
-    run({"sort": "seg", "mode": mode}, pols[0])
+    for pol in pols:
+        run({"sort": "seg", "mode": mode}, pol)
 param_amd.set_sort_tuning()
 param_amd.set_backward_tuning()
 param_amd.set_tuning()

@@ -19,6 +19,18 @@ for what in "$@"; do
     exp)
       timeout 600 python tools/r3_bwd_exp.py --iters 10 > "$out/bwd_exp.jsonl" 2> "$out/bwd_exp.err"
       cat "$out/bwd_exp.jsonl"; tail -3 "$out/bwd_exp.err" ;;
+    exp:*)
+      # exp:<runs>:<policies>[:dtype:tables]
+      IFS=: read -r _ runs pols dt tb <<< "$what"
+      timeout 600 python tools/r3_bwd_exp.py --iters 10 --runs "$runs" --policies "$pols" --dtype "${dt:-fp32}" --tables "${tb:-48}" > "$out/bwd_exp_${runs}_${pols}_${dt:-fp32}.jsonl" 2> "$out/bwd_exp.err"
+      python - "$out/bwd_exp_${runs}_${pols}_${dt:-fp32}.jsonl" <<'PY'
+import json,sys
+for ln in open(sys.argv[1]):
+    r=json.loads(ln)
+    tag=" ".join(f"{k}={r[k]}" for k in ("sort","mode","digit_rot","phases") if k in r)
+    print(f'{tag:28s} pol {r["row_policy"]} {r["indices"]:9s} {r["dtype"]} sort {r["sort_ms"]:.3f} apply {r["apply_ms"]:.3f} total {r["total_ms"]:.3f} frac {r["alg_frac_total"]:.3f} apply_frac {r["alg_frac_apply"]:.3f}')
+PY
+      tail -3 "$out/bwd_exp.err" ;;
     expbf16)
       timeout 600 python tools/r3_bwd_exp.py --iters 10 --dtype bf16 --tables 64 --policies 0 > "$out/bwd_exp_bf16.jsonl" 2> "$out/bwd_exp_bf16.err"
       cat "$out/bwd_exp_bf16.jsonl"; tail -3 "$out/bwd_exp_bf16.err" ;;
@@ -30,6 +42,36 @@ r=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print("value",r["value"],"roof",r["roofline"]["frac"],"bwd",{k:r["bwd_scatter_add"].get(k) for k in ("avg_s_sort_plus_apply","avg_s_apply_only","avg_s_sort","alg_frac")})
 u=r["bwd_scatter_add"].get("uniform",{}); print("bwd uniform",{k:u.get(k) for k in ("avg_s_sort_plus_apply","avg_s_apply_only","avg_s_sort","frac","apply_only_frac")})
 print("fwd_bwd",r["fwd_bwd_step"].get("avg_s"), r["fwd_bwd_step"].get("uniform",{}).get("avg_s")); print("cpu",r.get("cpu_baseline",{}).get("value"))
+PY
+      ;;
+    prof:*)
+      # prof:<runs>:<requests>  e.g. prof:seg0:uniform -- kernel trace of one sort flavour on one index distribution
+      IFS=: read -r _ runs reqs <<< "$what"
+      d=/tmp/r3prof_${runs}_${reqs}
+      rm -rf "$d"
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$d" -o p -- python "$GRAFT_REPO_ROOT/tools/r3_bwd_exp.py" --iters 10 --policies 0 --runs "$runs" --requests "$reqs" > "$d.out" 2> "$d.err")
+      f=$(find "$d" -name "*kernel_stats.csv" | head -1)
+      if [ -n "$f" ]; then cp "$f" "$out/prof_${runs}_${reqs}_kernel_stats.csv"; echo "== $runs $reqs"; head -22 "$f" | cut -c1-220; else echo "no stats for $runs $reqs"; tail -5 "$d.err"; ls -R "$d" | head; fi
+      ;;
+    pmc)
+      # separate rocprofv3 --pmc passes (no other trace domain), one counter group each; only the CSVs come home
+      mkdir -p "$out/pmc"
+      i=0
+      for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+        i=$((i+1)); d=/tmp/r3pmc_$i; rm -rf "$d"
+        (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$d" -o pmc -- \
+            python "$GRAFT_REPO_ROOT/tools/pmc_probe.py" --bwd --manifest "$GRAFT_REPO_ROOT/$out/pmc/pmc_manifest.json" > "$d.log" 2>&1)
+        mkdir -p "$out/pmc/pmc_$i"
+        f=$(find "$d" -name "*counter_collection.csv" | head -1)
+        [ -n "$f" ] && cp "$f" "$out/pmc/pmc_$i/pmc_counter_collection.csv" || tail -5 "$d.log"
+      done
+      python tools/parse_pmc.py "$out/pmc" r03_tmp > "$out/pmc_summary.json" 2> "$out/pmc_parse.err"
+      python - "$out/pmc_summary.json" <<'PY'
+import json,sys
+r=json.load(open(sys.argv[1]))
+print("calibration",r["calibration"])
+for k,v in r["kernels"].items():
+    print(k,{x:(round(v[x],4) if isinstance(v[x],float) else v[x]) for x in ("hbm_bytes_per_launch","algorithmic_bytes","hbm_over_algorithmic","l2_hit_rate","fetch_bytes_calibrated","write_bytes_calibrated") if x in v})
 PY
       ;;
     *) echo "unknown step $what" ;;
