@@ -215,6 +215,35 @@ class ShardedEmbeddingExchange:
         o = sum(self.fwd_recv_splits[:src])
         return self.recv[slot][o:o + self.fwd_recv_splits[src]].view(self.local_batch, self.widths[src])
 
+    def selfcheck(self, slot: int, peer_block: Callable, exact: bool = True, rtol: float = 1e-5) -> dict:
+        """Verify the payload of the forward exchange held in ``slot`` (already waited for) -- the reference's ``--c 1``
+        idea (comms_utils.py:997-1055: a collective's result is compared with what it must be), applied to the pooled
+        all-to-all: ``peer_block(src)`` returns what rank ``src`` must have sent THIS rank, ``[B_local, k]`` = the first k
+        columns of its block, recomputed locally from rank ``src``'s seeds (or None to skip that peer).  Every rank checks
+        its own receive buffer; the verdicts are combined with one MIN all-reduce, so every rank returns the same dict.
+        ``exact``: bit for bit (same kernel on both sides); otherwise ``rtol`` relative to the block's magnitude."""
+        bad, checked, worst = [], 0, 0.0
+        for src in range(self.world):
+            exp = peer_block(src)
+            if exp is None:
+                continue
+            checked += 1
+            got = self.recv_block(slot, src)[:, :exp.shape[1]]
+            if exact:
+                same = bool(torch.equal(got, exp))
+            else:
+                same = bool(((got - exp).abs() <= rtol * exp.abs().max().clamp_min(1e-30)).all())
+            if not same:
+                bad.append(src)
+                worst = max(worst, float((got - exp).abs().max()))
+        flag = torch.tensor([0 if bad else 1, checked], dtype=torch.int64, device=self.recv[slot].device)
+        if dist.is_initialized():
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
+        ok_everywhere, min_checked = bool(int(flag[0])), int(flag[1])
+        return {"a2a_selfcheck": "ok" if ok_everywhere else "MISMATCH", "this_rank_ok": not bad, "peers_checked": checked,
+                "min_peers_checked_over_ranks": min_checked, "mismatched_sources_on_this_rank": bad, "max_abs_diff": worst,
+                "ranks": self.world}
+
     def bytes_per_rank(self) -> int:
         """output-tensor bytes of ONE exchange per rank (the reference's ``memSize``, which stays the fp32 size under
         ``--bitwidth``: the report scales busBW by bitwidth / 32 instead, comms.py:1149); forward and backward are equal

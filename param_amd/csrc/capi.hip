@@ -34,7 +34,9 @@ int hip_fail(hipError_t rc, const char* what) {
 bool dtype_is_weight(int d) { return d == PM_F32 || d == PM_BF16 || d == PM_F16; }
 
 // Validate the host-visible part of a request and derive the launch geometry.
-int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p) {
+// forward = the call is pm_embbag_fwd / pm_embbag_fwd_quantized: only those get the staged-output geometry (smaller tiles,
+// index tile sized for the request) and work tiles; every other entry point keeps the plain bag-count tiling.
+int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool forward = false) {
     if (!op) return fail(PM_ERR_INVALID, "op is NULL");
     if (op->num_tables < 1) return fail(PM_ERR_INVALID, "num_tables must be >= 1");
     if (!dtype_is_weight(elem_dtype)) return fail(PM_ERR_INVALID, "weight/dst dtype must be PM_F32, PM_BF16 or PM_F16");
@@ -125,7 +127,8 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p) {
     // buffer fits 16 KB (the tile is halved until it does).  pm_set_forward_tuning(0) / PARAM_AMD_FWD_STAGE=0 turn it off.
     p.out_bits = 0;
     p.stage_out = 0;
-    {
+    p.stage_bags = 0;
+    if (forward) {
         int want = g_stage_out.load();
         if (want < 0) {
             const char* e = getenv("PARAM_AMD_FWD_STAGE");
@@ -156,6 +159,20 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p) {
             // tile): the staging buffer is 4 KB, the full-size index tile stays -- 20.6 KB per workgroup
             p.stage_out = op->max_dim;
         }
+        p.stage_bags = p.bags_per_block;
+        // Two tilings built and measured in round 3 for requests whose tables have very different pooling factors (Criteo
+        // multi-hot 1 .. 100) -- both slower than the 8-bag tiles in table-major order, which stay:
+        //  * WORK tiles (~640 lookups per tile whatever the pooling factor, tile boundaries derived on the device from the
+        //    tables' lookup counts): 186 us against 120 us under Zipf, 249 against 185 us under uniform indices (caps of
+        //    32 .. 1024 bags, targets of 320 .. 1280: all slower).  A pooling-1 bag is ONE row load; a lane group walking 16 ..
+        //    128 of them in turn has one load in flight where 1024 eight-bag workgroups have them all in flight at once -- the
+        //    small tiles ARE the memory-level parallelism.  Removed again (profiles/r03_criteo_fwd_work_tiles.txt).
+        //  * tile-major block order (t = b % T, so every table advances at the same rate and the heavy table's long workgroups
+        //    start throughout the launch): 165 against 120 us under Zipf, 220 against 186 us uniform -- a table's tiles then run
+        //    on all eight XCDs at once and on every CU next to other tables' rows.  Kept behind PARAM_AMD_FWD_TILE_MAJOR=1.
+        static const int tm_env = [] { const char* e = getenv("PARAM_AMD_FWD_TILE_MAJOR"); return e ? atoi(e) : -1; }();
+        const bool uneven = total_bags > 0 && op->num_indices % total_bags != 0;
+        if (!p.xcd_affine && op->num_tables > 1 && tm_env > 0 && uneven) p.xcd_affine = 2;
     }
     return PM_OK;
 }
@@ -274,7 +291,7 @@ int pm_rows_dequantize(const void* src, int64_t n_rows, int32_t dim, int32_t bit
 
 int pm_embbag_fwd(const pm_embbag_batch* op, float* out, pm_stream_t stream) {
     pm::KParams p;
-    int rc = make_params(op, op ? op->weight_dtype : -1, p);
+    int rc = make_params(op, op ? op->weight_dtype : -1, p, true);
     if (rc != PM_OK) return rc;
     if (p.bag_count == 0) return PM_OK;
     if (!out) return fail(PM_ERR_INVALID, "out is NULL");
@@ -288,7 +305,7 @@ int pm_embbag_fwd(const pm_embbag_batch* op, float* out, pm_stream_t stream) {
 
 int pm_embbag_fwd_quantized(const pm_embbag_batch* op, void* out, int32_t bitwidth, pm_stream_t stream) {
     pm::KParams p;
-    int rc = make_params(op, op ? op->weight_dtype : -1, p);
+    int rc = make_params(op, op ? op->weight_dtype : -1, p, true);
     if (rc != PM_OK) return rc;
     if ((rc = rowquant_args_ok(0, op->max_dim, bitwidth)) != PM_OK) return rc;
     if (op->out_stride % op->max_dim != 0) return fail(PM_ERR_INVALID, "out_stride must be a whole number of max_dim-element rows");

@@ -48,10 +48,11 @@ struct KParams {
     int32_t bags_per_block;
     int32_t idx_cap;             // LDS index-tile capacity (entries)
     int32_t idx64;               // 1: int64 indices/offsets, 0: int32
-    int32_t xcd_affine;          // 1: table t is served by XCD t % 8 (requires T % 8 == 0)
+    int32_t xcd_affine;          // 1: table t is served by XCD t % 8 (requires T % 8 == 0); 2: tile-major block order (t = b % T)
     int32_t nt_loads;            // 1: non-temporal table-row loads
     int32_t ordered;             // forward: 1 = ragged request, lane groups take the longest bags of a tile first
     int32_t stage_out;           // forward: > 0 = collect the tile's pooled rows in LDS (this many floats per row), write at tile end
+    int32_t stage_bags;          // forward: rows the staging buffer holds (tiles with more bags write row by row)
     int32_t out_bits;            // forward: 0 = fp32 output; 16 / 8 / 4 / 2 = io holds row-wise quantised rows (rowquant.hip), staged only
     float alpha;                 // bwd scale
 };
@@ -72,7 +73,14 @@ __device__ __forceinline__ int64_t bag_start_or_end(const KParams& p, int64_t g)
 // instead of being replicated in all eight (placement is a speed matter only).
 __device__ __forceinline__ void block_to_tile(const KParams& p, int& t, int& tile) {
     const int bid = blockIdx.x;
-    if (p.xcd_affine) {
+    if (p.xcd_affine == 2) {
+        // tile-major: consecutive blocks serve the same tile index of consecutive tables, so every table advances at the same
+        // rate.  For requests whose tables have very different pooling factors (Criteo multi-hot 1 .. 100): in table-major
+        // order the heaviest table's workgroups -- each a chain of 25 round trips -- are dispatched together, late, and the
+        // launch ends in their tail; interleaved, they start throughout the launch.
+        t = bid % p.T;
+        tile = bid / p.T;
+    } else if (p.xcd_affine) {
         const int xcd = bid % kXcds;
         const int slot = bid / kXcds;
         t = xcd + kXcds * (slot / p.tiles_per_table);
@@ -89,11 +97,22 @@ __device__ __forceinline__ void block_to_tile(const KParams& p, int& t, int& til
 // weights into LDS with coalesced loads.  Returns true if indices were staged.
 // LDS layout: int64 s_off[bags_per_block + 1] | int32 s_idx[idx_cap] | float s_w[idx_cap]
 template <bool WEIGHTED>
+__device__ __forceinline__ bool stage_tile_at(const KParams& p, int t, int64_t bag0, int nb, char* smem,
+                                              int64_t*& s_off, int32_t*& s_idx, float*& s_w);
+
+template <bool WEIGHTED>
 __device__ __forceinline__ bool stage_tile(const KParams& p, int t, int tile, char* smem, int& nb,
                                            int64_t*& s_off, int32_t*& s_idx, float*& s_w) {
     const int64_t bag0 = p.bag_begin + static_cast<int64_t>(tile) * p.bags_per_block;
     const int64_t left = p.bag_begin + p.bag_count - bag0;
     nb = left < p.bags_per_block ? static_cast<int>(left) : p.bags_per_block;
+    return stage_tile_at<WEIGHTED>(p, t, bag0, nb, smem, s_off, s_idx, s_w);
+}
+
+// the same for a tile given by its first bag and bag count (work tiles)
+template <bool WEIGHTED>
+__device__ __forceinline__ bool stage_tile_at(const KParams& p, int t, int64_t bag0, int nb, char* smem,
+                                              int64_t*& s_off, int32_t*& s_idx, float*& s_w) {
     const int64_t g0 = static_cast<int64_t>(t) * p.B + bag0;
 
     s_off = reinterpret_cast<int64_t*>(smem);

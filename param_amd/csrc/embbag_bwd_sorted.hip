@@ -75,6 +75,7 @@ struct SortedParams {
     int32_t seg_tiles;       // > 0: the sorted array is T * H equal segments of this many tiles (fixed pooling)
     int32_t H;               // bag phases (1 or 2): segments are (table, phase), one apply launch per phase
     int32_t phase;           // phase this launch applies
+    int32_t tile;            // sorted positions per workgroup of the apply kernels (kSortTile, or smaller for small requests)
     int32_t xcd;             // 1: XCD-affine block -> tile mapping (needs seg_tiles); 2: XCD-contiguous (any request)
     const uint32_t* d_n;     // not NULL: the number of sorted pairs lives on the device (<= n), written by the segmented sort
 };
@@ -258,9 +259,19 @@ struct SortWs {
 
 // chunks of the apply kernels: kSortTile / (kBlock / G) positions each; sized for the smallest
 // chunk any destination dtype can select for this max_dim (16-bit destinations: 8 elements/lane)
+// sorted positions per workgroup of the apply kernels.  1024 for large requests (2048: main +53 us, fix-up -28 us, round 1);
+// small requests get smaller tiles: the chip holds 1280 apply workgroups at a time (5 per CU), and a request of 1713 tiles
+// (the Criteo step: 1.75 M lookups) is one full wave of workgroups plus a third of one -- its apply took as long as two
+// waves.  PARAM_AMD_BWD_TILE overrides (256 / 512 / 1024).
+inline int apply_tile(int64_t n) {
+    static const int env = [] { const char* e = getenv("PARAM_AMD_BWD_TILE"); return e ? atoi(e) : 0; }();
+    if (env == 256 || env == 512 || env == 1024) return env;
+    return n < (static_cast<int64_t>(3) << 20) ? 256 : n < (static_cast<int64_t>(6) << 20) ? 512 : kSortTile;
+}
+
 inline int64_t max_chunks(int64_t n, int max_dim) {
     const int g = group_lanes(max_dim, 8);
-    const int c = kSortTile / (kBlock / g);
+    const int c = apply_tile(n) / (kBlock / g);
     return (n + c - 1) / c + 1;
 }
 
@@ -492,11 +503,11 @@ hipError_t sort_impl(const KParams& p, const SortPlan& g, SortWs& ws, hipStream_
                             g.segmented ? static_cast<size_t>(g.seg_len) : 0);
 }
 
-template <typename DST, typename K, int G>
-hipError_t launch_apply_w(SortedParams sp, hipStream_t stream) {
+template <typename DST, typename K, int G, int TILE>
+hipError_t launch_apply_t(SortedParams sp, hipStream_t stream) {
     constexpr int NG = kBlock / G;
-    constexpr int C = kSortTile / NG;
-    int64_t grid = (sp.n + kSortTile - 1) / kSortTile;
+    constexpr int C = TILE / NG;
+    int64_t grid = (sp.n + TILE - 1) / TILE;
     if (sp.xcd == 2)
         grid = static_cast<int64_t>(kXcds) * ((grid + kXcds - 1) / kXcds);
     else if (sp.seg_tiles > 0)
@@ -504,11 +515,11 @@ hipError_t launch_apply_w(SortedParams sp, hipStream_t stream) {
     const int64_t n_chunks = (sp.n + C - 1) / C;       // every chunk below this index wrote its record
     const int64_t fgrid = (n_chunks + NG - 1) / NG;
     const dim3 g1(static_cast<unsigned>(grid)), g2(static_cast<unsigned>(fgrid)), blk(kBlock);
-#define PM_LAUNCH_SORTED(W_, OPT_)                                                                             \
-    do {                                                                                                       \
-        hipLaunchKernelGGL((bwd_sorted_main_kernel<DST, K, G, W_, OPT_>), g1, blk,                             \
-                           static_cast<size_t>(sp.T) * ((OPT_) == 1 ? 28 : 20), stream, sp);                  \
-        hipLaunchKernelGGL((bwd_sorted_fixup_kernel<DST, K, G, W_, OPT_>), g2, blk, 0, stream, sp, n_chunks); \
+#define PM_LAUNCH_SORTED(W_, OPT_)                                                                                   \
+    do {                                                                                                             \
+        hipLaunchKernelGGL((bwd_sorted_main_kernel<DST, K, G, W_, OPT_, TILE>), g1, blk,                             \
+                           static_cast<size_t>(sp.T) * ((OPT_) == 1 ? 28 : 20), stream, sp);                        \
+        hipLaunchKernelGGL((bwd_sorted_fixup_kernel<DST, K, G, W_, OPT_, TILE>), g2, blk, 0, stream, sp, n_chunks); \
     } while (0)
     // one (main, fix-up) pair per bag phase, in stream order: phase 0 has updated a row before phase 1 touches it
     for (int ph = 0; ph < sp.H; ++ph) {
@@ -522,6 +533,15 @@ hipError_t launch_apply_w(SortedParams sp, hipStream_t stream) {
     }
 #undef PM_LAUNCH_SORTED
     return hipGetLastError();
+}
+
+template <typename DST, typename K, int G>
+hipError_t launch_apply_w(const SortedParams& sp, hipStream_t stream) {
+    switch (sp.tile) {
+        case 256: return launch_apply_t<DST, K, G, 256>(sp, stream);
+        case 512: return launch_apply_t<DST, K, G, 512>(sp, stream);
+        default: return launch_apply_t<DST, K, G, kSortTile>(sp, stream);
+    }
 }
 
 template <typename DST, typename K>
@@ -697,6 +717,7 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
     sp.phase = 0;
     sp.xcd = g.xcd ? (g.v2 ? 2 : 1) : 0;
     sp.d_n = g.v2 ? seg_sort_count(ws.temp, static_cast<size_t>(p.N), p.T) : nullptr;
+    sp.tile = g.v2 ? apply_tile(p.N) : kSortTile;      // round 2's plans (segments per table, phases) are laid out for 1024
     if (sp.n == 0) return hipSuccess;
     return g.key_bytes == 4 ? launch_apply_k<uint32_t>(sp, dst_dtype, max_dim, stream)
                             : launch_apply_k<uint64_t>(sp, dst_dtype, max_dim, stream);

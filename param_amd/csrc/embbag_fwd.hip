@@ -135,13 +135,15 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
     int t, tile;
     block_to_tile(p, t, tile);
     if (t >= p.T) return;
+    const int64_t bag0 = p.bag_begin + static_cast<int64_t>(tile) * p.bags_per_block;
+    const int64_t left_bags = p.bag_begin + p.bag_count - bag0;
+    const int nb = left_bags < p.bags_per_block ? static_cast<int>(left_bags) : p.bags_per_block;
     if (threadIdx.x == 0) s_next = NG;  // bags 0 .. NG-1 are taken statically; visible after stage_tile's barrier
 
-    int nb;
     int64_t* s_off;
     int32_t* s_idx;
     float* s_w;
-    const bool staged = stage_tile<WEIGHTED>(p, t, tile, smem, nb, s_off, s_idx, s_w);
+    const bool staged = stage_tile_at<WEIGHTED>(p, t, bag0, nb, smem, s_off, s_idx, s_w);
     const int64_t base = s_off[0];
     // ORDERED (ragged requests; the host picks it when the lookups do not divide evenly over the bags): longest bag first.
     // The lane groups take the tile's bags in descending order of length, so a long bag is never the last thing a
@@ -186,13 +188,13 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
     constexpr int ES = 16 / VEC;  // bytes per table element
     const int64_t row_bytes = static_cast<int64_t>(D) * ES;
     const char* W = reinterpret_cast<const char*>(p.tables[t]);
-    const int64_t bag0 = p.bag_begin + static_cast<int64_t>(tile) * p.bags_per_block;
     float* out_t = p.io + p.out_offsets[t];
     const bool nt = p.nt_loads != 0;
     // STAGE: the tile's pooled rows are collected in LDS and leave together when the tile is done -- one burst of
     // bags_per_block rows (16 KB, contiguous in the [T, B, D] layout) instead of one 512-byte row whenever a lane group
     // finishes a bag.  LDS: after the index tile, bags_per_block * D floats.
     float* s_out = reinterpret_cast<float*>(smem + tile_lds_bytes(p.bags_per_block, p.idx_cap, WEIGHTED));
+    const bool stage = STAGE && nb <= p.stage_bags;   // (always, with bag-count tiles)
 
     for (int slot = gid; slot < nb;) {
         const int bg = ORDERED ? s_ord[slot] : slot;
@@ -252,7 +254,7 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
                 }
             }
 
-            if (STAGE) {
+            if (STAGE && stage) {
                 f32x4* o4 = reinterpret_cast<f32x4*>(s_out + static_cast<size_t>(bg) * D + c);
 #pragma unroll
                 for (int k = 0; k < VEC; k += 4) o4[k / 4] = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
@@ -272,7 +274,7 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
         if (lig == 0) nxt = atomicAdd(&s_next, 1);
         slot = __shfl(nxt, 0, G);
     }
-    if (STAGE) {
+    if (STAGE && stage) {
         __syncthreads();
         if (p.out_bits == 0) {
             const int q = D / 4;                       // 16-byte pieces per row

@@ -339,35 +339,76 @@ __global__ void __launch_bounds__(kT) seg_hist_kernel(const TileDesc* tiles, con
 
 // per segment: exclusive prefix of the tile counts per digit (in place), absolute start and size of every (segment, digit)
 // bucket; classify != 0 (level 1 of modes 1 / 2): buckets too large for the local sort go to the second-level list.
-__global__ void __launch_bounds__(kRadix) seg_scan_kernel(SegHeader* hdr, const SegDesc* desc, const uint32_t* n_seg_dev, uint32_t n_seg_host,
-                                                          uint32_t* bh, uint32_t* bstart, uint32_t* bcnt, int classify, int mode,
-                                                          uint32_t* l2_list) {
+// 1024 threads = 4 row chunks x 256 digits, 16 independent loads per round trip: a segment of 200 tiles (the 100-hot Criteo
+// table) is 4 round trips per phase instead of the 25 a 256-thread walk needs -- that walk was the long pole of every pass of
+// the Criteo sort (one workgroup per segment, and one segment holds half the lookups).
+constexpr int kScanChunks = 4;
+constexpr int kScanU = 16;
+__global__ void __launch_bounds__(kRadix * kScanChunks) seg_scan_kernel(SegHeader* hdr, const SegDesc* desc, const uint32_t* n_seg_dev,
+                                                                        uint32_t n_seg_host, uint32_t* bh, uint32_t* bstart, uint32_t* bcnt,
+                                                                        int classify, int mode, uint32_t* l2_list) {
+    __shared__ uint32_t s_sum[kScanChunks][kRadix];
     __shared__ uint32_t s_tmp[kWaves];
-    const int d = threadIdx.x;
+    const int d = threadIdx.x % kRadix;
+    const int c = threadIdx.x / kRadix;
     const uint32_t n_seg = n_seg_dev ? *n_seg_dev : n_seg_host;
     for (uint32_t t = blockIdx.x; t < n_seg; t += gridDim.x) {
         const SegDesc sd = desc[t];
         const uint64_t r0 = sd.tile_base;
-        uint32_t run = 0;
-        for (uint32_t r = 0; r < sd.ntiles; r += 8) {
-            uint32_t v[8];
+        const uint32_t per = (sd.ntiles + kScanChunks - 1) / kScanChunks;
+        const uint32_t ra = c * per < sd.ntiles ? c * per : sd.ntiles;
+        const uint32_t rb = ra + per < sd.ntiles ? ra + per : sd.ntiles;
+        uint32_t sum = 0;
+        for (uint32_t r = ra; r < rb; r += kScanU) {
+            uint32_t v[kScanU];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = (r + u < sd.ntiles) ? bh[(r0 + r + u) * kRadix + d] : 0u;
+            for (int u = 0; u < kScanU; ++u) v[u] = (r + u < rb) ? bh[(r0 + r + u) * kRadix + d] : 0u;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (r + u < sd.ntiles) bh[(r0 + r + u) * kRadix + d] = run;
+            for (int u = 0; u < kScanU; ++u) sum += v[u];
+        }
+        s_sum[c][d] = sum;
+        __syncthreads();
+        uint32_t run = 0, total = 0;
+#pragma unroll
+        for (int cc = 0; cc < kScanChunks; ++cc) {
+            const uint32_t x = s_sum[cc][d];
+            if (cc < c) run += x;
+            total += x;
+        }
+        for (uint32_t r = ra; r < rb; r += kScanU) {     // in-place rewrite: the loads of a batch are issued before its stores
+            uint32_t v[kScanU];
+#pragma unroll
+            for (int u = 0; u < kScanU; ++u) v[u] = (r + u < rb) ? bh[(r0 + r + u) * kRadix + d] : 0u;
+#pragma unroll
+            for (int u = 0; u < kScanU; ++u) {
+                if (r + u < rb) bh[(r0 + r + u) * kRadix + d] = run;
                 run += v[u];
             }
         }
-        const uint32_t start = sd.out_start + block_excl_scan256(run, s_tmp);
-        const uint32_t b = t * kRadix + d;
-        bstart[b] = start;
-        bcnt[b] = run;
-        if (classify && run > kLocalCap) {
-            int lo, hi;
-            local_bits(mode, static_cast<int>(sd.rbits), lo, hi);
-            if (hi > lo) l2_list[atomicAdd(&hdr->n_l2, 1u)] = b;
+        // exclusive scan of the digit totals over the 256 digits (the threads of chunk 0; everybody keeps the barriers)
+        uint32_t incl = (c == 0) ? total : 0u;
+        const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, kWave);
+            if (lane >= off) incl += up;
         }
+        if (c == 0 && lane == kWave - 1) s_tmp[wave] = incl;
+        __syncthreads();
+        if (c == 0) {
+            uint32_t base = 0;
+            for (int w = 0; w < wave; ++w) base += s_tmp[w];
+            const uint32_t start = sd.out_start + base + incl - total;
+            const uint32_t b = t * kRadix + d;
+            bstart[b] = start;
+            bcnt[b] = total;
+            if (classify && total > kLocalCap) {
+                int lo, hi;
+                local_bits(mode, static_cast<int>(sd.rbits), lo, hi);
+                if (hi > lo) l2_list[atomicAdd(&hdr->n_l2, 1u)] = b;
+            }
+        }
+        __syncthreads();     // s_sum / s_tmp are rewritten by the next segment of a looping workgroup
     }
 }
 
@@ -832,7 +873,7 @@ hipError_t seg_sort_pairs(const SegSortRequest& rq, int mode, K* keys_a, K* keys
         K* kout = (p % 2 == 0) ? keys_b : keys_a;
         uint32_t* vout = (p % 2 == 0) ? vals_b : vals_a;
         hipLaunchKernelGGL((seg_hist_kernel<K>), dim3(tm), dim3(kT), 0, stream, s.tiles, &s.hdr->n_tiles, src, mode, p, s.bh);
-        hipLaunchKernelGGL(seg_scan_kernel, dim3(rq.T), dim3(kRadix), 0, stream, s.hdr, s.desc, static_cast<const uint32_t*>(nullptr),
+        hipLaunchKernelGGL(seg_scan_kernel, dim3(rq.T), dim3(kRadix * kScanChunks), 0, stream, s.hdr, s.desc, static_cast<const uint32_t*>(nullptr),
                            static_cast<uint32_t>(rq.T), s.bh, s.bstart, s.bcnt, (mode != 0 && p == 0) ? 1 : 0, mode, s.l2_list);
         hipLaunchKernelGGL((seg_scatter_kernel<K>), dim3(tm), dim3(kT), 0, stream, s.tiles, &s.hdr->n_tiles, src, mode, p, s.bh, s.bstart, kout,
                            vout);
@@ -853,7 +894,7 @@ hipError_t seg_sort_pairs(const SegSortRequest& rq, int mode, K* keys_a, K* keys
             K* kout = (q % 2 == 0) ? keys_a : keys_b;
             uint32_t* vout = (q % 2 == 0) ? vals_a : vals_b;
             hipLaunchKernelGGL((seg_hist_kernel<K>), dim3(kL2Grid), dim3(kT), 0, stream, s.tiles2, &s.hdr->n_tiles2, src, 0, q, s.bh2);
-            hipLaunchKernelGGL(seg_scan_kernel, dim3(kL2Grid / 2), dim3(kRadix), 0, stream, s.hdr, s.desc2, &s.hdr->n_l2, 0u, s.bh2, s.bstart2,
+            hipLaunchKernelGGL(seg_scan_kernel, dim3(kL2Grid / 2), dim3(kRadix * kScanChunks), 0, stream, s.hdr, s.desc2, &s.hdr->n_l2, 0u, s.bh2, s.bstart2,
                                s.bcnt2, 0, 0, static_cast<uint32_t*>(nullptr));
             hipLaunchKernelGGL((seg_scatter_loop_kernel<K>), dim3(kL2Grid), dim3(kT), 0, stream, s.tiles2, &s.hdr->n_tiles2, src, 0, q, s.bh2,
                                s.bstart2, kout, vout);

@@ -429,18 +429,28 @@ def comms_sweep_plugin_fixture(rank, world, port, outdir, argv_json):
         f.write(buf.getvalue())
 
 
-def sharded_exchange(rank, world, port):
-    """ShardedEmbeddingExchange on an UNEVEN table split (3 tables of mixed dims over 2 ranks -> [2, 1]): forward
-    receive blocks, the gradient's way back (splits swapped) and the pipelined step's bookkeeping (3 batches in flight),
-    against a single-process restatement.  Lookup / backward are torch stand-ins (the HIP kernels need a GPU)."""
+def sharded_exchange(rank, world, port, n_tables=3):
+    """ShardedEmbeddingExchange on an UNEVEN table split (3 tables of mixed dims over 2 ranks -> [2, 1]; 26 mixed tables over
+    4 / 8 ranks -> the reference's [7, 7, 6, 6] / [4, 4, 3, 3, 3, 3, 3, 3], dlrm.py:390-398): forward receive blocks, the
+    exchange self-check, the gradient's way back (splits swapped) and the pipelined step's bookkeeping (3 batches in
+    flight), against a single-process restatement.  Lookup / backward are torch stand-ins (the HIP kernels need a GPU)."""
     from param_amd.comms.pt.pipeline import ShardedEmbeddingExchange, table_split
 
     _env(rank, world, port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         assert table_split(26, 8) == [4, 4, 3, 3, 3, 3, 3, 3] and table_split(64, 8) == [8] * 8 and table_split(3, 2) == [2, 1]
-        rows, dims, pools, B_local = [40, 50, 60], [8, 4, 12], [3, 1, 5], 3
+        assert table_split(26, 4) == [7, 7, 6, 6]
+        if n_tables == 3:
+            rows, dims, pools, B_local = [40, 50, 60], [8, 4, 12], [3, 1, 5], 3
+        else:   # Criteo-like: mixed dims and pooling factors (incl. tiny tables), a small per-rank batch
+            rows = [[40, 7, 3, 90, 11][t % 5] + t for t in range(n_tables)]
+            dims = [[8, 4, 12, 4][t % 4] for t in range(n_tables)]
+            pools = [[3, 1, 5, 2, 1, 7][t % 6] for t in range(n_tables)]
+            B_local = 2
         split = table_split(len(rows), world)
+        if n_tables == 26 and world == 8:
+            assert split == [4, 4, 3, 3, 3, 3, 3, 3]
         first = [sum(split[:r]) for r in range(world)]
         mine = list(range(first[rank], first[rank] + split[rank]))
         widths = [sum(dims[first[r]:first[r] + split[r]]) for r in range(world)]
@@ -499,6 +509,17 @@ def sharded_exchange(rank, world, port):
                 for src in range(world):
                     exp = pooled_of(src, 0)[rank * B_local:(rank + 1) * B_local]
                     assert torch.allclose(ex.recv_block(0, src), exp, atol=1e-6), src
+                # the self-check bench.py runs after its timed region: every peer's first table recomputed locally
+                d0 = lambda src: dims[first[src]]   # noqa: E731
+                chk = ex.selfcheck(0, lambda src: pooled_of(src, 0)[rank * B_local:(rank + 1) * B_local, :d0(src)], exact=False)
+                assert chk["a2a_selfcheck"] == "ok" and chk["peers_checked"] == world and chk["ranks"] == world, chk
+                # a payload that is NOT what the peer sent is reported by every rank (rank 1 plants the fault)
+                if rank == 1:
+                    ex.recv[0][0] += 1.0
+                bad = ex.selfcheck(0, lambda src: pooled_of(src, 0)[rank * B_local:(rank + 1) * B_local, :d0(src)], exact=False)
+                assert bad["a2a_selfcheck"] == "MISMATCH" and bad["this_rank_ok"] == (rank != 1), bad
+                if rank == 1:
+                    ex.recv[0][0] -= 1.0
         ex.drain()
         assert applied == [int(request(rank, k)[0].sum()) for k in range(steps)]      # every batch once, in order
         # expected accumulators: grad(owner=me)[b_glob rows of rank j] = (j + 2) * pooled_me[those rows]

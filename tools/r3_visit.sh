@@ -53,6 +53,33 @@ PY
       f=$(find "$d" -name "*kernel_stats.csv" | head -1)
       if [ -n "$f" ]; then cp "$f" "$out/prof_${runs}_${reqs}_kernel_stats.csv"; echo "== $runs $reqs"; head -22 "$f" | cut -c1-220; else echo "no stats for $runs $reqs"; tail -5 "$d.err"; ls -R "$d" | head; fi
       ;;
+    profbench:*)
+      # profbench:<name>:<bench args with , for spaces>   rocprofv3 kernel stats of a bench.py command
+      IFS=: read -r _ name bargs <<< "$what"
+      d=/tmp/r3profbench_$name; rm -rf "$d"
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$d" -o p -- python "$GRAFT_REPO_ROOT/bench.py" ${bargs//,/ } > "$GRAFT_REPO_ROOT/$out/profbench_${name}.json" 2> "$d.err")
+      f=$(find "$d" -name "*kernel_stats.csv" | head -1)
+      if [ -n "$f" ]; then cp "$f" "$out/profbench_${name}_kernel_stats.csv"; python - "$f" <<'PY'
+import csv,sys,re
+for r in csv.DictReader(open(sys.argv[1])):
+    n=r["Name"]
+    if "pm::" in n and "fill_random" not in n:
+        short=re.sub(r"\(.*","",n.replace("void pm::(anonymous namespace)::","").replace("pm::(anonymous namespace)::",""))
+        print(f'{short[:72]:72s} calls {r["Calls"]:>5s} avg {float(r["AverageNs"])/1e3:9.1f} us  min {float(r["MinNs"])/1e3:8.1f} max {float(r["MaxNs"])/1e3:8.1f}')
+PY
+      else echo "no stats"; tail -5 "$d.err"; fi ;;
+    criteo:*)
+      # criteo:<ENV=val>;<ENV=val>...   forward (+ backward with :bwd suffix on the step name) of the Criteo workload under an environment setting
+      IFS=: read -r _ cfgs <<< "$what"
+      for c in ${cfgs//;/ }; do
+        env $c timeout 300 python bench.py --workload criteo --no-cpu-baseline --steps 30 > "$out/criteo_${c}.json" 2> "$out/criteo.err"
+        python - "$out/criteo_${c}.json" "$c" <<'PY'
+import json,sys
+r=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+b=r.get("bwd_scatter_add",{}); u=b.get("uniform",{})
+print(f"criteo {sys.argv[2]:32s}: fwd zipf {r['value']/1e9:.2f} G/s ({r['roofline']['zipf']['avg_launch_s']*1e6:.1f} us) uniform frac {r['roofline']['frac']:.3f} ({r['roofline']['avg_launch_s']*1e6:.1f} us) | bwd zipf {b.get('avg_s_sort_plus_apply',0)*1e6:.0f} us (sort {b.get('avg_s_sort',0)*1e6:.0f}) uniform {u.get('avg_s_sort_plus_apply',0)*1e6:.0f} us frac {u.get('frac',0):.3f} (sort {u.get('avg_s_sort',0)*1e6:.0f})")
+PY
+      done ;;
     pmc)
       # separate rocprofv3 --pmc passes (no other trace domain), one counter group each; only the CSVs come home
       mkdir -p "$out/pmc"
