@@ -53,6 +53,19 @@ PY
       f=$(find "$d" -name "*kernel_stats.csv" | head -1)
       if [ -n "$f" ]; then cp "$f" "$out/prof_${runs}_${reqs}_kernel_stats.csv"; echo "== $runs $reqs"; head -22 "$f" | cut -c1-220; else echo "no stats for $runs $reqs"; tail -5 "$d.err"; ls -R "$d" | head; fi
       ;;
+    distdebug:*)
+      # distdebug:<name>:<bench args with , for spaces>   the N>1 code path on a 1-rank RCCL group
+      IFS=: read -r _ name bargs <<< "$what"
+      timeout 900 python bench.py --dist-debug --no-cpu-baseline ${bargs//,/ } > "$out/distdebug_${name}.json" 2> "$out/distdebug_${name}.err"
+      python - "$out/distdebug_${name}.json" <<'PY'
+import json,sys
+r=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("workload:", r["config"]["workload"][:160])
+print("value", r["value"], "tables", r["config"]["tables_total"], "a2a", {k: r["all_to_all"].get(k) for k in ("avg_s","algbw_GBps","busbw_GBps","rccl_ranks","backend","busbw_over_xgmi_bound")})
+print("selfcheck", r["all_to_all"].get("selfcheck"))
+print("overlap", r["overlap"]); print("fwd_bwd", {k: r.get("fwd_bwd_step",{}).get(k) for k in ("avg_s_pipelined","avg_s_serial","overlap_eff")})
+PY
+      tail -2 "$out/distdebug_${name}.err" ;;
     profbench:*)
       # profbench:<name>:<bench args with , for spaces>   rocprofv3 kernel stats of a bench.py command
       IFS=: read -r _ name bargs <<< "$what"
