@@ -216,6 +216,9 @@ int oracle_embbag_bwd_bf16(uint16_t* dst, float* scratch, int64_t rows, int32_t 
  * optimizer of fbgemm_gpu's split-table-batched-embeddings code generator (fbgemm_gpu/codegen/genscript/optimizers.py
  * `rowwise_adagrad()`; the kernel it generates is `split_rowwise_adagrad_table_update_kernel`), as of the fbgemm_gpu
  * v0.5 - v1.0 line, written down from its documented formulas, NOT from a source or binary that could be run here.
+ * tests/golden/gen_adagrad_fbgemm.py produces the pinning fixture (fbgemm's own updated weights and state for seeded
+ * requests, weight decay none / L2 / decoupled) the moment fbgemm_gpu is importable next to a GPU; tests/test_oracle.py::
+ * test_oracle_rowwise_adagrad_pinned_to_fbgemm_fixture consumes it and skips until then.
  * PARITY UNPINNED for this routine (no reference output could be generated); the judge-visible consequence is stated in
  * DESIGN.md (sections 0 and 8).  What is pinned: the GPU kernel against THIS restatement (2e-5), this restatement
  * against an fp64 numpy form of the same formulas (tests/test_gpu_parity.py::test_fused_rowwise_adagrad_vs_oracle), and -- the

@@ -60,6 +60,12 @@ def backend_collectives(rank, world, port):
     _env(rank, world, port)
     bf = _backend(rank, world, port)
     try:
+        # get_next_group() walks the process groups round-robin (reference pytorch_dist_backend.py:1200,1251): one group
+        # after initialize_backend, both after initialize_groups
+        assert bf.get_next_group() is bf.get_default_group() and bf.get_next_group() is bf.get_default_group()
+        bf.initialize_groups({0: list(range(world)), 1: list(range(world))}, backend="gloo", force_new_group=True)
+        seen = [bf.get_next_group() for _ in range(4)]
+        assert seen[0] is not seen[1] and seen[0] is seen[2] and seen[1] is seen[3] and bf.get_num_pgs() == 2
         ca = collectiveArgsHolder()
         ca.world_size, ca.global_rank, ca.group, ca.device = world, rank, bf.get_default_group(), bf.get_device()
         assert bf.get_world_size() == world and bf.get_global_rank() == rank and bf.get_device().type == "cpu"
@@ -585,6 +591,13 @@ def quantized_collectives(rank, world, port, outdir):
             assert np.array_equal(ca.opTensor.numpy(), want), bits
             assert torch.equal(ca.ipTensor, before) and not ca.waitObj
             assert ca.quant_time.getTimeUS() > 0 and ca.dequant_time.getTimeUS() > 0
+            # a NON-CONTIGUOUS output tensor (every other element of a wider buffer) receives the restored values too
+            wide = torch.full((2 * sum(ca.opTensor_split),), -1.0)
+            ca.opTensor = wide[::2]
+            assert not ca.opTensor.is_contiguous()
+            bf.all_to_allv(ca)
+            assert np.array_equal(wide[::2].numpy(), want) and bool((wide[1::2] == -1.0).all()), bits
+            ca.opTensor = torch.full((sum(ca.opTensor_split),), -1.0)
             # list form (equal chunks), same formats
             ca.ipTensor = [chunk(rank, 0)[:1].reshape(-1) + d for d in range(world)]
             ca.opTensor = [torch.zeros(dim) for _ in range(world)]

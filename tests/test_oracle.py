@@ -193,3 +193,28 @@ def test_oracle_rowwise_adagrad_pinned_to_torch_adagrad_where_rowwise_is_element
     assert np.allclose(mom, s_t, rtol=1e-6, atol=0) and np.allclose(W, w_t[:, None], rtol=2e-6, atol=1e-7)
     assert np.array_equal(W[-5:], np.repeat(w_col[-5:, None], D, axis=1)) and not mom[-5:].any()
     assert all(np.array_equal(W[:, 0], W[:, d]) for d in range(1, D))
+
+
+def test_oracle_rowwise_adagrad_pinned_to_fbgemm_fixture(coracle, golden_dir):
+    """fbgemm_gpu's OWN EXACT_ROWWISE_ADAGRAD outputs (tests/golden/gen_adagrad_fbgemm.py writes the fixture wherever
+    fbgemm_gpu is importable -- it is not in the build image, so this test normally skips and the oracle's header says
+    PARITY UNPINNED): two steps, weight decay none / L2 / decoupled, duplicates inside and across bags."""
+    import os
+
+    path = os.path.join(golden_dir, "adagrad_fbgemm.npz")
+    if not os.path.exists(path):
+        pytest.skip("no fbgemm_gpu fixture: fbgemm_gpu was not importable where the goldens were generated (parity unpinned)")
+    z = np.load(path)
+    for tag, mode in (("none", 0), ("l2", 1), ("decouple", 2)):
+        rows = [int(r) for r in z[f"{tag}.rows"]]
+        D, B, L, lr, eps, wd = z[f"{tag}.hp"]
+        D, B, L = int(D), int(B), int(L)
+        idx, off, grads = z[f"{tag}.idx"], z[f"{tag}.off"], z[f"{tag}.grads"]
+        for t, r in enumerate(rows):
+            W, mom = z[f"{tag}.W0.{t}"].copy(), np.zeros(r, np.float32)
+            s, e = off[t * B], off[(t + 1) * B]
+            for g in grads:
+                coracle.bwd_rowwise_adagrad(W, mom, idx[s:e], off[t * B:(t + 1) * B] - s, np.ascontiguousarray(g[:, t * D:(t + 1) * D]),
+                                            None, lr=float(lr), eps=float(eps), weight_decay=float(wd), weight_decay_mode=mode)
+            assert np.allclose(W, z[f"{tag}.W.{t}"], rtol=2e-5, atol=1e-6), (tag, t)
+            assert np.allclose(mom, z[f"{tag}.mom.{t}"], rtol=2e-5, atol=1e-7), (tag, t)

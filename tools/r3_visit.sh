@@ -53,6 +53,40 @@ PY
       f=$(find "$d" -name "*kernel_stats.csv" | head -1)
       if [ -n "$f" ]; then cp "$f" "$out/prof_${runs}_${reqs}_kernel_stats.csv"; echo "== $runs $reqs"; head -22 "$f" | cut -c1-220; else echo "no stats for $runs $reqs"; tail -5 "$d.err"; ls -R "$d" | head; fi
       ;;
+    official)
+      # the round's record: GPU tests, smoke, the default bench line twice in a row, bf16 / Criteo lines, the N>1 path on a 1-rank
+      # RCCL group (26 tables, Criteo), rocprofv3 kernel stats of the headline launches and of the whole default command
+      timeout 1500 python -m pytest tests -q -m gpu > "$out/pytest.log" 2>&1; tail -3 "$out/pytest.log"
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.log" 2>&1; tail -1 "$out/smoke.log"
+      timeout 900 python bench.py > "$out/bench_line.json" 2> "$out/bench_line.err"
+      timeout 900 python bench.py > "$out/bench_line_run2.json" 2> "$out/bench_line_run2.err"
+      timeout 900 python bench.py --dtype bf16 --no-cpu-baseline > "$out/bench_line_bf16_T64.json" 2> "$out/bench_bf16.err"
+      timeout 900 python bench.py --workload criteo --no-cpu-baseline > "$out/bench_line_criteo.json" 2> "$out/bench_criteo.err"
+      timeout 900 python bench.py --dist-debug --tables 26 --no-cpu-baseline --steps 20 > "$out/distdebug_26tables.json" 2> "$out/dd26.err"
+      timeout 900 python bench.py --dist-debug --workload criteo --no-cpu-baseline --steps 20 > "$out/distdebug_criteo.json" 2> "$out/ddc.err"
+      for v in zipf:--only-headline uniform:--only-headline,--alpha,0 full:--no-cpu-baseline; do
+        name=${v%%:*}; bargs=${v#*:}
+        d=/tmp/r3off_$name; rm -rf "$d"
+        (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$d" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --steps 20 --warmup 5 ${bargs//,/ } > "$GRAFT_REPO_ROOT/$out/${name}_under_rocprofv3.json" 2> "$d.err")
+        f=$(find "$d" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$out/${name}_kernel_stats.csv"
+      done
+      python - "$out" <<'PY'
+import json,sys,os
+o=sys.argv[1]
+def ld(n):
+    try: return json.loads(open(os.path.join(o,n)).read().strip().splitlines()[-1])
+    except Exception as e: return {"error":str(e)}
+for n in ("bench_line.json","bench_line_run2.json","bench_line_bf16_T64.json","bench_line_criteo.json"):
+    r=ld(n)
+    if "error" in r: print(n,r); continue
+    b=r.get("bwd_scatter_add",{}); u=b.get("uniform",{}); c=r.get("cpu_baseline") or {}
+    print(f"{n}: value {r['value']/1e9:.2f} G  roof {r['roofline']['frac']:.3f}  bwd zipf {b.get('avg_s_sort_plus_apply',0)*1e3:.3f} ms (sort {b.get('avg_s_sort',0)*1e3:.3f}) alg {b.get('alg_frac',0):.3f} | uniform {u.get('avg_s_sort_plus_apply',0)*1e3:.3f} ms frac {u.get('frac',0):.3f} apply {u.get('apply_only_frac',0):.3f} sort {u.get('avg_s_sort',0)*1e3:.3f} | fwd+bwd {r.get('fwd_bwd_step',{}).get('avg_s',0)*1e3:.3f} / {r.get('fwd_bwd_step',{}).get('uniform',{}).get('avg_s',0)*1e3:.3f} ms | cpu {c.get('value')} cores {c.get('cores')} unstable {c.get('unstable')}")
+for n in ("distdebug_26tables.json","distdebug_criteo.json"):
+    r=ld(n)
+    if "error" in r: print(n,r); continue
+    print(n, "tables", r["config"]["tables_total"], "value %.2f G" % (r["value"]/1e9), r["all_to_all"].get("selfcheck",{}).get("a2a_selfcheck"), "fwd_bwd", r.get("fwd_bwd_step",{}).get("avg_s_pipelined"))
+PY
+      ;;
     distdebug:*)
       # distdebug:<name>:<bench args with , for spaces>   the N>1 code path on a 1-rank RCCL group
       IFS=: read -r _ name bargs <<< "$what"
