@@ -30,8 +30,11 @@ apply alone) and the whole fwd + bwd step, under Zipf and under uniform indices,
 layout.  Order: the uniform block runs first (with 25 warm-up launches of its own), the timed headline steps (W warm-ups, K
 steps, as given) directly after it -- a block that runs first after the set-up phase rides a clock / power transient of
 3-4 %.  ``cpu_baseline`` times the reference's CPU engine (torch.nn.EmbeddingBag, pytorch_emb.py:37-45 protocol) in a child
-process on a bounded sample -- one table, the index sets of the request's first 8 tables in turn -- and the 1-core C oracle
-(rank 0, N == 1 only); ``value`` there is the reference's own mode (all threads, autograd on).
+process on a bounded sample -- one table, the index sets of the request's first 8 tables in turn, 7 x 64 steps per mode -- and
+the 1-core C oracle (rank 0, N == 1 only).  ``value`` there is the reference's own mode (all threads, autograd on) unless the
+container's cgroup CPU quota is smaller than that thread pool (16 CPUs on the round-3 GPU boxes, where torch sees 256 hardware
+threads): the reference's mode then measures the throttle and is reported beside a quota-sized pool of the same engine, which
+becomes ``value``; ``unstable`` flags a repeat spread of 25 % or more.
 
 N > 1 additionally reports the exchange alone (algBW / busBW with the reference's definitions), the lookup alone, the
 overlap efficiency max(lookup, exchange) / step, and a fwd + bwd training step with BOTH exchanges (pooled embeddings out,
@@ -211,21 +214,26 @@ def _cpu_modes(W: torch.Tensor, idx_sets, B: int, L: int, budget_s: float):
     n_default = torch.get_num_threads()          # torch's choice: one thread per visible physical core
     quota = _cgroup_cpu_quota()
     n_quota = n_default if quota is None else max(1, min(n_default, int(quota) - 2 if quota >= 4 else int(quota)))
-    modes = [("param_default_all_threads_grad_on", n_default, False)]       # what PARAM does out of the box
+    # order: the pools that fit the quota first, the reference's default pool LAST -- a throttled mode leaves the container in
+    # debt for the following periods, and whatever is timed right after it inherits the throttle (first repeats 1.6 ms
+    # instead of 0.2 ms per step in round 3's first try)
+    modes = []
     if n_quota < n_default:
         modes.append(("quota_sized_pool_grad_on", n_quota, False))          # the same engine, a pool the cgroup lets run
-    modes += [("eight_threads_grad_on", min(8, n_default), False), ("one_thread_no_grad", 1, True)]
+    modes += [("eight_threads_grad_on", min(8, n_default), False), ("one_thread_no_grad", 1, True),
+              ("param_default_all_threads_grad_on", n_default, False)]      # what PARAM does out of the box
     res = {}
     t_start = time.perf_counter()
     for tag, nthr, no_grad in modes:
-        if time.perf_counter() - t_start > budget_s and tag != modes[0][0]:
+        if time.perf_counter() - t_start > budget_s and tag != "param_default_all_threads_grad_on":
             res[tag] = {"skipped": "CPU budget spent"}
             continue
+        time.sleep(0.3)                          # three cgroup periods: start every mode with a fresh quota
         torch.set_num_threads(nthr)
         thr0 = _cgroup_throttled()
         ctx = torch.no_grad() if no_grad else torch.enable_grad()
         with ctx:
-            measure_cpu(0, 3, cycler, None, None)
+            measure_cpu(0, 16, cycler, None, None)       # wake the pool up (the reference's warm-up, a little longer)
             reps = []
             for _ in range(CPU_REPEATS):
                 el, _ = measure_cpu(0, CPU_STEPS, cycler, None, None)
@@ -242,10 +250,9 @@ def _cpu_modes(W: torch.Tensor, idx_sets, B: int, L: int, budget_s: float):
 def cpu_child(spec: dict) -> dict:
     """entry of the child process: rebuild table 0 of the parent's workload on the GPU (counter-based fill: same seed ->
     same bits), copy it to the host with the index sets of the first tables of the request, drop the device objects, time
-    the CPU modes.  The process keeps the CPU mask it was given: every attempt to confine or pin the OpenMP pool on this
-    host type (OMP_PLACES / OMP_PROC_BIND, a socket mask, a mask of threads + 2 CPUs) ran into the same cliff -- a pool as
-    wide as its mask collapses to ~6 M lookups/s, presumably against the runtime's own helper threads -- while the
-    unconfined default (one thread per core on 256 hardware threads) is both the fastest and the steadiest."""
+    the CPU modes (_cpu_modes).  The process keeps the CPU mask it was given.  (Rounds 1 and 2 tried to confine or pin the
+    OpenMP pool -- OMP_PLACES / OMP_PROC_BIND, socket masks -- and saw a pool as wide as its mask collapse to ~6 M lookups/s:
+    that was the container's cgroup CPU quota, not the mask; see _cpu_modes.)"""
     dev = torch.device("cuda", spec["device"])
     torch.cuda.set_device(dev)
     m = param_amd.BatchedEmbeddingBagMI355([spec["rows"]], spec["dim"], dtype=_DT[spec["dtype"]], device=dev, init="normal",
@@ -310,7 +317,7 @@ def cpu_baseline(spec: dict, budget_s: float = 20.0):
         "sample": (f"torch.nn.EmbeddingBag(sum) on host (the engine the reference calls, its measure_cpu protocol, autograd on as "
                    f"the reference runs it), 1 table {spec['rows']}x{spec['dim']} fp32, batch {spec['batch']}, pool {spec['pooling']}, the "
                    f"index sets of the request's first 8 tables in turn (672 MB of rows per cycle: no cache residency across steps); "
-                   f"mode = {best_name}: {best['threads']} threads, median of {best['repeats']} x {best['steps']} steps after 3 warm-ups"
+                   f"mode = {best_name}: {best['threads']} threads, median of {best['repeats']} x {best['steps']} steps after 16 warm-ups"
                    + (f"; the container's cgroup CPU quota is {quota:g} CPUs, so the reference's default pool of "
                       f"{result.get('torch_default_threads')} threads is throttled ({modes[ref_name]['lookups_per_s'] / 1e9:.3f} G lookups/s, "
                       f"{modes[ref_name]['cgroup_throttled_periods']} throttled periods) and is reported in child.modes only"
