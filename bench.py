@@ -623,11 +623,11 @@ def main():
         # every rank recomputes, from the peers' seeds, table 0 of every peer for its own slice of the batch and compares it
         # with the block that peer sent.  Tables and requests are rank-seeded (1000 + r / 1 + 17 r), fills are counter-based.
         if rq is None:
-            try:
-                flush()
-                ex._lookup(0, idx, off)
-                ex.fwd_a2a(0).wait()
-                torch.cuda.synchronize()
+            flush()
+            ex._lookup(0, idx, off)                 # the same collective every rank has just run K + W times
+            ex.fwd_a2a(0).wait()
+            torch.cuda.synchronize()
+            try:                                    # rank-local work only inside the try: a failure here must not strand the peers
                 scratch = {}
 
                 def peer_block(src):
@@ -644,10 +644,11 @@ def main():
                     with torch.no_grad():
                         return emb(pi[lo:hi].contiguous(), (po[rank * B_local:(rank + 1) * B_local] - lo).contiguous())
 
-                result["all_to_all"]["selfcheck"] = ex.selfcheck(0, peer_block, exact=True)
+                local_check = ex.selfcheck(0, peer_block, exact=True, local_only=True)
                 scratch.clear()
-            except Exception as exc:   # a check that cannot run must not cost the bench line
-                result["all_to_all"]["selfcheck"] = {"a2a_selfcheck": f"not run: {exc}"}
+            except Exception as exc:
+                local_check = {"error": str(exc)}
+            result["all_to_all"]["selfcheck"] = ex.combine_selfcheck(local_check)      # one MIN all-reduce, on every rank
         else:
             result["all_to_all"]["selfcheck"] = {"a2a_selfcheck": "skipped: quantised payload (lossy by definition of --a2a-bitwidth)"}
 
@@ -658,9 +659,15 @@ def main():
         # the same pipelined step with the compute stream confined to 224 CUs (32 left to RCCL's copy kernels): the forward
         # loses nothing down to 192 CUs on its own, so whether RCCL wants CUs of its own shows here, on a real mesh
         if a.lookup_cus == 0 and not a.no_cu_sweep:
-            try:
-                flush()
+            ms224 = None
+            try:                                    # rank-local: creating the masked stream
                 ms224 = masked_stream(224, dev)
+            except Exception:
+                ms224 = None
+            can = torch.tensor([1 if ms224 is not None else 0], dtype=torch.int64, device=dev)
+            dist.all_reduce(can, op=dist.ReduceOp.MIN)          # every rank or none: the timed steps below are collectives
+            if int(can[0]):
+                flush()
                 ms224.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(ms224):
                     _, s224 = time_steps(step, n_sub, 2, barrier)
@@ -669,8 +676,8 @@ def main():
                 s224, = rank_max(s224)
                 result["overlap"]["step_s_lookup_cus_224"] = s224
                 result["overlap"]["lookups_per_s_lookup_cus_224"] = lookups_step_all / s224
-            except Exception as exc:
-                result["overlap"]["step_s_lookup_cus_224"] = f"not run: {exc}"
+            else:
+                result["overlap"]["step_s_lookup_cus_224"] = "not run: hipExtStreamCreateWithCUMask failed on a rank"
         if not a.no_bwd:
             def bwd_a2a_only():
                 ex.bwd_a2a(0).wait()

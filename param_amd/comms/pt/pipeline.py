@@ -215,13 +215,15 @@ class ShardedEmbeddingExchange:
         o = sum(self.fwd_recv_splits[:src])
         return self.recv[slot][o:o + self.fwd_recv_splits[src]].view(self.local_batch, self.widths[src])
 
-    def selfcheck(self, slot: int, peer_block: Callable, exact: bool = True, rtol: float = 1e-5) -> dict:
+    def selfcheck(self, slot: int, peer_block: Callable, exact: bool = True, rtol: float = 1e-5, local_only: bool = False) -> dict:
         """Verify the payload of the forward exchange held in ``slot`` (already waited for) -- the reference's ``--c 1``
         idea (comms_utils.py:997-1055: a collective's result is compared with what it must be), applied to the pooled
         all-to-all: ``peer_block(src)`` returns what rank ``src`` must have sent THIS rank, ``[B_local, k]`` = the first k
         columns of its block, recomputed locally from rank ``src``'s seeds (or None to skip that peer).  Every rank checks
         its own receive buffer; the verdicts are combined with one MIN all-reduce, so every rank returns the same dict.
-        ``exact``: bit for bit (same kernel on both sides); otherwise ``rtol`` relative to the block's magnitude."""
+        ``exact``: bit for bit (same kernel on both sides); otherwise ``rtol`` relative to the block's magnitude.
+        ``local_only``: no collective here -- the caller combines the ranks' verdicts itself (:meth:`combine_selfcheck`), so that
+        a rank whose recomputation fails cannot leave the others waiting in an all-reduce."""
         bad, checked, worst = [], 0, 0.0
         for src in range(self.world):
             exp = peer_block(src)
@@ -236,13 +238,20 @@ class ShardedEmbeddingExchange:
             if not same:
                 bad.append(src)
                 worst = max(worst, float((got - exp).abs().max()))
-        flag = torch.tensor([0 if bad else 1, checked], dtype=torch.int64, device=self.recv[slot].device)
+        local = {"this_rank_ok": not bad, "peers_checked": checked, "mismatched_sources_on_this_rank": bad, "max_abs_diff": worst}
+        return local if local_only else self.combine_selfcheck(local)
+
+    def combine_selfcheck(self, local: dict) -> dict:
+        """one MIN all-reduce over the ranks' local verdicts (every rank must call it; a rank whose check could not run passes
+        ``{"error": ...}`` and turns the global verdict into "not run on every rank")"""
+        ran = 0 if "error" in local else 1
+        ok = 1 if (ran and local.get("this_rank_ok")) else 0
+        flag = torch.tensor([ok, ran, int(local.get("peers_checked", 0))], dtype=torch.int64, device=self.recv[0].device)
         if dist.is_initialized():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)
-        ok_everywhere, min_checked = bool(int(flag[0])), int(flag[1])
-        return {"a2a_selfcheck": "ok" if ok_everywhere else "MISMATCH", "this_rank_ok": not bad, "peers_checked": checked,
-                "min_peers_checked_over_ranks": min_checked, "mismatched_sources_on_this_rank": bad, "max_abs_diff": worst,
-                "ranks": self.world}
+        ok_all, ran_all, min_checked = bool(int(flag[0])), bool(int(flag[1])), int(flag[2])
+        verdict = "ok" if ok_all else ("not run on every rank" if not ran_all else "MISMATCH")
+        return dict(local, a2a_selfcheck=verdict, min_peers_checked_over_ranks=min_checked, ranks=self.world)
 
     def bytes_per_rank(self) -> int:
         """output-tensor bytes of ONE exchange per rank (the reference's ``memSize``, which stays the fp32 size under

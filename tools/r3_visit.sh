@@ -87,6 +87,18 @@ for n in ("distdebug_26tables.json","distdebug_criteo.json"):
     print(n, "tables", r["config"]["tables_total"], "value %.2f G" % (r["value"]/1e9), r["all_to_all"].get("selfcheck",{}).get("a2a_selfcheck"), "fwd_bwd", r.get("fwd_bwd_step",{}).get("avg_s_pipelined"))
 PY
       ;;
+    criteofwd:*)
+      # criteofwd:<bench args with , for spaces>;<...>   forward of the Criteo workload under bench.py tuning flags
+      IFS=: read -r _ cfgs <<< "$what"
+      IFS=';' read -ra arr <<< "$cfgs"
+      for c in "${arr[@]}"; do
+        timeout 300 python bench.py --workload criteo --no-bwd --no-cpu-baseline --steps 30 ${c//,/ } > "$out/criteofwd.json" 2> "$out/criteofwd.err"
+        python - "$out/criteofwd.json" "$c" <<'PY'
+import json,sys
+r=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print(f"criteo fwd [{sys.argv[2]:28s}] zipf {r['value']/1e9:.2f} G/s ({r['roofline']['zipf']['avg_launch_s']*1e6:.1f} us) uniform frac {r['roofline']['frac']:.3f} ({r['roofline']['avg_launch_s']*1e6:.1f} us)")
+PY
+      done ;;
     distdebug:*)
       # distdebug:<name>:<bench args with , for spaces>   the N>1 code path on a 1-rank RCCL group
       IFS=: read -r _ name bargs <<< "$what"
