@@ -13,9 +13,9 @@
 // in radix_sort.hip):
 //   seg_prep_tables_kernel   one workgroup per table: segment start / count from the offsets, pooling factor if every bag
 //                            of the (sliced) table has the same length, key bits of the table from rows[t]
-//   seg_prep_scan_kernel     one workgroup: output start and first tile of every segment, one 32-byte descriptor per tile
-//   seg_build_keys_kernel    only for tables WITHOUT a pooling factor (ragged, weighted): (key, bag) per lookup at request
-//                            positions (binary search over LDS-staged offsets); workgroups of other tables exit at once
+//   seg_prep_scan_kernel     workgroup 0: output start and first tile of every segment, one 32-byte descriptor per tile; the
+//                            other workgroups, only for tables WITHOUT a pooling factor (ragged, weighted): (key, bag) per
+//                            lookup at request positions (binary search over LDS-staged offsets) -- they exit at once otherwise
 //   seg_hist / seg_scan / seg_scatter   one radix pass over 4096-element tiles: per-tile digit counts, per-segment
 //                            exclusive prefix (+ absolute bucket starts), stable scatter
 //   MODE 1 / 2 (one global partition pass, then buckets):
@@ -191,9 +191,56 @@ __device__ __forceinline__ void scan2_1024(uint32_t* s_a, uint32_t* s_b) {
     }
 }
 
-// prep 2: one workgroup of 1024 threads (T <= 1024): exclusive scans over the tables, tile descriptors, header
-__global__ void __launch_bounds__(1024) seg_prep_scan_kernel(SegDesc* desc, int T, SegHeader* hdr, TileDesc* tiles, uint32_t tiles_cap) {
+// keys / values at request positions for the tables that have no pooling factor (and, WEIGHTED, for all: the value is the
+// lookup's position, its bag goes to bag_of): workgroup (chunk of 1024 bags, table) of the preparation kernel below.
+template <typename K, bool WEIGHTED>
+__device__ __forceinline__ void build_keys_chunk(int t, int chunk, const void* indices, const void* offsets, int idx64, int T, int64_t B,
+                                                 int64_t N, int64_t bag_begin, int64_t bag_count, const SegDesc* desc, int tshift, K* keys,
+                                                 uint32_t* vals, uint32_t* bag_of, int64_t* s_off) {
+    constexpr int kBags = kBuildBags;
+    if (!WEIGHTED && desc[t].pooling > 0) return;
+    const int64_t bag0 = bag_begin + static_cast<int64_t>(chunk) * kBags;
+    const int64_t left = bag_begin + bag_count - bag0;
+    if (left <= 0) return;
+    const int nb = left < kBags ? static_cast<int>(left) : kBags;
+    const int64_t TB = static_cast<int64_t>(T) * B;
+    const int64_t g0 = static_cast<int64_t>(t) * B + bag0;
+    for (int i = threadIdx.x; i <= nb; i += blockDim.x) s_off[i] = (g0 + i < TB) ? load_index(offsets, g0 + i, idx64) : N;
+    __syncthreads();
+    const int64_t base = s_off[0], end = s_off[nb];
+    for (int64_t j = base + threadIdx.x; j < end; j += blockDim.x) {
+        int lo = 0, hi = nb;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_off[mid] <= j) lo = mid; else hi = mid;
+        }
+        const uint32_t bag = static_cast<uint32_t>(bag0 + lo);
+        keys[j] = (static_cast<K>(t) << tshift) | static_cast<K>(load_index(indices, j, idx64));
+        if (WEIGHTED) {
+            vals[j] = static_cast<uint32_t>(j);
+            bag_of[j] = bag;
+        } else {
+            vals[j] = bag;
+        }
+    }
+}
+
+// prep 2, workgroup 0 (1024 threads, T <= 1024): exclusive scans over the tables, tile descriptors, header.  The OTHER
+// workgroups of the launch build the (key, bag) pairs of the tables without a pooling factor (one workgroup per 1024 bags of a
+// table; they exit at once for tables that have one) -- the two jobs need only prep 1's results, and a launch saved is ~6 us.
+template <typename K, bool WEIGHTED>
+__global__ void __launch_bounds__(1024) seg_prep_scan_kernel(SegDesc* desc, int T, SegHeader* hdr, TileDesc* tiles, uint32_t tiles_cap,
+                                                             const void* indices, const void* offsets, int idx64, int64_t B, int64_t N,
+                                                             int64_t bag_begin, int64_t bag_count, int tshift, K* keys, uint32_t* vals,
+                                                             uint32_t* bag_of, int chunks_per_table) {
     __shared__ uint32_t s_cnt[1024], s_til[1024], s_tb[1025], s_out[1024];
+    __shared__ int64_t s_off[kBuildBags + 1];
+    if (blockIdx.x > 0) {
+        const int w = static_cast<int>(blockIdx.x) - 1;
+        build_keys_chunk<K, WEIGHTED>(w / chunks_per_table, w % chunks_per_table, indices, offsets, idx64, T, B, N, bag_begin, bag_count,
+                                      desc, tshift, keys, vals, bag_of, s_off);
+        return;
+    }
     const int t = threadIdx.x;
     const uint32_t c = t < T ? desc[t].count : 0u;
     const uint32_t nt = t < T ? desc[t].ntiles : 0u;
@@ -237,42 +284,6 @@ __global__ void __launch_bounds__(1024) seg_prep_scan_kernel(SegDesc* desc, int 
         td.rbits = d.rbits;
         td.magic = d.pooling > 1 ? static_cast<uint32_t>(0x100000000ull / d.pooling) + 1u : 0u;
         tiles[g] = td;
-    }
-}
-
-// keys / values at request positions for the tables that have no pooling factor (and, WEIGHTED, for all: the value is the
-// lookup's position, its bag goes to bag_of).  grid (bag tiles of 1024, T).
-template <typename K, bool WEIGHTED>
-__global__ void __launch_bounds__(kT) seg_build_keys_kernel(const void* indices, const void* offsets, int idx64, int T, int64_t B,
-                                                            int64_t N, int64_t bag_begin, int64_t bag_count, const SegDesc* desc,
-                                                            int tshift, K* keys, uint32_t* vals, uint32_t* bag_of) {
-    constexpr int kBags = kBuildBags;
-    __shared__ int64_t s_off[kBags + 1];
-    const int t = blockIdx.y;
-    if (!WEIGHTED && desc[t].pooling > 0) return;
-    const int64_t bag0 = bag_begin + static_cast<int64_t>(blockIdx.x) * kBags;
-    const int64_t left = bag_begin + bag_count - bag0;
-    if (left <= 0) return;
-    const int nb = left < kBags ? static_cast<int>(left) : kBags;
-    const int64_t TB = static_cast<int64_t>(T) * B;
-    const int64_t g0 = static_cast<int64_t>(t) * B + bag0;
-    for (int i = threadIdx.x; i <= nb; i += kT) s_off[i] = (g0 + i < TB) ? load_index(offsets, g0 + i, idx64) : N;
-    __syncthreads();
-    const int64_t base = s_off[0], end = s_off[nb];
-    for (int64_t j = base + threadIdx.x; j < end; j += kT) {
-        int lo = 0, hi = nb;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (s_off[mid] <= j) lo = mid; else hi = mid;
-        }
-        const uint32_t bag = static_cast<uint32_t>(bag0 + lo);
-        keys[j] = (static_cast<K>(t) << tshift) | static_cast<K>(load_index(indices, j, idx64));
-        if (WEIGHTED) {
-            vals[j] = static_cast<uint32_t>(j);
-            bag_of[j] = bag;
-        } else {
-            vals[j] = bag;
-        }
     }
 }
 
@@ -847,15 +858,15 @@ hipError_t seg_sort_pairs(const SegSortRequest& rq, int mode, K* keys_a, K* keys
     const unsigned tm = static_cast<unsigned>(tiles_max(n, rq.T));
     hipLaunchKernelGGL(seg_prep_tables_kernel, dim3(rq.T), dim3(1024), 0, stream, rq.offsets, rq.idx64, rq.rows, rq.T, rq.B, rq.N,
                        rq.bag_begin, rq.bag_count, rq.weighted ? 1 : 0, s.desc);
-    hipLaunchKernelGGL(seg_prep_scan_kernel, dim3(1), dim3(1024), 0, stream, s.desc, rq.T, s.hdr, s.tiles, tm);
-    if (rq.bag_count > 0) {
-        const dim3 gk(static_cast<unsigned>((rq.bag_count + kBuildBags - 1) / kBuildBags), static_cast<unsigned>(rq.T));
+    {
+        const int chunks = rq.bag_count > 0 ? static_cast<int>((rq.bag_count + kBuildBags - 1) / kBuildBags) : 0;
+        const dim3 gp(1u + static_cast<unsigned>(chunks) * static_cast<unsigned>(rq.T));
         if (rq.weighted)
-            hipLaunchKernelGGL((seg_build_keys_kernel<K, true>), gk, dim3(kT), 0, stream, rq.indices, rq.offsets, rq.idx64, rq.T, rq.B, rq.N,
-                               rq.bag_begin, rq.bag_count, s.desc, rq.tshift, keys_a, vals_a, bag_of);
+            hipLaunchKernelGGL((seg_prep_scan_kernel<K, true>), gp, dim3(1024), 0, stream, s.desc, rq.T, s.hdr, s.tiles, tm, rq.indices,
+                               rq.offsets, rq.idx64, rq.B, rq.N, rq.bag_begin, rq.bag_count, rq.tshift, keys_a, vals_a, bag_of, chunks);
         else
-            hipLaunchKernelGGL((seg_build_keys_kernel<K, false>), gk, dim3(kT), 0, stream, rq.indices, rq.offsets, rq.idx64, rq.T, rq.B, rq.N,
-                               rq.bag_begin, rq.bag_count, s.desc, rq.tshift, keys_a, vals_a, bag_of);
+            hipLaunchKernelGGL((seg_prep_scan_kernel<K, false>), gp, dim3(1024), 0, stream, s.desc, rq.T, s.hdr, s.tiles, tm, rq.indices,
+                               rq.offsets, rq.idx64, rq.B, rq.N, rq.bag_begin, rq.bag_count, rq.tshift, keys_a, vals_a, bag_of, chunks);
     }
     // pass 0 reads the request (or the built keys in the a buffers) and writes the b buffers; later passes alternate, so the
     // sorted pairs end in the b buffers iff the pass count is odd (seg_sort_result_in_b).  Modes 1 / 2 run one global pass and
