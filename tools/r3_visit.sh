@@ -87,6 +87,17 @@ for n in ("distdebug_26tables.json","distdebug_criteo.json"):
     print(n, "tables", r["config"]["tables_total"], "value %.2f G" % (r["value"]/1e9), r["all_to_all"].get("selfcheck",{}).get("a2a_selfcheck"), "fwd_bwd", r.get("fwd_bwd_step",{}).get("avg_s_pipelined"))
 PY
       ;;
+    fwd:*)
+      # fwd:<ENV=val>;<ENV=val>...   the headline forward (Zipf value, uniform roofline fraction, other layout) under an environment setting
+      IFS=: read -r _ cfgs <<< "$what"
+      for c in ${cfgs//;/ }; do
+        env $c timeout 300 python bench.py --no-bwd --no-cpu-baseline --steps 30 > "$out/fwd_${c}.json" 2> "$out/fwd.err"
+        python - "$out/fwd_${c}.json" "$c" <<'PY'
+import json,sys
+r=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); o=r.get("other_layout",{})
+print(f"fwd [{sys.argv[2]:30s}] zipf {r['value']/1e9:.2f} G/s ({r['roofline']['zipf']['avg_launch_s']*1e6:.1f} us) uniform frac {r['roofline']['frac']:.4f} ({r['roofline']['avg_launch_s']*1e6:.1f} us) | other layout zipf {o.get('zipf_lookups_per_s',0)/1e9:.2f} G/s uniform {o.get('uniform_frac',0):.4f}")
+PY
+      done ;;
     criteofwd:*)
       # criteofwd:<bench args with , for spaces>;<...>   forward of the Criteo workload under bench.py tuning flags
       IFS=: read -r _ cfgs <<< "$what"
