@@ -200,7 +200,11 @@ def _cpu_modes(W: torch.Tensor, idx_sets, B: int, L: int, budget_s: float):
     finishes inside one quota period at full width -- 0.1 ms per step --, a longer run exhausts the quota and is throttled for
     the rest of every period -- 1-5 ms per step, in multiples of the scheduler's slice; the modes differed in their step
     counts, not in autograd.  With 64 steps everywhere all 128-thread modes agree (3.1-3.2 ms per step, throttled); a pool
-    no larger than the quota is not throttled and is both the fastest and the steadiest: that is the number to quote."""
+    no larger than the quota is not throttled and is both the fastest and the steadiest: that is the number to quote.
+    (Run to run it still moves by up to +-20 % -- 0.83 ... 1.25 G lookups/s over the round's runs: the box's 256 hardware threads
+    are shared with other containers (load average 25 when probed), and where 14 threads and the table's pages land is the
+    scheduler's choice.  Pinning the pool to 16 fixed cores of one socket was tried and is worse: 0.59-0.72 G with outliers of
+    30 x in two runs of three -- those cores are everybody's first choice.  The pool is left unpinned.)"""
     from param_amd.compute.pt.pytorch_emb import measure_cpu
 
     off = torch.arange(B, dtype=torch.int64) * L
