@@ -1,0 +1,63 @@
+// param_amd/csrc/bwd_sorted_apply.h -- private to the sorted backward: the apply kernels' argument block, the destination
+// element types and the launchers.  Included by embbag_bwd_sorted.hip (host logic) and by the three per-dtype translation
+// units embbag_bwd_sorted_{f32,bf16,f16}.hip, which hold the kernel instantiations -- 3 dtypes x 2 key widths x 4 lane-group
+// sizes x weighted x optimizer x 3 tile sizes of main + fix-up kernels compile in parallel instead of in one 2.5-minute unit.
+#pragma once
+
+#include "common.h"
+
+namespace pm {
+
+constexpr int kSortTile = 1024;  // sorted positions per workgroup in step 3 (2048: main +53 us, fix-up -28 us, gpurun s7)
+
+constexpr int kExactRun = 256;       // crossing runs up to this length are re-walked exactly
+constexpr int kMaxTablesLds = 1024;  // per-table metadata staged in LDS up to this many tables
+
+struct ChunkRec {
+    uint32_t lead_len;   // positions at the start of the chunk continuing a run begun earlier (0: none)
+    uint32_t trail_len;  // positions at the end of the chunk starting a run that continues (0: none)
+};
+
+struct SortedParams {
+    ChunkRec* recs;          // per-chunk piece lengths of boundary-crossing runs (main -> fix-up)
+    float* partials;         // per chunk: lead / trail fp32 partial sums, 2 * max_dim floats
+    int32_t T;
+    const void* keys;        // sorted keys (uint32 / uint64)
+    const uint32_t* vals;    // sorted values: bag within table (unweighted) or lookup position j (weighted)
+    const uint32_t* bag_of;  // weighted only: bag within table of lookup position j
+    void* const* dst;        // destination tables
+    const int32_t* dims;
+    const int64_t* out_offsets;
+    const float* grad;
+    const float* psw;
+    int64_t out_stride;
+    int64_t n;               // number of sorted pairs
+    int32_t rbits;           // key = (t << rbits) | row ; keys with bit (tbits+rbits) set are padding
+    int32_t kbits;           // tbits + rbits
+    int32_t max_dim;
+    int32_t nt_rows;         // 1: streaming (non-temporal) destination-row loads/stores
+    float alpha;
+    float* const* mom;       // row-wise Adagrad: device array [T] of per-row fp32 state (else NULL)
+    float lr;
+    float eps;
+    float wd;                // weight decay (row-wise Adagrad)
+    int32_t wd_mode;         // PM_WD_NONE / PM_WD_L2 / PM_WD_DECOUPLE
+    int32_t sr;              // 1: stochastic rounding of the updated row (16-bit tables)
+    uint64_t sr_seed;
+    int32_t exact_run;       // crossing runs up to this length are re-walked exactly in the fix-up
+    int32_t tshift;          // table id = key >> tshift (rbits + phase bits)
+    int32_t seg_tiles;       // > 0: the sorted array is T * H equal segments of this many tiles (fixed pooling)
+    int32_t H;               // bag phases (1 or 2): segments are (table, phase), one apply launch per phase
+    int32_t phase;           // phase this launch applies
+    int32_t tile;            // sorted positions per workgroup of the apply kernels (kSortTile, or smaller for small requests)
+    int32_t xcd;             // 1: XCD-affine block -> tile mapping (needs seg_tiles); 2: XCD-contiguous (any request)
+    const uint32_t* d_n;     // not NULL: the number of sorted pairs lives on the device (<= n), written by the segmented sort
+};
+
+
+// the apply of one destination dtype (defined in embbag_bwd_sorted_<dtype>.hip)
+hipError_t bwd_sorted_launch_f32(const SortedParams& sp, int key_bytes, int max_dim, hipStream_t stream);
+hipError_t bwd_sorted_launch_bf16(const SortedParams& sp, int key_bytes, int max_dim, hipStream_t stream);
+hipError_t bwd_sorted_launch_f16(const SortedParams& sp, int key_bytes, int max_dim, hipStream_t stream);
+
+}  // namespace pm

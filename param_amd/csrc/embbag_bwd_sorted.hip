@@ -34,51 +34,13 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 
-#include "common.h"
+#include "bwd_sorted_apply.h"
 
 namespace pm {
 namespace {
 
 constexpr int kDefaultSortMode = 0;
-constexpr int kSortTile = 1024;  // sorted positions per workgroup in step 3 (2048: main +53 us, fix-up -28 us, gpurun s7)
-
-struct ChunkRec;
-
-struct SortedParams {
-    ChunkRec* recs;          // per-chunk piece lengths of boundary-crossing runs (main -> fix-up)
-    float* partials;         // per chunk: lead / trail fp32 partial sums, 2 * max_dim floats
-    int32_t T;
-    const void* keys;        // sorted keys (uint32 / uint64)
-    const uint32_t* vals;    // sorted values: bag within table (unweighted) or lookup position j (weighted)
-    const uint32_t* bag_of;  // weighted only: bag within table of lookup position j
-    void* const* dst;        // destination tables
-    const int32_t* dims;
-    const int64_t* out_offsets;
-    const float* grad;
-    const float* psw;
-    int64_t out_stride;
-    int64_t n;               // number of sorted pairs
-    int32_t rbits;           // key = (t << rbits) | row ; keys with bit (tbits+rbits) set are padding
-    int32_t kbits;           // tbits + rbits
-    int32_t max_dim;
-    int32_t nt_rows;         // 1: streaming (non-temporal) destination-row loads/stores
-    float alpha;
-    float* const* mom;       // row-wise Adagrad: device array [T] of per-row fp32 state (else NULL)
-    float lr;
-    float eps;
-    float wd;                // weight decay (row-wise Adagrad)
-    int32_t wd_mode;         // PM_WD_NONE / PM_WD_L2 / PM_WD_DECOUPLE
-    int32_t sr;              // 1: stochastic rounding of the updated row (16-bit tables)
-    uint64_t sr_seed;
-    int32_t exact_run;       // crossing runs up to this length are re-walked exactly in the fix-up
-    int32_t tshift;          // table id = key >> tshift (rbits + phase bits)
-    int32_t seg_tiles;       // > 0: the sorted array is T * H equal segments of this many tiles (fixed pooling)
-    int32_t H;               // bag phases (1 or 2): segments are (table, phase), one apply launch per phase
-    int32_t phase;           // phase this launch applies
-    int32_t tile;            // sorted positions per workgroup of the apply kernels (kSortTile, or smaller for small requests)
-    int32_t xcd;             // 1: XCD-affine block -> tile mapping (needs seg_tiles); 2: XCD-contiguous (any request)
-    const uint32_t* d_n;     // not NULL: the number of sorted pairs lives on the device (<= n), written by the segmented sort
-};
+// (kSortTile, SortedParams, the destination types, the kernels and their launchers: bwd_sorted_apply.h / _impl.inc)
 
 // ---------------------------------------------------------------------------------------------
 // step 1: keys / values, same tiling and LDS offset staging as the forward
@@ -123,124 +85,7 @@ __global__ void __launch_bounds__(kBlock) build_keys_kernel(const KParams p, K* 
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// step 3 helpers: destination element types
-// 16-byte destination-row accesses; nt = streaming hint (every touched row is read once and written
-// once per call, so it should not displace the gradient rows that ARE re-read from L2)
-// cache policy of the destination-row accesses (SortedParams::nt_rows, pm_set_tuning nt_loads): 0 default, 1 non-temporal
-// (nt), 2 system scope (volatile: sc0 sc1 -- misses the non-coherent caches on the way in, writes through on the way out)
-// 3 / 4: plain / non-temporal load, agent-scope (sc1) store -- the store writes through and DROPS the line from the XCD's L2
-// (MI355X_MICROARCH.md, store flavours), so a row occupies L2 only between its load and its store and the re-read gradient
-// rows keep the capacity
-__device__ __forceinline__ u32x4 raw16_load(const char* p, int pol) {
-    const PM_GLOBAL u32x4* q = as_global<u32x4>(p);   // global, not flat (common.h)
-    if (pol == 2) return *reinterpret_cast<const volatile PM_GLOBAL u32x4*>(q);
-    return (pol == 1 || pol == 4) ? __builtin_nontemporal_load(q) : *q;
-}
-__device__ __forceinline__ void raw16_store(char* p, const u32x4 v, int pol) {
-    PM_GLOBAL u32x4* q = as_global<u32x4>(p);
-    if (pol == 2) *reinterpret_cast<volatile PM_GLOBAL u32x4*>(q) = v;
-    else if (pol >= 3) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(q), "v"(v) : "memory");
-    else if (pol == 1) __builtin_nontemporal_store(v, q);
-    else *q = v;
-}
 
-// counter-based random bits for stochastic rounding: one 64-bit splitmix output per (seed, row key, column pair)
-__device__ __forceinline__ uint32_t sr_bits(uint64_t seed, uint64_t rowkey, int col_pair) {
-    uint64_t x = seed ^ (rowkey * 0x9E3779B97F4A7C15ull) ^ (static_cast<uint64_t>(col_pair) * 0xD1B54A32D192ED03ull);
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return static_cast<uint32_t>((x ^ (x >> 31)) >> 32);
-}
-
-struct SDstF32 {
-    static constexpr int kVec = 4, kES = 4;
-    __device__ static __forceinline__ void store_sr(char* p, const float (&a)[4], int nt, uint64_t, uint64_t, int) {
-        store(p, a, nt);   // fp32 tables: nothing to round
-    }
-    __device__ static __forceinline__ void load(const char* p, float (&a)[4], int nt = 0) {
-        const u32x4 v = raw16_load(p, nt);
-        a[0] = __uint_as_float(v.x); a[1] = __uint_as_float(v.y); a[2] = __uint_as_float(v.z); a[3] = __uint_as_float(v.w);
-    }
-    __device__ static __forceinline__ void store(char* p, const float (&a)[4], int nt = 0) {
-        raw16_store(p, u32x4{__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3])}, nt);
-    }
-};
-__device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-// fp32 -> bf16, stochastic: add 16 uniform random bits below the kept mantissa, truncate.  P(round up) equals the
-// discarded fraction, so the expectation is the fp32 value; Inf/NaN pass through the nearest-even path.
-__device__ __forceinline__ uint32_t f32_to_bf16_sr(float f, uint32_t r16) {
-    const uint32_t u = __float_as_uint(f);
-    if ((u & 0x7f800000u) == 0x7f800000u) return f32_to_bf16_rne(f);
-    return (u + (r16 & 0xffffu)) >> 16;
-}
-struct SDstBF16 {
-    static constexpr int kVec = 8, kES = 2;
-    __device__ static __forceinline__ void store_sr(char* p, const float (&a)[8], int nt, uint64_t seed, uint64_t rowkey, int c) {
-        uint32_t w[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t r = sr_bits(seed, rowkey, (c >> 1) + i);
-            w[i] = f32_to_bf16_sr(a[2 * i], r) | (f32_to_bf16_sr(a[2 * i + 1], r >> 16) << 16);
-        }
-        raw16_store(p, u32x4{w[0], w[1], w[2], w[3]}, nt);
-    }
-    __device__ static __forceinline__ void load(const char* p, float (&a)[8], int nt = 0) {
-        const u32x4 v = raw16_load(p, nt);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { a[2 * i] = __uint_as_float(w[i] << 16); a[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
-    }
-    __device__ static __forceinline__ void store(char* p, const float (&a)[8], int nt = 0) {
-        uint32_t w[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = f32_to_bf16_rne(a[2 * i]) | (f32_to_bf16_rne(a[2 * i + 1]) << 16);
-        raw16_store(p, u32x4{w[0], w[1], w[2], w[3]}, nt);
-    }
-};
-// fp32 -> fp16, stochastic: 13 random bits below the 10 kept mantissa bits, then a truncating conversion
-// (the low 13 bits are cleared, so the cast is exact in fp16's normal range; same scheme as fbgemm's)
-__device__ __forceinline__ uint32_t f32_to_f16_sr(float f, uint32_t r13) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7f800000u) != 0x7f800000u) u = (u + (r13 & 0x1fffu)) & 0xffffe000u;
-    return static_cast<uint32_t>(__builtin_bit_cast(uint16_t, static_cast<_Float16>(__uint_as_float(u))));
-}
-struct SDstF16 {
-    static constexpr int kVec = 8, kES = 2;
-    __device__ static __forceinline__ void store_sr(char* p, const float (&a)[8], int nt, uint64_t seed, uint64_t rowkey, int c) {
-        uint32_t w[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t r = sr_bits(seed, rowkey, (c >> 1) + i);
-            w[i] = f32_to_f16_sr(a[2 * i], r) | (f32_to_f16_sr(a[2 * i + 1], r >> 16) << 16);
-        }
-        raw16_store(p, u32x4{w[0], w[1], w[2], w[3]}, nt);
-    }
-    __device__ static __forceinline__ void load(const char* p, float (&a)[8], int nt = 0) {
-        const u32x4 v = raw16_load(p, nt);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            a[2 * i] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(w[i] & 0xffffu)));
-            a[2 * i + 1] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(w[i] >> 16)));
-        }
-    }
-    __device__ static __forceinline__ void store(char* p, const float (&a)[8], int nt = 0) {
-        uint32_t w[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            w[i] = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, static_cast<_Float16>(a[2 * i]))) |
-                   (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, static_cast<_Float16>(a[2 * i + 1]))) << 16);
-        raw16_store(p, u32x4{w[0], w[1], w[2], w[3]}, nt);
-    }
-};
-
-#include "embbag_bwd_sorted_kernels.inc"
 
 // ---------------------------------------------------------------------------------------------
 // workspace layout (shared by the sort and apply entry points)
@@ -503,66 +348,6 @@ hipError_t sort_impl(const KParams& p, const SortPlan& g, SortWs& ws, hipStream_
                             g.segmented ? static_cast<size_t>(g.seg_len) : 0);
 }
 
-template <typename DST, typename K, int G, int TILE>
-hipError_t launch_apply_t(SortedParams sp, hipStream_t stream) {
-    constexpr int NG = kBlock / G;
-    constexpr int C = TILE / NG;
-    int64_t grid = (sp.n + TILE - 1) / TILE;
-    if (sp.xcd == 2)
-        grid = static_cast<int64_t>(kXcds) * ((grid + kXcds - 1) / kXcds);
-    else if (sp.seg_tiles > 0)
-        grid = (sp.xcd ? static_cast<int64_t>(kXcds) * ((sp.T + kXcds - 1) / kXcds) : static_cast<int64_t>(sp.T)) * sp.seg_tiles;
-    const int64_t n_chunks = (sp.n + C - 1) / C;       // every chunk below this index wrote its record
-    const int64_t fgrid = (n_chunks + NG - 1) / NG;
-    const dim3 g1(static_cast<unsigned>(grid)), g2(static_cast<unsigned>(fgrid)), blk(kBlock);
-#define PM_LAUNCH_SORTED(W_, OPT_)                                                                                   \
-    do {                                                                                                             \
-        hipLaunchKernelGGL((bwd_sorted_main_kernel<DST, K, G, W_, OPT_, TILE>), g1, blk,                             \
-                           static_cast<size_t>(sp.T) * ((OPT_) == 1 ? 28 : 20), stream, sp);                        \
-        hipLaunchKernelGGL((bwd_sorted_fixup_kernel<DST, K, G, W_, OPT_, TILE>), g2, blk, 0, stream, sp, n_chunks); \
-    } while (0)
-    // one (main, fix-up) pair per bag phase, in stream order: phase 0 has updated a row before phase 1 touches it
-    for (int ph = 0; ph < sp.H; ++ph) {
-        sp.phase = ph;
-        if (sp.mom) {  // row-wise Adagrad: one column pass with all G lanes (cross-lane reduction)
-            if (sp.max_dim > G * DST::kVec || sp.H != 1) return hipErrorInvalidValue;
-            if (sp.psw) PM_LAUNCH_SORTED(true, 1); else PM_LAUNCH_SORTED(false, 1);
-        } else {
-            if (sp.psw) PM_LAUNCH_SORTED(true, 0); else PM_LAUNCH_SORTED(false, 0);
-        }
-    }
-#undef PM_LAUNCH_SORTED
-    return hipGetLastError();
-}
-
-template <typename DST, typename K, int G>
-hipError_t launch_apply_w(const SortedParams& sp, hipStream_t stream) {
-    switch (sp.tile) {
-        case 256: return launch_apply_t<DST, K, G, 256>(sp, stream);
-        case 512: return launch_apply_t<DST, K, G, 512>(sp, stream);
-        default: return launch_apply_t<DST, K, G, kSortTile>(sp, stream);
-    }
-}
-
-template <typename DST, typename K>
-hipError_t launch_apply_g(const SortedParams& sp, int max_dim, hipStream_t stream) {
-    switch (group_lanes(max_dim, DST::kVec)) {
-        case 8: return launch_apply_w<DST, K, 8>(sp, stream);
-        case 16: return launch_apply_w<DST, K, 16>(sp, stream);
-        case 32: return launch_apply_w<DST, K, 32>(sp, stream);
-        default: return launch_apply_w<DST, K, 64>(sp, stream);
-    }
-}
-
-template <typename K>
-hipError_t launch_apply_k(const SortedParams& sp, int dst_dtype, int max_dim, hipStream_t stream) {
-    switch (dst_dtype) {
-        case PM_F32: return launch_apply_g<SDstF32, K>(sp, max_dim, stream);
-        case PM_BF16: return launch_apply_g<SDstBF16, K>(sp, max_dim, stream);
-        default: return launch_apply_g<SDstF16, K>(sp, max_dim, stream);
-    }
-}
-
 // the workspace is sized for the widest key the request can get (two phases), whatever plan is used later
 int ws_key_bytes(const KParams& p, int64_t max_rows) { return (bits_for(max_rows) + 1 + bits_for(p.T) + 1 <= 32) ? 4 : 8; }
 int ws_kbits_sort(const KParams& p, int64_t max_rows) { return bits_for(max_rows) + 1 + bits_for(p.T) + 1; }
@@ -719,8 +504,11 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
     sp.d_n = g.v2 ? seg_sort_count(ws.temp, static_cast<size_t>(p.N), p.T) : nullptr;
     sp.tile = g.v2 ? apply_tile(p.N) : kSortTile;      // round 2's plans (segments per table, phases) are laid out for 1024
     if (sp.n == 0) return hipSuccess;
-    return g.key_bytes == 4 ? launch_apply_k<uint32_t>(sp, dst_dtype, max_dim, stream)
-                            : launch_apply_k<uint64_t>(sp, dst_dtype, max_dim, stream);
+    switch (dst_dtype) {
+        case PM_F32: return bwd_sorted_launch_f32(sp, g.key_bytes, max_dim, stream);
+        case PM_BF16: return bwd_sorted_launch_bf16(sp, g.key_bytes, max_dim, stream);
+        default: return bwd_sorted_launch_f16(sp, g.key_bytes, max_dim, stream);
+    }
 }
 
 }  // namespace pm

@@ -1,0 +1,14 @@
+// param_amd/csrc/embbag_bwd_sorted_f16.hip -- the sorted backward's apply kernels for f16 destination tables (one translation
+// unit per destination dtype: see bwd_sorted_apply.h).
+#include "bwd_sorted_apply.h"
+
+namespace pm {
+namespace {
+#include "bwd_sorted_apply_impl.inc"
+}  // namespace
+
+hipError_t bwd_sorted_launch_f16(const SortedParams& sp, int key_bytes, int max_dim, hipStream_t stream) {
+    return key_bytes == 4 ? launch_apply_g<SDstF16, uint32_t>(sp, max_dim, stream) : launch_apply_g<SDstF16, uint64_t>(sp, max_dim, stream);
+}
+
+}  // namespace pm
