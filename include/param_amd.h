@@ -311,7 +311,11 @@ int pm_set_backward_tuning(int32_t sort_impl, int32_t order, int32_t xcd_affine,
 /*
  * ABI v4.  How the segmented key sort (sort_impl 0) orders a table's pairs (-1 = default; PARAM_AMD_SORT_MODE in the
  * environment changes the default):
- *   0  LSD passes over all row bits: (table, row, position) order, ceil(row bits / 8) global passes
+ *   0  LSD passes over all row bits: (table, row, position) order; 8 bits per pass, 9 where that saves a pass (17-18 and
+ *      25-27 row bits).  ONE kernel per pass: the digit counts of all passes come from one read of the request, and a
+ *      tile learns how many pairs precede it from its predecessors' published counts while the pass runs (look-back)
+ *   3  the same order from three kernels per pass (histogram, scan, scatter) -- the cross-check of 0, and what requests
+ *      of 2^30 lookups or more get
  *   1  ONE global partition pass on the low row digit, then every (table, digit) bucket is sorted by its remaining bits
  *      inside LDS: (table, row & 255, row >> 8, position) order -- equal rows adjacent and in request order, which is all
  *      the apply kernel needs; buckets stay balanced under any skew

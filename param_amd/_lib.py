@@ -220,6 +220,6 @@ def needs_pooling_hint() -> bool:
 
 
 def set_sort_tuning(mode: int = -1) -> None:
-    """``pm_set_sort_tuning``: segmented sort mode 0 LSD passes / 1 low-digit partition + bucket-local LDS sort / 2 top-digit
-    partition + local sort; -1 = default"""
+    """``pm_set_sort_tuning``: segmented sort mode 0 LSD passes, one look-back kernel per pass / 1 low-digit partition +
+    bucket-local LDS sort / 2 top-digit partition + local sort / 3 LSD passes of three kernels each; -1 = default"""
     check(load().pm_set_sort_tuning(mode))

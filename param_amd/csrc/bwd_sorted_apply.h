@@ -11,6 +11,7 @@ namespace pm {
 constexpr int kSortTile = 1024;  // sorted positions per workgroup in step 3 (2048: main +53 us, fix-up -28 us, gpurun s7)
 
 constexpr int kExactRun = 256;       // crossing runs up to this length are re-walked exactly
+constexpr int kFixGrid = 2048;      // workgroups of the fix-up kernel: one listed run per lane group and round
 constexpr int kMaxTablesLds = 1024;  // per-table metadata staged in LDS up to this many tables
 
 struct ChunkRec {
@@ -20,6 +21,8 @@ struct ChunkRec {
 
 struct SortedParams {
     ChunkRec* recs;          // per-chunk piece lengths of boundary-crossing runs (main -> fix-up)
+    uint32_t* fix_list;      // chunks holding the head of a run left in pieces, appended by the main kernel
+    uint32_t* fix_ctl;       // [0], [1]: list lengths, used in turn; [2], [3]: the generation as main / fix-up kernels read it
     float* partials;         // per chunk: lead / trail fp32 partial sums, 2 * max_dim floats
     int32_t T;
     const void* keys;        // sorted keys (uint32 / uint64)

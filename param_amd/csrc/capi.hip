@@ -215,7 +215,7 @@ int pm_set_backward_tuning(int32_t sort_impl, int32_t order, int32_t xcd_affine,
 }
 
 int pm_set_sort_tuning(int32_t mode) {
-    if (mode < -1 || mode > 2) return fail(PM_ERR_INVALID, "mode must be -1, 0, 1 or 2");
+    if (mode < -1 || mode > 3) return fail(PM_ERR_INVALID, "mode must be -1, 0, 1, 2 or 3");
     pm::set_sort_tuning(mode);
     return PM_OK;
 }

@@ -196,8 +196,11 @@ struct SegSortRequest {
     int tshift;              // key = table << tshift | row
     int rbits_max;           // bits_for(max_rows): the number of global passes of mode 0
     bool weighted;           // values = lookup positions (+ bag_of), every table through the key-building kernel
+    uint32_t* zero4;         // not NULL: four words the sort's first kernel sets to zero (the apply's work-list control words)
 };
 size_t seg_sort_scratch_bytes(size_t n_max, int T);
+int seg_sort_radix_bits(int mode, int rbits_max);   // 8, or 9 where a 9-bit digit saves a global pass (mode 0)
+bool seg_sort_lookback(int mode, int rbits_max, int64_t n);   // mode 0 as one kernel per pass (tiles learn their prefixes from their predecessors in flight)
 int seg_sort_passes(int mode, int rbits_max);
 bool seg_sort_result_in_b(int mode, int rbits_max);
 const SegDesc* seg_sort_desc(const void* scratch, size_t n_max, int T);

@@ -96,6 +96,8 @@ struct SortWs {
     uint32_t* vals_b;
     uint32_t* bag_of;
     ChunkRec* recs;
+    uint32_t* fix_list;      // chunk ids the apply's main kernel hands to its fix-up kernel
+    uint32_t* fix_ctl;       // two list lengths and two generation words (bwd_sorted_apply.h): zeroed by every sort
     float* partials;
     void* temp;
     size_t temp_bytes;
@@ -155,13 +157,14 @@ int knob(std::atomic<int>& k, int env_default) {
 int sort_impl_knob() { return knob(g_sort_impl, env_is("PARAM_AMD_SORT", "rocprim") ? 1 : env_is("PARAM_AMD_SORT", "legacy") ? 2 : 0); }
 bool use_rocprim_sort() { return sort_impl_knob() == 1; }
 // how the segmented sort orders a table's pairs (pm_set_sort_tuning, PARAM_AMD_SORT_MODE): 0 LSD passes over all row bits
-// (ascending rows), 1 one partition pass on the low row digit + bucket-local sort in LDS, 2 the same on the top digit
+// (ascending rows; one kernel per pass, tiles learn their prefixes from their predecessors in flight), 1 one partition pass on
+// the low row digit + bucket-local sort in LDS, 2 the same on the top digit, 3 = 0 with histogram / scan / scatter kernels per pass
 std::atomic<int> g_sort_mode{-1};
 int sort_mode_knob() {
     int v = g_sort_mode.load();
     if (v < 0) {
         const char* e = getenv("PARAM_AMD_SORT_MODE");
-        v = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : kDefaultSortMode;
+        v = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : kDefaultSortMode;
         g_sort_mode.store(v);
     }
     return v;
@@ -195,6 +198,8 @@ hipError_t ws_layout(void* base, int64_t n, int T, int key_bytes, int kbits_sort
     ws.bag_of = reinterpret_cast<uint32_t*>(take(weighted ? static_cast<size_t>(n) * 4 : 0));
     const size_t nch = static_cast<size_t>(max_chunks(n, max_dim));
     ws.recs = reinterpret_cast<ChunkRec*>(take(nch * sizeof(ChunkRec)));
+    ws.fix_list = reinterpret_cast<uint32_t*>(take(nch * sizeof(uint32_t)));
+    ws.fix_ctl = reinterpret_cast<uint32_t*>(take(4 * sizeof(uint32_t)));
     ws.partials = reinterpret_cast<float*>(take(nch * 2 * static_cast<size_t>(max_dim) * sizeof(float)));
     ws.temp = take(tb);
     ws.temp_bytes = tb;
@@ -227,7 +232,7 @@ struct SortPlan {
     int32_t seg_tiles;   // apply tiles (kSortTile) per segment, 0 = no segment structure
     int32_t T;
     bool v2;             // sorted by seg_sort.hip: segments, pooling and the pair count live on the device
-    int mode;            // seg_sort mode (0 LSD passes, 1 / 2 partition + bucket-local sort)
+    int mode;            // seg_sort mode (0 / 3 LSD passes, 1 / 2 partition + bucket-local sort)
     // what the sort was issued for: the apply must follow with the same request on the same workspace
     const void* indices;
     const void* offsets;
@@ -319,8 +324,12 @@ hipError_t sort_impl(const KParams& p, const SortPlan& g, SortWs& ws, hipStream_
         rq.tshift = g.tshift;
         rq.rbits_max = g.rbits;
         rq.weighted = g.weighted;
+        rq.zero4 = ws.fix_ctl;
         return seg_sort_pairs<K>(rq, g.mode, ka, kb, ws.vals_a, ws.vals_b, ws.bag_of, ws.temp, stream);
     }
+    // the apply's work-list control words start at zero (the segmented sort's first kernel does this itself)
+    hipError_t zrc = hipMemsetAsync(ws.fix_ctl, 0, 4 * sizeof(uint32_t), stream);
+    if (zrc != hipSuccess) return zrc;
     const int64_t s0 = p.bag_begin, s1 = p.bag_begin + p.bag_count;
     // per-table segments of a fixed-pooling request, one phase, no weights: bag and table of a lookup follow from its
     // position, so the first radix pass forms the pairs itself from the index array and no key-building kernel runs
@@ -403,9 +412,10 @@ std::string sort_plan_describe(const KParams& p, int64_t max_rows, int64_t fixed
     char buf[640];
     if (g.v2) {
         snprintf(buf, sizeof(buf),
-                 "sort=seg mode=%d key_bytes=%d rbits=%d hbits=0 kbits=%d sort_bits=%d passes=%d local=%d segmented=1 segments=device "
-                 "pooling=device phases=1 xcd=%d sliced=%d weighted=%d result_in_b=%d fused_keys=%d",
-                 g.mode, g.key_bytes, g.rbits, g.kbits, g.rbits, passes, g.mode != 0 ? 1 : 0, g.xcd ? 1 : 0, g.sliced ? 1 : 0,
+                 "sort=seg mode=%d key_bytes=%d rbits=%d hbits=0 kbits=%d sort_bits=%d passes=%d radix_bits=%d lookback=%d local=%d "
+                 "segmented=1 segments=device pooling=device phases=1 xcd=%d sliced=%d weighted=%d result_in_b=%d fused_keys=%d",
+                 g.mode, g.key_bytes, g.rbits, g.kbits, g.rbits, passes, seg_sort_radix_bits(g.mode, g.rbits),
+                 seg_sort_lookback(g.mode, g.rbits, p.N) ? 1 : 0, (g.mode == 1 || g.mode == 2) ? 1 : 0, g.xcd ? 1 : 0, g.sliced ? 1 : 0,
                  g.weighted ? 1 : 0, g.in_b ? 1 : 0, g.fused_keys ? 1 : 0);
         return buf;
     }
@@ -471,6 +481,8 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
     if (p.T > kMaxTablesLds) return hipErrorInvalidValue;
     SortedParams sp;
     sp.recs = ws.recs;
+    sp.fix_list = ws.fix_list;
+    sp.fix_ctl = ws.fix_ctl;
     sp.partials = ws.partials;
     sp.T = p.T;
     sp.keys = g.in_b ? ws.keys_b : ws.keys_a;

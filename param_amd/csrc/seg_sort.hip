@@ -41,6 +41,7 @@ constexpr int kWaves = kT / kWave;      // 4
 constexpr int kTile = 4096;             // elements per radix tile (16 per thread)
 constexpr int kTileItems = kTile / kT;  // 16
 constexpr int kRadix = 256;
+constexpr int kRadixMax = 512;          // mode 0 sorts 9 bits per pass where that saves a pass
 constexpr uint32_t kWaveCap = 1024;     // bucket-local sort by one wave: 16 pairs per lane
 constexpr uint32_t kLocalCap = kTile;   // ... by one workgroup; larger buckets go to the second level
 constexpr int kL2Grid = 512;            // persistent grid of the second-level passes
@@ -51,7 +52,8 @@ struct SegHeader {
     uint32_t n_tiles;    // radix tiles of the first level
     uint32_t n_l2;       // buckets on the second-level list (= second-level segments)
     uint32_t n_tiles2;   // radix tiles of the second level
-    uint32_t pad[12];
+    uint32_t lookback_timeouts;   // look-back walks that gave up (never, unless workgroups are not dispatched in index order)
+    uint32_t pad[11];
 };
 
 // one per radix tile: a pass kernel's workgroup learns everything about its tile from one 32-byte load
@@ -77,18 +79,20 @@ __device__ __forceinline__ int bits_for_dev(uint64_t n_values) {   // bits neede
     return n_values <= 1 ? 0 : 64 - __builtin_clzll(n_values - 1);
 }
 
-// digit of pass `pass` for a segment that sorts `bits` bits starting at bit `bit0`: (shift, mask).  mode 0 / 1: LSD, 8 bits per
-// pass from bit0 (mode 1 runs pass 0 only).  mode 2: pass 0 = the top digit.  A width of 0 makes the pass a stable copy.
-__device__ __forceinline__ void pass_digit(int mode, int pass, uint32_t rbits_packed, int& shift, uint32_t& mask) {
+// digit of pass `pass` for a segment that sorts `bits` bits starting at bit `bit0`: (shift, mask).  mode 0 / 1: LSD, rb (8 or 9)
+// bits per pass from bit0 (mode 1 runs pass 0 only).  mode 2: pass 0 = the top digit.  A width of 0 makes the pass a stable copy.
+// rb = 9 (512 digit values, mode 0 only) is chosen where it saves a global pass: 25 ... 27 row bits (the 40 M-row Criteo tables:
+// 3 passes instead of 4), 17 / 18 bits (2 instead of 3), 9 bits.
+__device__ __forceinline__ void pass_digit(int mode, int pass, uint32_t rbits_packed, int rb, int& shift, uint32_t& mask) {
     const int bits = static_cast<int>(rbits_packed & 255u), bit0 = static_cast<int>(rbits_packed >> 8);
     int w;
     if (mode == 2) {
         w = bits < 8 ? bits : 8;
         shift = bit0 + bits - w;
     } else {
-        shift = bit0 + 8 * pass;
-        w = bits - 8 * pass;
-        w = w < 0 ? 0 : (w > 8 ? 8 : w);
+        shift = bit0 + rb * pass;
+        w = bits - rb * pass;
+        w = w < 0 ? 0 : (w > rb ? rb : w);
         if (w == 0) shift = 0;
     }
     mask = (1u << w) - 1u;
@@ -100,10 +104,11 @@ __device__ __forceinline__ void local_bits(int mode, int rbits, int& lo, int& hi
     if (hi < lo) hi = lo;
 }
 
+template <int NB = 8>
 __device__ __forceinline__ uint64_t match_digit8(uint32_t d, bool valid) {
     uint64_t m = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < NB; ++b) {
         const bool bit = (d >> b) & 1u;
         const uint64_t bal = __ballot(bit);
         m &= bit ? bal : ~bal;
@@ -139,8 +144,9 @@ __device__ __forceinline__ void wave_lds_fence() {
 // prep 1: one workgroup (1024 threads) per table
 __global__ void __launch_bounds__(1024) seg_prep_tables_kernel(const void* offsets, int idx64, const int64_t* rows, int T, int64_t B,
                                                                int64_t N, int64_t bag_begin, int64_t bag_count, int force_ragged,
-                                                               SegDesc* desc) {
+                                                               SegDesc* desc, uint32_t* zero4) {
     const int t = blockIdx.x;
+    if (zero4 && t == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0u;
     const int64_t TB = static_cast<int64_t>(T) * B;
     const int64_t g0 = static_cast<int64_t>(t) * B + bag_begin;
     auto off_at = [&](int64_t g) -> int64_t { return g < TB ? load_index(offsets, g, idx64) : N; };
@@ -263,6 +269,7 @@ __global__ void __launch_bounds__(1024) seg_prep_scan_kernel(SegDesc* desc, int 
         hdr->n_tiles = n_tiles;
         hdr->n_l2 = 0;
         hdr->n_tiles2 = 0;
+        hdr->lookback_timeouts = 0;
     }
     __syncthreads();
     const uint32_t n_write = n_tiles < tiles_cap ? n_tiles : tiles_cap;
@@ -301,12 +308,43 @@ struct PassSrc {
     uint32_t bag_begin;
 };
 
+// the row ids (or keys: their low bits are the row) of a tile for the histogram kernels: position k * 256 + thread, all loads
+// in flight before the first use
+template <typename K>
+__device__ __forceinline__ void load_tile_rows(const TileDesc& td, const PassSrc<K>& src, uint64_t (&row)[kTileItems]) {
+    const uint32_t cnt = td.cnt, last = cnt - 1u;       // cnt >= 1; positions past the end re-read the last element (and are ignored)
+    auto at = [&](int k) { const uint32_t q = k * kT + threadIdx.x; return q < cnt ? q : last; };
+    if (src.first) {
+        // the row digits of request-order tiles can always be taken from the index array (built keys carry the same row bits)
+        if (src.idx64) {
+            const PM_GLOBAL int64_t* ip = as_global<int64_t>(src.indices) + td.in_base;
+#pragma unroll
+            for (int k = 0; k < kTileItems; ++k) row[k] = static_cast<uint64_t>(ip[at(k)]);
+        } else {
+            const PM_GLOBAL int32_t* ip = as_global<int32_t>(src.indices) + td.in_base;
+            uint32_t raw[kTileItems];
+#pragma unroll
+            for (int k = 0; k < kTileItems; ++k) raw[k] = static_cast<uint32_t>(ip[at(k)]);
+#pragma unroll
+            for (int k = 0; k < kTileItems; ++k) row[k] = raw[k];
+        }
+    } else {
+        const K* kp = src.keys + td.out_base;
+        K raw[kTileItems];
+#pragma unroll
+        for (int k = 0; k < kTileItems; ++k) raw[k] = kp[at(k)];
+#pragma unroll
+        for (int k = 0; k < kTileItems; ++k) row[k] = static_cast<uint64_t>(raw[k]);
+    }
+}
+
 // tiles are taken g = blockIdx.x, + gridDim.x, ... < *n_tiles: level 1 launches one workgroup per possible tile, level 2 a
 // persistent grid (the tile count of level 2 is known only on the device, and is zero for most requests)
-template <typename K>
+template <typename K, int RB>
 __global__ void __launch_bounds__(kT) seg_hist_kernel(const TileDesc* tiles, const uint32_t* n_tiles, const PassSrc<K> src, int mode, int pass,
                                                       uint32_t* bh) {
-    __shared__ uint32_t h[kRadix];
+    constexpr int RAD = 1 << RB;
+    __shared__ uint32_t h[RAD];
     // the first descriptor is fetched together with the tile count, not after it (grids never exceed the descriptor arrays):
     // a workgroup's start-up is a chain of dependent loads, and every link costs a memory latency that nothing hides
     TileDesc td = tiles[blockIdx.x];
@@ -316,22 +354,17 @@ __global__ void __launch_bounds__(kT) seg_hist_kernel(const TileDesc* tiles, con
         const uint32_t cnt = td.cnt;
         int shift;
         uint32_t mask;
-        pass_digit(mode, pass, td.rbits, shift, mask);
-        h[threadIdx.x] = 0;
+        pass_digit(mode, pass, td.rbits, RB, shift, mask);
+        for (int i = threadIdx.x; i < RAD; i += kT) h[i] = 0;
         __syncthreads();
         const int lane = threadIdx.x % kWave;
-        const uint64_t base = src.first ? td.in_base : td.out_base;
-#pragma unroll 4
+        uint64_t row[kTileItems];
+        load_tile_rows<K>(td, src, row);
+#pragma unroll
         for (int k = 0; k < kTileItems; ++k) {
             const uint32_t i = static_cast<uint32_t>(k) * kT + threadIdx.x;
             const bool valid = i < cnt;
-            uint32_t dg = 0u;
-            if (valid) {
-                // the row digit of pass 0 can always be taken from the index array (built keys carry the same row bits)
-                const uint64_t row = src.first ? static_cast<uint64_t>(load_index(src.indices, static_cast<int64_t>(base + i), src.idx64))
-                                               : static_cast<uint64_t>(src.keys[base + i]);
-                dg = static_cast<uint32_t>(row >> shift) & mask;
-            }
+            const uint32_t dg = valid ? static_cast<uint32_t>(row[k] >> shift) & mask : 0u;
             // a wave whose keys share the digit adds once (top digits of a skewed head, small tables); else one LDS atomic per lane
             const uint64_t vmask = __ballot(valid);
             const uint32_t firstd = __builtin_amdgcn_readfirstlane(dg);
@@ -343,7 +376,7 @@ __global__ void __launch_bounds__(kT) seg_hist_kernel(const TileDesc* tiles, con
             }
         }
         __syncthreads();
-        bh[static_cast<uint64_t>(g) * kRadix + threadIdx.x] = h[threadIdx.x];
+        for (int i = threadIdx.x; i < RAD; i += kT) bh[static_cast<uint64_t>(g) * RAD + i] = h[i];
         __syncthreads();
     }
 }
@@ -355,13 +388,17 @@ __global__ void __launch_bounds__(kT) seg_hist_kernel(const TileDesc* tiles, con
 // the Criteo sort (one workgroup per segment, and one segment holds half the lookups).
 constexpr int kScanChunks = 4;
 constexpr int kScanU = 16;
+template <int RB>
 __global__ void __launch_bounds__(kRadix * kScanChunks) seg_scan_kernel(SegHeader* hdr, const SegDesc* desc, const uint32_t* n_seg_dev,
                                                                         uint32_t n_seg_host, uint32_t* bh, uint32_t* bstart, uint32_t* bcnt,
                                                                         int classify, int mode, uint32_t* l2_list) {
-    __shared__ uint32_t s_sum[kScanChunks][kRadix];
+    constexpr int RAD = 1 << RB;
+    constexpr int DPT = RAD / kRadix;                    // digits per thread: 1 (256 digit values) or 2 (512: d and d + 256)
+    __shared__ uint32_t s_sum[kScanChunks][RAD];
     __shared__ uint32_t s_tmp[kWaves];
-    const int d = threadIdx.x % kRadix;
+    const int d0 = threadIdx.x % kRadix;
     const int c = threadIdx.x / kRadix;
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
     const uint32_t n_seg = n_seg_dev ? *n_seg_dev : n_seg_host;
     for (uint32_t t = blockIdx.x; t < n_seg; t += gridDim.x) {
         const SegDesc sd = desc[t];
@@ -369,57 +406,86 @@ __global__ void __launch_bounds__(kRadix * kScanChunks) seg_scan_kernel(SegHeade
         const uint32_t per = (sd.ntiles + kScanChunks - 1) / kScanChunks;
         const uint32_t ra = c * per < sd.ntiles ? c * per : sd.ntiles;
         const uint32_t rb = ra + per < sd.ntiles ? ra + per : sd.ntiles;
-        uint32_t sum = 0;
-        for (uint32_t r = ra; r < rb; r += kScanU) {
-            uint32_t v[kScanU];
+        // a thread's digits (d0 and, with 512 digit values, d0 + 256) walk the tiles together: the loads of both are in
+        // flight at once, the chain of dependent trips stays as short as with one digit
+        {
+            uint32_t sum[DPT];
 #pragma unroll
-            for (int u = 0; u < kScanU; ++u) v[u] = (r + u < rb) ? bh[(r0 + r + u) * kRadix + d] : 0u;
+            for (int j = 0; j < DPT; ++j) sum[j] = 0;
+            for (uint32_t r = ra; r < rb; r += kScanU) {
+                uint32_t v[DPT][kScanU];
 #pragma unroll
-            for (int u = 0; u < kScanU; ++u) sum += v[u];
+                for (int u = 0; u < kScanU; ++u)
+#pragma unroll
+                    for (int j = 0; j < DPT; ++j) v[j][u] = (r + u < rb) ? bh[(r0 + r + u) * RAD + d0 + j * kRadix] : 0u;
+#pragma unroll
+                for (int u = 0; u < kScanU; ++u)
+#pragma unroll
+                    for (int j = 0; j < DPT; ++j) sum[j] += v[j][u];
+            }
+#pragma unroll
+            for (int j = 0; j < DPT; ++j) s_sum[c][d0 + j * kRadix] = sum[j];
         }
-        s_sum[c][d] = sum;
         __syncthreads();
-        uint32_t run = 0, total = 0;
+        uint32_t total[DPT];
+        {
+            uint32_t run[DPT];
 #pragma unroll
-        for (int cc = 0; cc < kScanChunks; ++cc) {
-            const uint32_t x = s_sum[cc][d];
-            if (cc < c) run += x;
-            total += x;
-        }
-        for (uint32_t r = ra; r < rb; r += kScanU) {     // in-place rewrite: the loads of a batch are issued before its stores
-            uint32_t v[kScanU];
+            for (int j = 0; j < DPT; ++j) {
+                run[j] = 0;
+                total[j] = 0;
 #pragma unroll
-            for (int u = 0; u < kScanU; ++u) v[u] = (r + u < rb) ? bh[(r0 + r + u) * kRadix + d] : 0u;
+                for (int cc = 0; cc < kScanChunks; ++cc) {
+                    const uint32_t x = s_sum[cc][d0 + j * kRadix];
+                    if (cc < c) run[j] += x;
+                    total[j] += x;
+                }
+            }
+            for (uint32_t r = ra; r < rb; r += kScanU) {     // in-place rewrite: the loads of a batch are issued before its stores
+                uint32_t v[DPT][kScanU];
 #pragma unroll
-            for (int u = 0; u < kScanU; ++u) {
-                if (r + u < rb) bh[(r0 + r + u) * kRadix + d] = run;
-                run += v[u];
+                for (int u = 0; u < kScanU; ++u)
+#pragma unroll
+                    for (int j = 0; j < DPT; ++j) v[j][u] = (r + u < rb) ? bh[(r0 + r + u) * RAD + d0 + j * kRadix] : 0u;
+#pragma unroll
+                for (int u = 0; u < kScanU; ++u)
+#pragma unroll
+                    for (int j = 0; j < DPT; ++j) {
+                        if (r + u < rb) bh[(r0 + r + u) * RAD + d0 + j * kRadix] = run[j];
+                        run[j] += v[j][u];
+                    }
             }
         }
-        // exclusive scan of the digit totals over the 256 digits (the threads of chunk 0; everybody keeps the barriers)
-        uint32_t incl = (c == 0) ? total : 0u;
-        const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+        // exclusive scan of the digit totals in digit order (the 256 threads of chunk 0; everybody keeps the barriers): the
+        // digits d0 of all threads first, then the digits d0 + 256
+        uint32_t carry = 0;
 #pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const uint32_t up = __shfl_up(incl, off, kWave);
-            if (lane >= off) incl += up;
-        }
-        if (c == 0 && lane == kWave - 1) s_tmp[wave] = incl;
-        __syncthreads();
-        if (c == 0) {
-            uint32_t base = 0;
-            for (int w = 0; w < wave; ++w) base += s_tmp[w];
-            const uint32_t start = sd.out_start + base + incl - total;
-            const uint32_t b = t * kRadix + d;
-            bstart[b] = start;
-            bcnt[b] = total;
-            if (classify && total > kLocalCap) {
-                int lo, hi;
-                local_bits(mode, static_cast<int>(sd.rbits), lo, hi);
-                if (hi > lo) l2_list[atomicAdd(&hdr->n_l2, 1u)] = b;
+        for (int j = 0; j < DPT; ++j) {
+            uint32_t incl = (c == 0) ? total[j] : 0u;
+#pragma unroll
+            for (int off = 1; off < kWave; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off, kWave);
+                if (lane >= off) incl += up;
             }
+            if (c == 0 && lane == kWave - 1) s_tmp[wave] = incl;
+            __syncthreads();
+            uint32_t all = 0;
+            for (int w = 0; w < kWaves; ++w) all += s_tmp[w];
+            if (c == 0) {
+                uint32_t base = 0;
+                for (int w = 0; w < wave; ++w) base += s_tmp[w];
+                const uint32_t b = t * RAD + d0 + j * kRadix;
+                bstart[b] = sd.out_start + carry + base + incl - total[j];
+                bcnt[b] = total[j];
+                if (classify && total[j] > kLocalCap) {
+                    int lo, hi;
+                    local_bits(mode, static_cast<int>(sd.rbits), lo, hi);
+                    if (hi > lo) l2_list[atomicAdd(&hdr->n_l2, 1u)] = b;
+                }
+            }
+            carry += all;
+            __syncthreads();     // s_tmp (and, after the last round, s_sum) are rewritten next
         }
-        __syncthreads();     // s_sum / s_tmp are rewritten by the next segment of a looping workgroup
     }
 }
 
@@ -427,15 +493,14 @@ __global__ void __launch_bounds__(kRadix * kScanChunks) seg_scan_kernel(SegHeade
 // holds tile positions wave * chunk + r * 64 + lane, r = 0 .. ITEMS-1 (valid: r * 64 + lane < chunk and position < cnt),
 // so waves own consecutive runs of the tile and (wave, r, lane) order = position order.  On return s_key / s_val hold
 // the tile reordered by digit (stable), s_dstart[d] = first staged position of digit d.
-template <typename K, int ITEMS>
-__device__ __forceinline__ void tile_stage_by_digit(const K (&key)[ITEMS], const uint32_t (&val)[ITEMS], uint32_t cnt, uint32_t chunk,
-                                                    int shift, uint32_t mask, K* s_key, uint32_t* s_val, uint32_t* s_wcnt,
-                                                    uint32_t* s_dstart, uint32_t* s_tmp) {
+template <typename K, int ITEMS, int RB>
+__device__ __forceinline__ void tile_count_digits(const K (&key)[ITEMS], uint32_t (&rank)[ITEMS], uint32_t cnt, uint32_t chunk, int shift,
+                                                  uint32_t mask, uint32_t* s_wcnt) {
+    constexpr int RAD = 1 << RB;
     const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
-    for (int i = threadIdx.x; i < kWaves * kRadix; i += kT) s_wcnt[i] = 0;
+    for (int i = threadIdx.x; i < kWaves * RAD; i += kT) s_wcnt[i] = 0;
     __syncthreads();
-    uint32_t rank[ITEMS];
-    uint32_t* wcnt = s_wcnt + wave * kRadix;
+    uint32_t* wcnt = s_wcnt + wave * RAD;
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         rank[r] = 0;
@@ -443,7 +508,7 @@ __device__ __forceinline__ void tile_stage_by_digit(const K (&key)[ITEMS], const
             const uint32_t off = static_cast<uint32_t>(r) * kWave + lane;
             const bool valid = off < chunk && wave * chunk + off < cnt;
             const uint32_t d = static_cast<uint32_t>(key[r] >> shift) & mask;
-            const uint64_t m = match_digit8(d, valid);
+            const uint64_t m = match_digit8<RB>(d, valid);
             const uint32_t below = static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
             const uint32_t base = valid ? wcnt[d] : 0u;
             rank[r] = base + below;
@@ -453,18 +518,42 @@ __device__ __forceinline__ void tile_stage_by_digit(const K (&key)[ITEMS], const
         }
     }
     __syncthreads();
-    {
-        const int d = threadIdx.x;
+}
+
+// ... per-wave counts -> per-wave starts inside each digit's staged run, s_dstart[d] = first staged position of digit d; with
+// s_count, the tile's count of every digit is left there.  Ends with a barrier.
+template <int RB>
+__device__ __forceinline__ void tile_digit_starts(uint32_t* s_wcnt, uint32_t* s_dstart, uint32_t* s_tmp, uint32_t* s_count) {
+    constexpr int RAD = 1 << RB;
+    uint32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < RAD / kT; ++j) {              // digit order: the digits 0 .. 255 of all threads, then 256 .. 511
+        const int d = threadIdx.x + j * kT;
         uint32_t acc = 0;
 #pragma unroll
         for (int w = 0; w < kWaves; ++w) {
-            const uint32_t c = s_wcnt[w * kRadix + d];
-            s_wcnt[w * kRadix + d] = acc;     // wave w's elements of digit d start this far into the digit's staged run
+            const uint32_t c = s_wcnt[w * RAD + d];
+            s_wcnt[w * RAD + d] = acc;     // wave w's elements of digit d start this far into the digit's staged run
             acc += c;
         }
-        s_dstart[d] = block_excl_scan256(acc, s_tmp);
+        if (s_count) s_count[d] = acc;
+        s_dstart[d] = carry + block_excl_scan256(acc, s_tmp);
+        if (j + 1 < RAD / kT) {
+            carry += s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+            __syncthreads();               // s_tmp is rewritten by the next scan
+        }
     }
     __syncthreads();
+}
+
+// ... the elements go to their staged positions.  Ends with a barrier.
+template <typename K, int ITEMS, int RB>
+__device__ __forceinline__ void tile_place(const K (&key)[ITEMS], const uint32_t (&val)[ITEMS], const uint32_t (&rank)[ITEMS], uint32_t cnt,
+                                           uint32_t chunk, int shift, uint32_t mask, K* s_key, uint32_t* s_val, const uint32_t* s_wcnt,
+                                           const uint32_t* s_dstart, bool barrier) {
+    constexpr int RAD = 1 << RB;
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    const uint32_t* wcnt = s_wcnt + wave * RAD;
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         if (static_cast<uint32_t>(r) * kWave < chunk) {
@@ -477,42 +566,85 @@ __device__ __forceinline__ void tile_stage_by_digit(const K (&key)[ITEMS], const
             }
         }
     }
-    __syncthreads();
+    if (barrier) __syncthreads();
+}
+
+template <typename K, int ITEMS, int RB = 8>
+__device__ __forceinline__ void tile_stage_by_digit(const K (&key)[ITEMS], const uint32_t (&val)[ITEMS], uint32_t cnt, uint32_t chunk,
+                                                    int shift, uint32_t mask, K* s_key, uint32_t* s_val, uint32_t* s_wcnt,
+                                                    uint32_t* s_dstart, uint32_t* s_tmp) {
+    uint32_t rank[ITEMS];
+    tile_count_digits<K, ITEMS, RB>(key, rank, cnt, chunk, shift, mask, s_wcnt);
+    tile_digit_starts<RB>(s_wcnt, s_dstart, s_tmp, nullptr);
+    tile_place<K, ITEMS, RB>(key, val, rank, cnt, chunk, shift, mask, s_key, s_val, s_wcnt, s_dstart, true);
+}
+
+// a tile's pairs into registers: thread (wave, lane) holds tile positions wave * 1024 + r * 64 + lane.  ALL loads are issued
+// before the first value is used (written as one loop, load and key arithmetic per element, the compiler waits for every
+// load before it issues the next: sixteen memory latencies in a row at the start of every workgroup).
+template <typename K>
+__device__ __forceinline__ void load_tile_pairs(const TileDesc& td, const PassSrc<K>& src, uint64_t base, bool from_idx, K (&key)[kTileItems],
+                                                uint32_t (&val)[kTileItems]) {
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    constexpr uint32_t chunk = kTile / kWaves;
+    const uint32_t cnt = td.cnt, p0 = wave * chunk + lane, last = cnt - 1u;     // cnt >= 1; positions past the end re-read the last
+    auto at = [&](int r) { const uint32_t q = p0 + r * kWave; return q < cnt ? q : last; };   // element: straight-line code
+    if (from_idx) {
+        if (src.idx64) {
+            const PM_GLOBAL int64_t* ip = as_global<int64_t>(src.indices) + base;
+            int64_t raw[kTileItems];
+#pragma unroll
+            for (int r = 0; r < kTileItems; ++r) raw[r] = ip[at(r)];
+#pragma unroll
+            for (int r = 0; r < kTileItems; ++r) key[r] = static_cast<K>(raw[r]);
+        } else {
+            const PM_GLOBAL int32_t* ip = as_global<int32_t>(src.indices) + base;
+            int32_t raw[kTileItems];
+#pragma unroll
+            for (int r = 0; r < kTileItems; ++r) raw[r] = ip[at(r)];
+#pragma unroll
+            for (int r = 0; r < kTileItems; ++r) key[r] = static_cast<K>(static_cast<uint32_t>(raw[r]));
+        }
+        const K tkey = static_cast<K>(td.seg) << src.tshift;
+#pragma unroll
+        for (int r = 0; r < kTileItems; ++r) {
+            const uint32_t pos = p0 + r * kWave;
+            const bool valid = pos < cnt;
+            key[r] = valid ? (tkey | key[r]) : static_cast<K>(0);
+            val[r] = valid ? src.bag_begin + fast_div(td.first + pos, td.pooling, td.magic) : 0u;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < kTileItems; ++r) {
+            const uint32_t pos = p0 + r * kWave;
+            const bool valid = pos < cnt;
+            const K kk = src.keys[base + at(r)];
+            const uint32_t vv = src.vals[base + at(r)];
+            key[r] = valid ? kk : static_cast<K>(0);
+            val[r] = valid ? vv : 0u;
+        }
+    }
 }
 
 // one tile of a scatter pass (inlined into both kernels below: the LDS arrays keep their address space)
-template <typename K>
+template <typename K, int RB>
 __device__ __forceinline__ void scatter_tile(const TileDesc td, uint32_t g, const PassSrc<K>& src, int mode, int pass, const uint32_t* prefix,
                                              const uint32_t* bstart, K* kout, uint32_t* vout, K* s_key, uint32_t* s_val, uint32_t* s_wcnt,
                                              uint32_t* s_dstart, uint32_t* s_gbase, uint32_t* s_tmp, uint32_t lane_zero) {
-    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
     constexpr uint32_t chunk = kTile / kWaves;
-    const uint32_t t = td.seg, cnt = td.cnt, first = td.first;
+    const uint32_t t = td.seg, cnt = td.cnt;
     int shift;
     uint32_t mask;
-    pass_digit(mode, pass, td.rbits, shift, mask);
+    constexpr int RAD = 1 << RB;
+    pass_digit(mode, pass, td.rbits, RB, shift, mask);
     const uint64_t base = (src.first ? td.in_base : td.out_base) + lane_zero;
     const bool from_idx = src.first && td.pooling > 0;    // keys formed from the index array, bag = position / pooling
-    s_gbase[threadIdx.x] = bstart[t * kRadix + threadIdx.x] + prefix[static_cast<uint64_t>(g) * kRadix + threadIdx.x];
+#pragma unroll
+    for (int d = threadIdx.x; d < RAD; d += kT) s_gbase[d] = bstart[t * RAD + d] + prefix[static_cast<uint64_t>(g) * RAD + d];
     K key[kTileItems];
     uint32_t val[kTileItems];
-#pragma unroll
-    for (int r = 0; r < kTileItems; ++r) {
-        const uint32_t pos = wave * chunk + r * kWave + lane;
-        const bool valid = pos < cnt;
-        key[r] = 0;
-        val[r] = 0;
-        if (valid) {
-            if (from_idx) {
-                key[r] = (static_cast<K>(t) << src.tshift) | static_cast<K>(load_index(src.indices, static_cast<int64_t>(base + pos), src.idx64));
-                val[r] = src.bag_begin + fast_div(first + pos, td.pooling, td.magic);
-            } else {
-                key[r] = src.keys[base + pos];
-                val[r] = src.vals[base + pos];
-            }
-        }
-    }
-    tile_stage_by_digit<K, kTileItems>(key, val, cnt, chunk, shift, mask, s_key, s_val, s_wcnt, s_dstart, s_tmp);
+    load_tile_pairs<K>(td, src, base, from_idx, key, val);
+    tile_stage_by_digit<K, kTileItems, RB>(key, val, cnt, chunk, shift, mask, s_key, s_val, s_wcnt, s_dstart, s_tmp);
 #pragma unroll 4
     for (int k = 0; k < kTileItems; ++k) {
         const uint32_t q = k * kT + threadIdx.x;
@@ -527,38 +659,289 @@ __device__ __forceinline__ void scatter_tile(const TileDesc td, uint32_t g, cons
 }
 
 // level 1: one workgroup per possible tile (114 VGPRs: the four workgroups per CU that the 38 KB of LDS allow)
-template <typename K>
+template <typename K, int RB>
 __global__ void __launch_bounds__(kT) seg_scatter_kernel(const TileDesc* tiles, const uint32_t* n_tiles, const PassSrc<K> src, int mode, int pass,
                                                          const uint32_t* prefix, const uint32_t* bstart, K* kout, uint32_t* vout) {
     __shared__ K s_key[kTile];
     __shared__ uint32_t s_val[kTile];
-    __shared__ uint32_t s_wcnt[kWaves * kRadix];
-    __shared__ uint32_t s_dstart[kRadix];
-    __shared__ uint32_t s_gbase[kRadix];
+    __shared__ uint32_t s_wcnt[kWaves << RB];
+    __shared__ uint32_t s_dstart[1 << RB];
+    __shared__ uint32_t s_gbase[1 << RB];
     __shared__ uint32_t s_tmp[kWaves];
     const TileDesc td = tiles[blockIdx.x];      // together with the tile count (see seg_hist_kernel)
     if (blockIdx.x >= *n_tiles) return;
-    scatter_tile<K>(td, blockIdx.x, src, mode, pass, prefix, bstart, kout, vout, s_key, s_val, s_wcnt, s_dstart, s_gbase, s_tmp, 0u);
+    scatter_tile<K, RB>(td, blockIdx.x, src, mode, pass, prefix, bstart, kout, vout, s_key, s_val, s_wcnt, s_dstart, s_gbase, s_tmp, 0u);
 }
 
 // level 2: persistent grid.  (A plain loop around the tile body lets the compiler hoist every lane-dependent address out of
 // it -- 179 VGPRs, two workgroups per CU --; the body's addresses therefore hang on a zero the compiler cannot see through.)
-template <typename K>
+template <typename K, int RB>
 __global__ void __launch_bounds__(kT) seg_scatter_loop_kernel(const TileDesc* tiles, const uint32_t* n_tiles, const PassSrc<K> src, int mode,
                                                               int pass, const uint32_t* prefix, const uint32_t* bstart, K* kout, uint32_t* vout) {
     __shared__ K s_key[kTile];
     __shared__ uint32_t s_val[kTile];
-    __shared__ uint32_t s_wcnt[kWaves * kRadix];
-    __shared__ uint32_t s_dstart[kRadix];
-    __shared__ uint32_t s_gbase[kRadix];
+    __shared__ uint32_t s_wcnt[kWaves << RB];
+    __shared__ uint32_t s_dstart[1 << RB];
+    __shared__ uint32_t s_gbase[1 << RB];
     __shared__ uint32_t s_tmp[kWaves];
     const uint32_t nt = *n_tiles;
 #pragma clang loop unroll(disable)
     for (uint32_t g = blockIdx.x; g < nt; g += gridDim.x) {
         uint32_t lane_zero;
         asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
-        scatter_tile<K>(tiles[g], g, src, mode, pass, prefix, bstart, kout, vout, s_key, s_val, s_wcnt, s_dstart, s_gbase, s_tmp, lane_zero);
+        scatter_tile<K, RB>(tiles[g], g, src, mode, pass, prefix, bstart, kout, vout, s_key, s_val, s_wcnt, s_dstart, s_gbase, s_tmp, lane_zero);
         __syncthreads();   // s_gbase / the staged tile are rewritten by the next tile
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Mode 0 in ONE kernel per pass ("look-back" form; the three-kernel pass above stays for modes 1 / 2, the second level and
+// requests of 2^30 pairs or more).  The digit histograms of ALL passes are taken in one read of the request (seg_hist_all),
+// one small kernel turns them into the tables' bucket starts for every pass (seg_scan_all: table totals do not depend on
+// the order of the pairs), and each pass is then a single launch in which a tile learns how many pairs of each digit
+// precede it in its table from the tiles before it WHILE THE PASS RUNS: every tile publishes its digit counts in a status
+// row (one 32-bit word per digit: 2 flag bits | 30 value bits), walks back over its predecessors' rows adding their
+// counts until it meets one that already carries an inclusive prefix, and publishes its own inclusive prefix.  Rows are
+// written and polled with device-coherent (sc1) 16-byte accesses, four digits per lane; a word is self-contained (value
+// and flag travel together), so no fence is involved.  A tile only ever waits for tiles of lower index in the same table;
+// workgroups are dispatched in index order, so the lowest unfinished tile is always running and the walk cannot deadlock
+// (the poll is bounded all the same: a stuck walk gives up, counts in hdr->lookback_timeouts, and the result is wrong
+// rather than the device hung).
+constexpr uint32_t kStAggregate = 1u << 30, kStInclusive = 2u << 30, kStValue = (1u << 30) - 1u;
+constexpr int kMaxLbPasses = 5;
+constexpr size_t kLbRowWords = 4 * 512;   // passes x digit values of any plan the look-back form takes (seg_sort_lookback): 4 x 9 bits, 5 x 8 bits
+constexpr uint32_t kLbSpinCap = 1u << 20;
+
+struct U4 { uint32_t x, y, z, w; };
+using u32x4 = __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t;
+
+__device__ __forceinline__ u32x4 load_status(const uint32_t* p) {      // device-coherent: never served from a stale line
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
+constexpr int kLbBatch = 4;
+__device__ __forceinline__ void load_status_batch(const uint32_t* const (&p)[kLbBatch], u32x4 (&v)[kLbBatch]) {
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+        "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3])
+        : "memory");
+}
+__device__ __forceinline__ void store_status(uint32_t* p, u32x4 v) {   // write-through
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+
+// all passes' digit counts of every tile of the REQUEST: status rows st[pass][tile][digit] = count, flagged as published for
+// pass 0 only (pass 0's tiles are the request's; the other rows give seg_scan_all the table totals and read "not published")
+template <typename K, int RB>
+__global__ void __launch_bounds__(kT) seg_hist_all_kernel(const TileDesc* tiles, const uint32_t* n_tiles, const PassSrc<K> src, int npass,
+                                                          uint32_t tiles_cap, uint32_t* st) {
+    constexpr int RAD = 1 << RB;
+    __shared__ uint32_t h[kMaxLbPasses * RAD];
+    const TileDesc td = tiles[blockIdx.x];
+    const uint32_t nt = *n_tiles;
+    if (blockIdx.x >= nt) return;
+    const uint32_t g = blockIdx.x, cnt = td.cnt;
+    int shift[kMaxLbPasses];
+    uint32_t mask[kMaxLbPasses];
+#pragma unroll
+    for (int p = 0; p < kMaxLbPasses; ++p) pass_digit(0, p, td.rbits, RB, shift[p], mask[p]);
+    for (int i = threadIdx.x; i < npass * RAD; i += kT) h[i] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x % kWave;
+    uint64_t row[kTileItems];
+    load_tile_rows<K>(td, src, row);
+#pragma unroll
+    for (int k = 0; k < kTileItems; ++k) {
+        const uint32_t i = static_cast<uint32_t>(k) * kT + threadIdx.x;
+        const bool valid = i < cnt;
+        const uint64_t vmask = __ballot(valid);
+#pragma unroll
+        for (int p = 0; p < kMaxLbPasses; ++p) {
+            if (p < npass) {
+                const uint32_t dg = static_cast<uint32_t>(row[k] >> shift[p]) & mask[p];
+                // a wave whose keys share the digit adds once (top digits, small tables); else one LDS atomic per lane
+                const uint32_t firstd = __builtin_amdgcn_readfirstlane(dg);
+                const bool uniform = __ballot(valid && dg != firstd) == 0 && (vmask & 1ull);
+                if (uniform) {
+                    if (lane == 0) atomicAdd(&h[p * RAD + firstd], static_cast<uint32_t>(__popcll(vmask)));
+                } else if (valid) {
+                    atomicAdd(&h[p * RAD + dg], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const bool first_tile = td.first == 0;
+    for (int i = threadIdx.x; i < npass * RAD; i += kT) {
+        const int p = i / RAD, d = i % RAD;
+        const uint32_t c = h[i];
+        // pass 0: the count is this tile's aggregate (for a table's first tile: its inclusive prefix) from the start.  Later
+        // passes: flag 0 = not published -- the count is there for seg_scan_all only (these tiles are not those passes' tiles)
+        st[(static_cast<uint64_t>(p) * tiles_cap + g) * RAD + d] = c | (p != 0 ? 0u : first_tile ? kStInclusive : kStAggregate);
+    }
+}
+
+// grid (T, npass): bucket starts of table t in pass p = the table's first output position + exclusive scan over the digits of
+// the column sums of its tiles' counts
+template <int RB>
+__global__ void __launch_bounds__(kRadix * kScanChunks) seg_scan_all_kernel(const SegDesc* desc, const uint32_t* st, uint32_t tiles_cap, int T,
+                                                                            uint32_t* bstart_all) {
+    constexpr int RAD = 1 << RB;
+    constexpr int DPT = RAD / kRadix;
+    __shared__ uint32_t s_sum[kScanChunks][RAD];
+    __shared__ uint32_t s_tmp[kWaves];
+    const int d0 = threadIdx.x % kRadix, c = threadIdx.x / kRadix;
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    const uint32_t t = blockIdx.x, p = blockIdx.y;
+    const SegDesc sd = desc[t];
+    const uint64_t r0 = static_cast<uint64_t>(p) * tiles_cap + sd.tile_base;
+    const uint32_t per = (sd.ntiles + kScanChunks - 1) / kScanChunks;
+    const uint32_t ra = c * per < sd.ntiles ? c * per : sd.ntiles;
+    const uint32_t rb = ra + per < sd.ntiles ? ra + per : sd.ntiles;
+    uint32_t sum[DPT];
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) sum[j] = 0;
+    for (uint32_t r = ra; r < rb; r += kScanU) {
+        // rows past the chunk re-read its last row and are dropped afterwards: straight-line loads, all in flight together (a
+        // load under a predicate is waited for where it stands)
+        uint32_t v[DPT][kScanU];
+#pragma unroll
+        for (int u = 0; u < kScanU; ++u) {
+            const uint32_t rr = r + u < rb ? r + u : rb - 1u;
+#pragma unroll
+            for (int j = 0; j < DPT; ++j) v[j][u] = st[(r0 + rr) * RAD + d0 + j * kRadix];
+        }
+#pragma unroll
+        for (int u = 0; u < kScanU; ++u)
+#pragma unroll
+            for (int j = 0; j < DPT; ++j) sum[j] += (r + u < rb) ? (v[j][u] & kStValue) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) s_sum[c][d0 + j * kRadix] = sum[j];
+    __syncthreads();
+    uint32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) {
+        uint32_t total = 0;
+#pragma unroll
+        for (int cc = 0; cc < kScanChunks; ++cc) total += s_sum[cc][d0 + j * kRadix];
+        uint32_t incl = (c == 0) ? total : 0u;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, kWave);
+            if (lane >= off) incl += up;
+        }
+        if (c == 0 && lane == kWave - 1) s_tmp[wave] = incl;
+        __syncthreads();
+        uint32_t all = 0;
+        for (int w = 0; w < kWaves; ++w) all += s_tmp[w];
+        if (c == 0) {
+            uint32_t base = 0;
+            for (int w = 0; w < wave; ++w) base += s_tmp[w];
+            bstart_all[(static_cast<uint64_t>(p) * T + t) * RAD + d0 + j * kRadix] = sd.out_start + carry + base + incl - total;
+        }
+        carry += all;
+        __syncthreads();
+    }
+}
+
+// one pass: grid = one workgroup per possible tile
+template <typename K, int RB>
+__global__ void __launch_bounds__(kT) seg_lookback_pass_kernel(const TileDesc* tiles, SegHeader* hdr, const PassSrc<K> src, int pass, int T,
+                                                               uint32_t tiles_cap, uint32_t* st_all, const uint32_t* bstart_all, K* kout,
+                                                               uint32_t* vout) {
+    constexpr int RAD = 1 << RB;
+    constexpr int LW = RAD / 256;            // waves that publish and walk back: 256 digits each, four per lane
+    __shared__ K s_key[kTile];
+    __shared__ uint32_t s_val[kTile];
+    __shared__ uint32_t s_wcnt[kWaves << RB];
+    __shared__ uint32_t s_dstart[1 << RB];
+    __shared__ __attribute__((aligned(16))) uint32_t s_gbase[1 << RB];
+    __shared__ uint32_t s_tmp[kWaves];
+    const TileDesc td = tiles[blockIdx.x];
+    if (blockIdx.x >= hdr->n_tiles) return;
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    constexpr uint32_t chunk = kTile / kWaves;
+    const uint32_t g = blockIdx.x, t = td.seg, cnt = td.cnt, first = td.first;
+    const uint32_t j = first / static_cast<uint32_t>(kTile);                  // this tile's index inside its table
+    int shift;
+    uint32_t mask;
+    pass_digit(0, pass, td.rbits, RB, shift, mask);
+    uint32_t* st = st_all + static_cast<uint64_t>(pass) * tiles_cap * RAD;
+    const int dq = (wave * 256 + lane * 4) & (RAD - 1);                       // the look-back waves' first digit
+    u32x4 tb = {0u, 0u, 0u, 0u};
+    if (wave < LW) tb = *reinterpret_cast<const u32x4*>(bstart_all + (static_cast<uint64_t>(pass) * T + t) * RAD + dq);
+    const uint64_t base = src.first ? td.in_base : td.out_base;
+    const bool from_idx = src.first && td.pooling > 0;    // keys formed from the index array, bag = position / pooling
+    K key[kTileItems];
+    uint32_t val[kTileItems];
+    load_tile_pairs<K>(td, src, base, from_idx, key, val);
+    uint32_t rank[kTileItems];
+    tile_count_digits<K, kTileItems, RB>(key, rank, cnt, chunk, shift, mask, s_wcnt);
+    tile_digit_starts<RB>(s_wcnt, s_dstart, s_tmp, s_gbase);                  // s_gbase: the tile's count of every digit, for now
+    u32x4 mine = {0u, 0u, 0u, 0u};
+    if (wave < LW) {
+        mine = *reinterpret_cast<const u32x4*>(s_gbase + dq);
+        // pass 0's aggregates were published by seg_hist_all; a table's first tile publishes its inclusive prefix at once
+        if (pass != 0) store_status(st + static_cast<uint64_t>(g) * RAD + dq, mine | (j == 0 ? kStInclusive : kStAggregate));
+    }
+    tile_place<K, kTileItems, RB>(key, val, rank, cnt, chunk, shift, mask, s_key, s_val, s_wcnt, s_dstart, false);
+    if (wave < LW) {
+        u32x4 ex = {0u, 0u, 0u, 0u};
+        u32x4 open = {~0u, ~0u, ~0u, ~0u};                                    // digits still walking: all-ones
+        bool walking = j > 0;
+        uint32_t k = j;                                                       // next predecessor: table tile k - 1
+        while (walking) {
+            // kLbBatch predecessors per trip, their rows requested together (short of predecessors, the table's first tile is
+            // read again and skipped); the walk waits only at a row that is not published yet
+            const uint32_t* row[kLbBatch];
+            u32x4 s4[kLbBatch];
+#pragma unroll
+            for (int b = 0; b < kLbBatch; ++b) {
+                const uint32_t kb = k > static_cast<uint32_t>(b) ? k - 1u - b : 0u;
+                row[b] = st + static_cast<uint64_t>(g - (j - kb)) * RAD + dq;
+            }
+            load_status_batch(row, s4);
+#pragma unroll
+            for (int b = 0; b < kLbBatch; ++b) {
+                if (walking && k > 0) {                                       // wave-uniform
+                    --k;
+                    u32x4 v = s4[b];
+                    uint32_t spins = 0;
+                    while (__any(((v[0] >> 30) == 0u) | ((v[1] >> 30) == 0u) | ((v[2] >> 30) == 0u) | ((v[3] >> 30) == 0u))) {
+                        if (++spins > kLbSpinCap) {
+                            if (lane == 0) atomicAdd(&hdr->lookback_timeouts, 1u);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                        v = load_status(row[b]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        ex[c] += v[c] & kStValue & open[c];
+                        if ((v[c] >> 30) == 2u) open[c] = 0u;
+                    }
+                    walking = k > 0 && __any((open[0] | open[1] | open[2] | open[3]) != 0u);
+                }
+            }
+        }
+        if (j > 0) store_status(st + static_cast<uint64_t>(g) * RAD + dq, ((ex + mine) & kStValue) | kStInclusive);
+        *reinterpret_cast<u32x4*>(s_gbase + dq) = tb + ex;                    // where this tile's run of each digit starts
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int q0 = 0; q0 < kTileItems; ++q0) {
+        const uint32_t q = q0 * kT + threadIdx.x;
+        if (q < cnt) {
+            const K kk = s_key[q];
+            const uint32_t dg = static_cast<uint32_t>(kk >> shift) & mask;
+            const uint64_t o = static_cast<uint64_t>(s_gbase[dg]) + (q - s_dstart[dg]);
+            kout[o] = kk;
+            vout[o] = s_val[q];
+        }
     }
 }
 
@@ -811,6 +1194,8 @@ struct Scratch {
     uint32_t* bh2;
     uint32_t* bstart2;
     uint32_t* bcnt2;
+    uint32_t* st_all;        // look-back form: status rows [pass][tile][digit]
+    uint32_t* bstart_all;    // ... bucket starts [pass][table][digit]
     size_t total;
 };
 
@@ -823,20 +1208,23 @@ Scratch scratch_layout(void* base, size_t n, int T) {
     s.hdr = reinterpret_cast<SegHeader*>(take(sizeof(SegHeader)));
     s.desc = reinterpret_cast<SegDesc*>(take(sizeof(SegDesc) * static_cast<size_t>(T)));
     s.tiles = reinterpret_cast<TileDesc*>(take(sizeof(TileDesc) * tm));
-    s.bh = reinterpret_cast<uint32_t*>(take(4 * tm * kRadix));
-    s.bstart = reinterpret_cast<uint32_t*>(take(4 * nb));
-    s.bcnt = reinterpret_cast<uint32_t*>(take(4 * nb));
+    s.bh = reinterpret_cast<uint32_t*>(take(4 * tm * kRadixMax));       // level 1 may run 9-bit digits (seg_sort_radix_bits)
+    s.bstart = reinterpret_cast<uint32_t*>(take(4 * static_cast<size_t>(T) * kRadixMax));
+    s.bcnt = reinterpret_cast<uint32_t*>(take(4 * static_cast<size_t>(T) * kRadixMax));
     s.l2_list = reinterpret_cast<uint32_t*>(take(4 * nb));
     s.desc2 = reinterpret_cast<SegDesc*>(take(sizeof(SegDesc) * s2));
     s.tiles2 = reinterpret_cast<TileDesc*>(take(sizeof(TileDesc) * t2));
     s.bh2 = reinterpret_cast<uint32_t*>(take(4 * t2 * kRadix));
     s.bstart2 = reinterpret_cast<uint32_t*>(take(4 * s2 * kRadix));
     s.bcnt2 = reinterpret_cast<uint32_t*>(take(4 * s2 * kRadix));
+    s.st_all = reinterpret_cast<uint32_t*>(take(4 * tm * kLbRowWords));
+    s.bstart_all = reinterpret_cast<uint32_t*>(take(4 * static_cast<size_t>(T) * kLbRowWords));
     s.total = off;
     return s;
 }
 
 }  // namespace
+
 
 size_t seg_sort_scratch_bytes(size_t n_max, int T) { return scratch_layout(nullptr, n_max, T).total; }
 
@@ -845,8 +1233,54 @@ const uint32_t* seg_sort_count(const void* scratch, size_t n_max, int T) {
     return &scratch_layout(const_cast<void*>(scratch), n_max, T).hdr->n_total;
 }
 
-int seg_sort_passes(int mode, int rbits_max) { return mode == 0 ? (rbits_max <= 0 ? 1 : (rbits_max + 7) / 8) : 1; }
+// mode 0 sorts 9 bits per pass where that saves a global pass over the pairs: 25 .. 27 row bits (the 40 M-row Criteo tables:
+// 3 passes instead of 4), 17 / 18 bits (2 instead of 3), 9 bits.  Everywhere else 8: a 512-value digit costs LDS (three
+// workgroups per CU instead of four) and twice the per-tile histogram traffic.
+int seg_sort_radix_bits(int mode, int rbits_max) {
+    if ((mode != 0 && mode != 3) || rbits_max <= 8) return 8;
+    return (rbits_max + 8) / 9 < (rbits_max + 7) / 8 ? 9 : 8;
+}
+int seg_sort_passes(int mode, int rbits_max) {
+    if ((mode != 0 && mode != 3) || rbits_max <= 0) return 1;
+    const int rb = seg_sort_radix_bits(mode, rbits_max);
+    return (rbits_max + rb - 1) / rb;
+}
 bool seg_sort_result_in_b(int mode, int rbits_max) { return seg_sort_passes(mode, rbits_max) % 2 == 1; }
+
+// the look-back form serves mode 0 where its status words (30 value bits) and scratch rows (kLbRowWords) hold the request
+bool seg_sort_lookback(int mode, int rbits_max, int64_t n) {
+    if (mode != 0 || n >= (1ll << 30)) return false;        // mode 3 = mode 0 with the three-kernel passes
+    const int np = seg_sort_passes(mode, rbits_max);
+    return np <= kMaxLbPasses && static_cast<size_t>(np) << seg_sort_radix_bits(mode, rbits_max) <= kLbRowWords;
+}
+
+namespace {
+template <typename K, int RB>
+void launch_lookback(const Scratch& s, unsigned tm, int T, PassSrc<K> src, int total, K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b,
+                     hipStream_t stream) {
+    src.first = 1;
+    src.keys = keys_a;
+    src.vals = vals_a;
+    hipLaunchKernelGGL((seg_hist_all_kernel<K, RB>), dim3(tm), dim3(kT), 0, stream, s.tiles, &s.hdr->n_tiles, src, total, tm, s.st_all);
+    hipLaunchKernelGGL((seg_scan_all_kernel<RB>), dim3(T, total), dim3(kRadix * kScanChunks), 0, stream, s.desc, s.st_all, tm, T, s.bstart_all);
+    for (int p = 0; p < total; ++p) {
+        src.first = p == 0 ? 1 : 0;
+        src.keys = p == 0 ? keys_a : (p % 2 == 1 ? keys_b : keys_a);
+        src.vals = p == 0 ? vals_a : (p % 2 == 1 ? vals_b : vals_a);
+        K* kout = (p % 2 == 0) ? keys_b : keys_a;
+        uint32_t* vout = (p % 2 == 0) ? vals_b : vals_a;
+        hipLaunchKernelGGL((seg_lookback_pass_kernel<K, RB>), dim3(tm), dim3(kT), 0, stream, s.tiles, s.hdr, src, p, T, tm, s.st_all, s.bstart_all,
+                           kout, vout);
+    }
+}
+template <typename K, int RB>
+void launch_level1_pass(const Scratch& s, unsigned tm, int T, const PassSrc<K>& src, int mode, int p, K* kout, uint32_t* vout, hipStream_t stream) {
+    hipLaunchKernelGGL((seg_hist_kernel<K, RB>), dim3(tm), dim3(kT), 0, stream, s.tiles, &s.hdr->n_tiles, src, mode, p, s.bh);
+    hipLaunchKernelGGL((seg_scan_kernel<RB>), dim3(T), dim3(kRadix * kScanChunks), 0, stream, s.hdr, s.desc, static_cast<const uint32_t*>(nullptr),
+                       static_cast<uint32_t>(T), s.bh, s.bstart, s.bcnt, (mode != 0 && p == 0) ? 1 : 0, mode, s.l2_list);
+    hipLaunchKernelGGL((seg_scatter_kernel<K, RB>), dim3(tm), dim3(kT), 0, stream, s.tiles, &s.hdr->n_tiles, src, mode, p, s.bh, s.bstart, kout, vout);
+}
+}  // namespace
 
 template <typename K>
 hipError_t seg_sort_pairs(const SegSortRequest& rq, int mode, K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t* bag_of,
@@ -857,7 +1291,7 @@ hipError_t seg_sort_pairs(const SegSortRequest& rq, int mode, K* keys_a, K* keys
     const Scratch s = scratch_layout(scratch, n, rq.T);
     const unsigned tm = static_cast<unsigned>(tiles_max(n, rq.T));
     hipLaunchKernelGGL(seg_prep_tables_kernel, dim3(rq.T), dim3(1024), 0, stream, rq.offsets, rq.idx64, rq.rows, rq.T, rq.B, rq.N,
-                       rq.bag_begin, rq.bag_count, rq.weighted ? 1 : 0, s.desc);
+                       rq.bag_begin, rq.bag_count, rq.weighted ? 1 : 0, s.desc, rq.zero4);
     {
         const int chunks = rq.bag_count > 0 ? static_cast<int>((rq.bag_count + kBuildBags - 1) / kBuildBags) : 0;
         const dim3 gp(1u + static_cast<unsigned>(chunks) * static_cast<unsigned>(rq.T));
@@ -871,23 +1305,27 @@ hipError_t seg_sort_pairs(const SegSortRequest& rq, int mode, K* keys_a, K* keys
     // pass 0 reads the request (or the built keys in the a buffers) and writes the b buffers; later passes alternate, so the
     // sorted pairs end in the b buffers iff the pass count is odd (seg_sort_result_in_b).  Modes 1 / 2 run one global pass and
     // then work in place in b; the a buffers are the second level's spare space.
-    const int total = seg_sort_passes(mode, rq.rbits_max);
+    const int total = seg_sort_passes(mode, rq.rbits_max), rb = seg_sort_radix_bits(mode, rq.rbits_max);
+    const bool lookback = seg_sort_lookback(mode, rq.rbits_max, rq.N);
+    if (mode == 3) mode = 0;
     PassSrc<K> src;
     src.indices = rq.indices;
     src.idx64 = rq.idx64;
     src.tshift = rq.tshift;
     src.bag_begin = static_cast<uint32_t>(rq.bag_begin);
+    if (lookback) {
+        if (rb == 9) launch_lookback<K, 9>(s, tm, rq.T, src, total, keys_a, keys_b, vals_a, vals_b, stream);
+        else launch_lookback<K, 8>(s, tm, rq.T, src, total, keys_a, keys_b, vals_a, vals_b, stream);
+        return hipGetLastError();
+    }
     for (int p = 0; p < total; ++p) {
         src.first = p == 0 ? 1 : 0;
         src.keys = p == 0 ? keys_a : (p % 2 == 1 ? keys_b : keys_a);
         src.vals = p == 0 ? vals_a : (p % 2 == 1 ? vals_b : vals_a);
         K* kout = (p % 2 == 0) ? keys_b : keys_a;
         uint32_t* vout = (p % 2 == 0) ? vals_b : vals_a;
-        hipLaunchKernelGGL((seg_hist_kernel<K>), dim3(tm), dim3(kT), 0, stream, s.tiles, &s.hdr->n_tiles, src, mode, p, s.bh);
-        hipLaunchKernelGGL(seg_scan_kernel, dim3(rq.T), dim3(kRadix * kScanChunks), 0, stream, s.hdr, s.desc, static_cast<const uint32_t*>(nullptr),
-                           static_cast<uint32_t>(rq.T), s.bh, s.bstart, s.bcnt, (mode != 0 && p == 0) ? 1 : 0, mode, s.l2_list);
-        hipLaunchKernelGGL((seg_scatter_kernel<K>), dim3(tm), dim3(kT), 0, stream, s.tiles, &s.hdr->n_tiles, src, mode, p, s.bh, s.bstart, kout,
-                           vout);
+        if (rb == 9) launch_level1_pass<K, 9>(s, tm, rq.T, src, mode, p, kout, vout, stream);
+        else launch_level1_pass<K, 8>(s, tm, rq.T, src, mode, p, kout, vout, stream);
     }
     if (mode != 0 && rq.rbits_max > 8) {
         const uint32_t nb = static_cast<uint32_t>(rq.T) * kRadix;
@@ -904,10 +1342,10 @@ hipError_t seg_sort_pairs(const SegSortRequest& rq, int mode, K* keys_a, K* keys
             src.vals = (q % 2 == 0) ? vals_b : vals_a;
             K* kout = (q % 2 == 0) ? keys_a : keys_b;
             uint32_t* vout = (q % 2 == 0) ? vals_a : vals_b;
-            hipLaunchKernelGGL((seg_hist_kernel<K>), dim3(kL2Grid), dim3(kT), 0, stream, s.tiles2, &s.hdr->n_tiles2, src, 0, q, s.bh2);
-            hipLaunchKernelGGL(seg_scan_kernel, dim3(kL2Grid / 2), dim3(kRadix * kScanChunks), 0, stream, s.hdr, s.desc2, &s.hdr->n_l2, 0u, s.bh2, s.bstart2,
+            hipLaunchKernelGGL((seg_hist_kernel<K, 8>), dim3(kL2Grid), dim3(kT), 0, stream, s.tiles2, &s.hdr->n_tiles2, src, 0, q, s.bh2);
+            hipLaunchKernelGGL((seg_scan_kernel<8>), dim3(kL2Grid / 2), dim3(kRadix * kScanChunks), 0, stream, s.hdr, s.desc2, &s.hdr->n_l2, 0u, s.bh2, s.bstart2,
                                s.bcnt2, 0, 0, static_cast<uint32_t*>(nullptr));
-            hipLaunchKernelGGL((seg_scatter_loop_kernel<K>), dim3(kL2Grid), dim3(kT), 0, stream, s.tiles2, &s.hdr->n_tiles2, src, 0, q, s.bh2,
+            hipLaunchKernelGGL((seg_scatter_loop_kernel<K, 8>), dim3(kL2Grid), dim3(kT), 0, stream, s.tiles2, &s.hdr->n_tiles2, src, 0, q, s.bh2,
                                s.bstart2, kout, vout);
         }
     }

@@ -55,7 +55,7 @@ def test_argument_validation_without_gpu():
     assert b"bag_begin" in L.pm_last_error()
     assert L.pm_set_tuning(3, 0, -1, -1) == _lib.PM_ERR_INVALID
     assert L.pm_set_tuning(0, 0, -1, -1) == _lib.PM_OK
-    assert L.pm_set_backward_tuning(3, 0, 0, -1) == _lib.PM_ERR_INVALID and L.pm_set_sort_tuning(3) == _lib.PM_ERR_INVALID and L.pm_set_sort_tuning(-1) == _lib.PM_OK and L.pm_set_backward_tuning(-1, -1, -1, -1) == _lib.PM_OK
+    assert L.pm_set_backward_tuning(3, 0, 0, -1) == _lib.PM_ERR_INVALID and L.pm_set_sort_tuning(4) == _lib.PM_ERR_INVALID and L.pm_set_sort_tuning(-1) == _lib.PM_OK and L.pm_set_backward_tuning(-1, -1, -1, -1) == _lib.PM_OK
     in_b = ctypes.c_int32(-1)
     assert L.pm_radix_sort_pairs(None, None, None, None, 0, None, 4, 0, 24, 0, None, 0, ctypes.byref(in_b), None) == _lib.PM_OK
     assert in_b.value == 1                                        # 3 passes: the result would be in the b buffers
@@ -147,12 +147,15 @@ def test_sort_plan_decisions_on_the_host():
         assert seg["xcd"] == "1" and seg["key_bytes"] == "4" and seg["rbits"] == "24" and seg["kbits"] == "30" and seg["sort_bits"] == "24"
         assert seg["fused_keys"] == ("0" if kw.get("weighted") else "1")
     assert _plan(L, 26, 8192, 8, 40_000_000)["rbits"] == "26"
-    for mode, passes, in_b in ((0, "3", "1"), (1, "1", "1"), (2, "1", "1")):
+    for mode, passes, in_b in ((0, "3", "1"), (1, "1", "1"), (2, "1", "1"), (3, "3", "1")):
         assert L.pm_set_sort_tuning(mode) == _lib.PM_OK
         seg = _plan(L, 48, 8192, 20, 10_000_000)
-        assert seg["mode"] == str(mode) and seg["passes"] == passes and seg["result_in_b"] == in_b and seg["local"] == ("0" if mode == 0 else "1")
+        assert seg["mode"] == str(mode) and seg["passes"] == passes and seg["result_in_b"] == in_b
+        assert seg["local"] == ("1" if mode in (1, 2) else "0") and seg["lookback"] == ("1" if mode == 0 else "0")
     assert L.pm_set_sort_tuning(0) == _lib.PM_OK
-    assert _plan(L, 26, 8192, 8, 40_000_000)["passes"] == "4" and _plan(L, 26, 8192, 8, 40_000_000)["result_in_b"] == "0"
+    criteo = _plan(L, 26, 8192, 8, 40_000_000)                    # 26 row bits: 9-bit digits save a pass (3 instead of 4)
+    assert criteo["passes"] == "3" and criteo["radix_bits"] == "9" and criteo["result_in_b"] == "1"
+    assert _plan(L, 26, 8192, 8, 10_000_000)["radix_bits"] == "8" and _plan(L, 4, 512, 8, 200_000)["passes"] == "2"
     assert _plan(L, 1024, 64, 64, 1 << 30)["key_bytes"] == "8"
     assert L.pm_set_sort_tuning(-1) == _lib.PM_OK
     # round 2's host-side plans (sort_impl 2), kept as the measured alternative

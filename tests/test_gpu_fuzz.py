@@ -73,7 +73,7 @@ def test_random_request_vs_oracle(seed, coracle):
     rng = np.random.default_rng(1000 + seed)
     c = _case(rng)
     T, B, dims, rows = c["T"], c["B"], c["dims"], c["rows"]
-    param_amd.set_sort_tuning(seed % 3)        # the segmented sort's three modes take turns
+    param_amd.set_sort_tuning(seed % 4)        # the segmented sort's four modes take turns
     m = BatchedEmbeddingBagMI355(rows, dims, dtype=c["wdt"], device=DEV, layout=c["layout"], init="normal", seed=seed,
                                  fused_update=False)
     tabs_f32 = [m.table(t).float().cpu().numpy().copy() for t in range(T)]

@@ -85,7 +85,7 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 @pytest.mark.parametrize("case", sorted(CASES))
 @pytest.mark.parametrize("idt", [torch.int64, torch.int32])
 def test_sorted_pairs_equal_numpys_stable_order(case, mode, idt):
@@ -126,6 +126,48 @@ def test_sorted_pairs_equal_numpys_stable_order(case, mode, idt):
     k, v, tshift = _sorted(m, it, ot, B, psw)
     ek, ev = _expected(idx, off, T, B, mode, tshift, weighted=True)
     assert np.array_equal(k, ek) and np.array_equal(v, ev), (case, mode, "weighted")
+    param_amd.set_sort_tuning()
+
+@pytest.mark.parametrize("mode", [0, 3])
+@pytest.mark.parametrize("big", [300, 512, 513, 200_000, 1 << 18, 40_000_000, 100_000_000, (1 << 27) + 1])
+def test_nine_bit_digits_where_they_save_a_pass(big, mode):
+    """mode 0 sorts 9 bits per pass when ceil(bits / 9) < ceil(bits / 8) for the request's widest table (9, 17, 18, 25 .. 27,
+    33 .. 36 row bits): the plan says so, smaller tables ride along (fewer digits, copy passes), and the order is numpy's.
+    (1 << 27) + 1 rows = 28 bits and 513 rows = 10 bits stay on 8-bit digits.)"""
+    import param_amd
+    from param_amd import BatchedEmbeddingBagMI355
+    from param_amd.embedding_bag import sort_plan
+
+    rng = np.random.default_rng(big % 1000003)
+    bits = max(1, int(big - 1).bit_length())
+    others = [3, 200, 100, 60] if big < 1000 else [3, 70000, 600, 1 << 24 if big > (1 << 24) else 5000]
+    rows, B = [big] + others, 1024
+    pools = [9, 2, 5, 1, 12]
+    if big == 100_000_000:           # 27 row bits + 6 table bits: 8-byte keys on 9-bit digits
+        rows, pools = rows + [50] * 36, pools + [1] * 36
+    dim = 4
+    free, _ = torch.cuda.mem_get_info()
+    if free < sum(rows) * dim * 4 + (8 << 30):
+        pytest.skip("not enough free HBM for the table")
+    hot = [(0.2, np.array([big - 1, 0, big // 2, min(big - 1, 511), min(big - 1, 512)]))] + [None] * (len(rows) - 1)
+    idx, off = _request(rng, rows, B, lambda t: np.full(B, pools[t]), hot=hot)
+    param_amd.set_sort_tuning(mode)
+    m = BatchedEmbeddingBagMI355(rows, dim, device=DEV, init=None, fused_update=False)
+    it, ot = torch.from_numpy(idx).to(DEV), torch.from_numpy(off).to(DEV)
+    plan = dict(kv.split("=") for kv in sort_plan(m._tables(), it, ot, B).split())
+    assert plan["lookback"] == ("1" if mode == 0 else "0"), plan
+    nine = -(-bits // 9) < -(-bits // 8) and bits > 8
+    assert plan["rbits"] == str(bits) and plan["radix_bits"] == ("9" if nine else "8"), plan
+    assert plan["key_bytes"] == ("8" if len(rows) > 32 else "4"), plan
+    assert plan["passes"] == str(-(-bits // (9 if nine else 8))), plan
+    k, v, tshift = _sorted(m, it, ot, B)
+    ek, ev = _expected(idx, off, len(rows), B, 0, tshift)
+    assert np.array_equal(k, ek), (big, int(np.argmax(k != ek)))
+    assert np.array_equal(v, ev), (big, int(np.argmax(v != ev)))
+    b0, nb = 100, 517
+    k, v, tshift = _sorted(m, it, ot, B, None, b0, nb)
+    ek, ev = _expected(idx, off, len(rows), B, 0, tshift, b0, nb)
+    assert np.array_equal(k, ek) and np.array_equal(v, ev), (big, "slice")
     param_amd.set_sort_tuning()
 
 
