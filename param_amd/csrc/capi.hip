@@ -10,6 +10,11 @@ namespace {
 
 thread_local std::string g_last_error;
 
+// Row loads a lane group keeps in flight in the forward.  Round 3 found that rounds 1-2 had measured this knob with ONE load
+// in flight whatever its value (a wait at the merge of the staged / unstaged index paths, embbag_fwd.hip); with the batch
+// real: 1 -> 19.3 G lookups/s Zipf / 0.727 of the HBM peak uniform, 2 -> 22.2 / 0.734, 3 -> 21.5 / 0.712, 4 -> 21.7 / 0.732,
+// 6 -> 21.3 / 0.712, 8 -> 21.4 / 0.732 (48 x 10 M x 128 fp32, profiles/r03_fwd_unroll_sweep.txt); Criteo 14.1 / 15.6 / 15.1 at 1 / 2 / 4.
+constexpr int kDefaultUnroll = 2;
 std::atomic<int> g_unroll{0};
 std::atomic<int> g_bags_per_block{0};
 std::atomic<int> g_xcd_affine{-1};
@@ -190,8 +195,8 @@ const char* pm_build_info(void) {
 const char* pm_last_error(void) { return g_last_error.c_str(); }
 
 int pm_set_tuning(int32_t unroll, int32_t bags_per_block, int32_t xcd_affine, int32_t nt_loads) {
-    if (unroll != 0 && unroll != 2 && unroll != 4 && unroll != 8)
-        return fail(PM_ERR_INVALID, "unroll must be 0, 2, 4 or 8");
+    if (unroll != 0 && unroll != 1 && unroll != 2 && unroll != 3 && unroll != 4 && unroll != 6 && unroll != 8)
+        return fail(PM_ERR_INVALID, "unroll must be 0, 1, 2, 3, 4, 6 or 8");
     if (bags_per_block < 0) return fail(PM_ERR_INVALID, "bags_per_block must be >= 0");
     g_unroll.store(unroll);
     g_bags_per_block.store(bags_per_block);
@@ -297,7 +302,7 @@ int pm_embbag_fwd(const pm_embbag_batch* op, float* out, pm_stream_t stream) {
     if (!out) return fail(PM_ERR_INVALID, "out is NULL");
     p.io = out;
     int unroll = g_unroll.load();
-    if (unroll == 0) unroll = 4;  // sweep r1a: 4 rows in flight/lane at 8 waves/SIMD beats 8 at 5 waves
+    if (unroll == 0) unroll = kDefaultUnroll;
     hipError_t h = pm::launch_embbag_fwd(p, op->weight_dtype, op->max_dim, unroll, static_cast<hipStream_t>(stream));
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_fwd launch");
     return PM_OK;
@@ -318,7 +323,7 @@ int pm_embbag_fwd_quantized(const pm_embbag_batch* op, void* out, int32_t bitwid
     p.io = static_cast<float*>(out);
     p.out_bits = bitwidth;
     int unroll = g_unroll.load();
-    if (unroll == 0) unroll = 4;
+    if (unroll == 0) unroll = kDefaultUnroll;
     hipError_t h = pm::launch_embbag_fwd(p, op->weight_dtype, op->max_dim, unroll, static_cast<hipStream_t>(stream));
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_fwd_quantized launch");
     return PM_OK;

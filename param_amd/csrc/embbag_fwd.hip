@@ -19,6 +19,8 @@
 //   * output rows are written with non-temporal 16-byte stores (never re-read by this kernel);
 //   * blockIdx -> (table, tile) can be XCD-affine (common.h) so a table's hot rows stay in
 //     one XCD's L2 under Zipf-skewed indices.
+#include <type_traits>
+
 #include "common.h"
 #include "rowquant.inc"
 
@@ -202,72 +204,81 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
         const int64_t e = s_off[bg + 1];
         float* orow = out_t + (bag0 + bg) * p.out_stride;
 
-        for (int c = lig * VEC; c < D; c += G * VEC) {
-            const char* Wc = W + static_cast<int64_t>(c) * ES;
-            float acc[VEC];
+        // The pooling loop is instantiated twice, for indices staged in LDS and for indices read from the request: with the
+        // choice made per lookup (`staged ? s_idx[..] : load_index(..)`) both paths meet in front of every row load, and the
+        // `s_waitcnt vmcnt(0)` the global-index path needs there made the staged path wait for its PREVIOUS ROW LOAD as well --
+        // one row in flight per lane group instead of UNROLL.
+        auto pool = [&](auto staged_c) {
+            constexpr bool ST = decltype(staged_c)::value;
+            for (int c = lig * VEC; c < D; c += G * VEC) {
+                const char* Wc = W + static_cast<int64_t>(c) * ES;
+                float acc[VEC];
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+                for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
 
-            int64_t j = s;
-            // full batches: UNROLL independent row loads in flight, then ordered adds
-            for (; j + UNROLL <= e; j += UNROLL) {
-                u32x4 raw[UNROLL];
-                float w[UNROLL];
+                int64_t j = s;
+                // full batches: UNROLL independent row loads in flight (all indices first, then all rows), then ordered adds
+                for (; j + UNROLL <= e; j += UNROLL) {
+                    u32x4 raw[UNROLL];
+                    float w[UNROLL];
+                    int64_t r[UNROLL];
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                    const int64_t jj = j + u;
-                    const int64_t r = staged ? static_cast<int64_t>(s_idx[jj - base])
-                                             : load_index(p.indices, jj, p.idx64);
-                    if (WEIGHTED) w[u] = staged ? s_w[jj - base] : as_global<float>(p.psw)[jj];
-                    raw[u] = load16(Wc + r * row_bytes, nt);
-                }
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                    float f[VEC];
-                    Elem<WT>::widen(raw[u], f);
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) acc[k] = WEIGHTED ? fmaf(w[u], f[k], acc[k]) : acc[k] + f[k];
-                }
-            }
-            // tail (< UNROLL lookups): exec-masked loads, same order
-            if (j < e) {
-                u32x4 raw[UNROLL];
-                float w[UNROLL];
-#pragma unroll
-                for (int u = 0; u < UNROLL - 1; ++u) {
-                    const int64_t jj = j + u;
-                    if (jj < e) {
-                        const int64_t r = staged ? static_cast<int64_t>(s_idx[jj - base])
-                                                 : load_index(p.indices, jj, p.idx64);
-                        if (WEIGHTED) w[u] = staged ? s_w[jj - base] : as_global<float>(p.psw)[jj];
-                        raw[u] = load16(Wc + r * row_bytes, nt);
+                    for (int u = 0; u < UNROLL; ++u) {
+                        const int64_t jj = j + u;
+                        r[u] = ST ? static_cast<int64_t>(s_idx[jj - base]) : load_index(p.indices, jj, p.idx64);
+                        if (WEIGHTED) w[u] = ST ? s_w[jj - base] : as_global<float>(p.psw)[jj];
                     }
-                }
 #pragma unroll
-                for (int u = 0; u < UNROLL - 1; ++u) {
-                    if (j + u < e) {
+                    for (int u = 0; u < UNROLL; ++u) raw[u] = load16(Wc + r[u] * row_bytes, nt);
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u) {
                         float f[VEC];
                         Elem<WT>::widen(raw[u], f);
 #pragma unroll
                         for (int k = 0; k < VEC; ++k) acc[k] = WEIGHTED ? fmaf(w[u], f[k], acc[k]) : acc[k] + f[k];
                     }
                 }
-            }
+                // tail (< UNROLL lookups): straight-line loads (positions past the bag read its last lookup again and are
+                // dropped), same order of additions
+                if (j < e) {
+                    u32x4 raw[UNROLL];
+                    float w[UNROLL];
+                    int64_t r[UNROLL];
+#pragma unroll
+                    for (int u = 0; u < UNROLL - 1; ++u) {
+                        const int64_t jj = j + u < e ? j + u : e - 1;
+                        r[u] = ST ? static_cast<int64_t>(s_idx[jj - base]) : load_index(p.indices, jj, p.idx64);
+                        if (WEIGHTED) w[u] = ST ? s_w[jj - base] : as_global<float>(p.psw)[jj];
+                    }
+#pragma unroll
+                    for (int u = 0; u < UNROLL - 1; ++u) raw[u] = load16(Wc + r[u] * row_bytes, nt);
+#pragma unroll
+                    for (int u = 0; u < UNROLL - 1; ++u) {
+                        if (j + u < e) {
+                            float f[VEC];
+                            Elem<WT>::widen(raw[u], f);
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) acc[k] = WEIGHTED ? fmaf(w[u], f[k], acc[k]) : acc[k] + f[k];
+                        }
+                    }
+                }
 
-            if (STAGE && stage) {
-                f32x4* o4 = reinterpret_cast<f32x4*>(s_out + static_cast<size_t>(bg) * D + c);
+                if (STAGE && stage) {
+                    f32x4* o4 = reinterpret_cast<f32x4*>(s_out + static_cast<size_t>(bg) * D + c);
 #pragma unroll
-                for (int k = 0; k < VEC; k += 4) o4[k / 4] = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
-            } else {
-                // streaming stores: the pooled row is consumed by another kernel / the all-to-all
-                f32x4* o4 = reinterpret_cast<f32x4*>(orow + c);
+                    for (int k = 0; k < VEC; k += 4) o4[k / 4] = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+                } else {
+                    // streaming stores: the pooled row is consumed by another kernel / the all-to-all
+                    f32x4* o4 = reinterpret_cast<f32x4*>(orow + c);
 #pragma unroll
-                for (int k = 0; k < VEC; k += 4) {
-                    f32x4 v = {acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
-                    __builtin_nontemporal_store(v, o4 + k / 4);
+                    for (int k = 0; k < VEC; k += 4) {
+                        f32x4 v = {acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+                        __builtin_nontemporal_store(v, o4 + k / 4);
+                    }
                 }
             }
-        }
+        };
+        if (staged) pool(std::true_type{}); else pool(std::false_type{});
         // next bag: one LDS atomic per bag, broadcast inside the group.  Which group pools which bag does not
         // change any result (a bag is pooled by exactly one group, in index order), only the balance.
         int nxt = 0;
@@ -307,8 +318,11 @@ hipError_t launch_w(const KParams& p, hipStream_t stream) {
 template <typename WT, int G>
 hipError_t launch_u(const KParams& p, int unroll, hipStream_t stream) {
     switch (unroll) {
+        case 1: return launch_w<WT, G, 1>(p, stream);
         case 2: return launch_w<WT, G, 2>(p, stream);
+        case 3: return launch_w<WT, G, 3>(p, stream);
         case 4: return launch_w<WT, G, 4>(p, stream);
+        case 6: return launch_w<WT, G, 6>(p, stream);
         default: return launch_w<WT, G, 8>(p, stream);
     }
 }
