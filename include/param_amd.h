@@ -269,7 +269,7 @@ int pm_fill_random(void* dst, int64_t count, int32_t dtype, int32_t dist, float 
 
 /*
  * Tuning knobs of the forward/backward launch (process-wide, mainly for bench
- * sweeps): unroll = rows in flight per lane group (1,2,4,8; 0 = default),
+ * sweeps): unroll = rows in flight per lane group (1,2,3,4,6,8; 0 = default = 2),
  * bags_per_block (0 = default), xcd_affine = 1 maps table t to XCD t%8 when
  * num_tables%8==0 (keeps each table's hot rows in one L2), -1 = default.  nt_loads: forward -- any value > 0 = non-temporal
  * row loads; sorted backward -- cache policy of the destination-row accesses: 0 plain, 1 non-temporal, 2 system scope,

@@ -106,14 +106,15 @@ struct SortWs {
 
 // chunks of the apply kernels: kSortTile / (kBlock / G) positions each; sized for the smallest
 // chunk any destination dtype can select for this max_dim (16-bit destinations: 8 elements/lane)
-// sorted positions per workgroup of the apply kernels.  1024 for large requests (2048: main +53 us, fix-up -28 us, round 1);
-// small requests get smaller tiles: the chip holds 1280 apply workgroups at a time (5 per CU), and a request of 1713 tiles
-// (the Criteo step: 1.75 M lookups) is one full wave of workgroups plus a third of one -- its apply took as long as two
-// waves.  PARAM_AMD_BWD_TILE overrides (256 / 512 / 1024).
+// sorted positions per workgroup of the apply kernels: 512 (256 below 768 K lookups, where 512 would leave CUs idle).  Measured
+// with the kernels' load batches real and tile windows that keep short runs whole (round 3, visit v49; apply ms uniform / Zipf
+// on 48 x 10 M x 128 fp32, Criteo backward us Zipf / uniform):  256: 1.452 / 0.945, 426 / 488;  512: 1.468 / 0.835, 403 / 470;
+// 1024: 1.496 / 0.815, 394 / 481.  Smaller tiles balance the tail of a launch better; larger ones cut a long run (a Zipf head,
+// a 3-row table) into fewer pieces for the fix-up kernel.  PARAM_AMD_BWD_TILE overrides (256 / 512 / 1024).
 inline int apply_tile(int64_t n) {
     static const int env = [] { const char* e = getenv("PARAM_AMD_BWD_TILE"); return e ? atoi(e) : 0; }();
     if (env == 256 || env == 512 || env == 1024) return env;
-    return n < (static_cast<int64_t>(3) << 20) ? 256 : n < (static_cast<int64_t>(6) << 20) ? 512 : kSortTile;
+    return n < (static_cast<int64_t>(3) << 18) ? 256 : 512;
 }
 
 inline int64_t max_chunks(int64_t n, int max_dim) {

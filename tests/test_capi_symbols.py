@@ -53,7 +53,7 @@ def test_argument_validation_without_gpu():
     op.index_dtype, op.batch, op.bag_begin, op.bag_count = _lib.PM_I64, 4, 2, 3
     assert L.pm_embbag_fwd(ctypes.byref(op), None, None) == _lib.PM_ERR_INVALID
     assert b"bag_begin" in L.pm_last_error()
-    assert L.pm_set_tuning(3, 0, -1, -1) == _lib.PM_ERR_INVALID
+    assert L.pm_set_tuning(5, 0, -1, -1) == _lib.PM_ERR_INVALID
     assert L.pm_set_tuning(0, 0, -1, -1) == _lib.PM_OK
     assert L.pm_set_backward_tuning(3, 0, 0, -1) == _lib.PM_ERR_INVALID and L.pm_set_sort_tuning(4) == _lib.PM_ERR_INVALID and L.pm_set_sort_tuning(-1) == _lib.PM_OK and L.pm_set_backward_tuning(-1, -1, -1, -1) == _lib.PM_OK
     in_b = ctypes.c_int32(-1)
