@@ -284,3 +284,63 @@ def test_offsets_refilled_in_place_are_looked_at_again(coracle):
                                       np.ascontiguousarray(grad[:, t * D:(t + 1) * D]))
                 assert np.array_equal(dws[t].cpu().numpy(), exp), (impl, step, t)
     param_amd.set_backward_tuning()
+
+
+@pytest.mark.parametrize("hot_frac", [0.0, 0.6])
+def test_one_table_a_thousand_tiles_deep_lookback(hot_frac):
+    """ONE segment of ~1000 radix tiles (4 M lookups of one table): every tile's walk over its predecessors' status rows is as
+    deep as the look-back form gets (all tiles start together); with `hot_frac` most pairs share a handful of rows -- one digit
+    bucket holds most of every tile.  Sorted pairs element for element against numpy's stable order, modes 0 and 3."""
+    import param_amd
+    from param_amd import BatchedEmbeddingBagMI355
+
+    rng = np.random.default_rng(41 + int(hot_frac * 10))
+    rows, B, L = [3_000_000, 77], 1 << 17, 31           # table 0: 4 063 232 lookups = 992 tiles; table 1: the same count, 7 row bits
+    hot = [(hot_frac, np.array([0, 1, 255, 256, 65535, 65536, 2_999_999])), None] if hot_frac > 0 else None
+    idx, off = _request(rng, rows, B, lambda t: np.full(B, L), hot=hot)
+    m = BatchedEmbeddingBagMI355(rows, 4, device=DEV, init=None, fused_update=False)
+    it, ot = torch.from_numpy(idx).to(DEV), torch.from_numpy(off).to(DEV)
+    for mode in (0, 3):
+        param_amd.set_sort_tuning(mode)
+        k, v, tshift = _sorted(m, it, ot, B)
+        ek, ev = _expected(idx, off, len(rows), B, mode, tshift)
+        assert np.array_equal(k, ek), (mode, int(np.argmax(k != ek)))
+        assert np.array_equal(v, ev), (mode, int(np.argmax(v != ev)))
+    param_amd.set_sort_tuning()
+
+
+def test_one_sort_applied_three_times_with_runs_to_mend(coracle):
+    """the apply's work list of runs for the fix-up kernel is emptied on the device between launches (two counters in turn, no
+    host state): ONE sort, THREE applies of a request full of long runs (rows looked up thousands of times, runs across every
+    tile border) must equal three sequential applies of the oracle on rows with <= 256 lookups, 1e-5 of an fp64 sum beyond"""
+    from param_amd import BatchedEmbeddingBagMI355
+
+    rng = np.random.default_rng(8)
+    rows, B, L, D = [3, 40, 20000, 1_000_000], 2048, 24, 32
+    T = len(rows)
+    hot = [None, None, (0.5, np.array([7, 8, 19999])), (0.3, np.array([0, 999_999]))]
+    idx, off = _request(rng, rows, B, lambda t: np.full(B, L), hot=hot)
+    m = BatchedEmbeddingBagMI355(rows, D, device=DEV, init="normal", seed=5, fused_update=False)
+    it, ot = torch.from_numpy(idx).to(DEV), torch.from_numpy(off).to(DEV)
+    grads = [rng.standard_normal((B, T * D)).astype(np.float32) for _ in range(3)]
+    W0 = [m.table(t).cpu().numpy().copy() for t in range(T)]
+    m.sort_indices(it, ot, batch=B)
+    for g in grads:
+        m.scatter_add_(torch.from_numpy(g).to(DEV), it, ot, alpha=-0.125, batch=B, presorted=True)
+    for t in range(T):
+        s, e = int(off[t * B]), int(off[(t + 1) * B])
+        loc = off[t * B:(t + 1) * B] - s
+        exp = W0[t].copy()
+        truth, mag = W0[t].astype(np.float64), np.abs(W0[t]).astype(np.float64)
+        for g in grads:
+            gt = np.ascontiguousarray(g[:, t * D:(t + 1) * D])
+            exp = coracle.bwd_f32(exp, idx[s:e], loc, gt, None, alpha=-0.125)
+            contrib = -0.125 * gt.astype(np.float64)[np.repeat(np.arange(B), L)]
+            np.add.at(truth, idx[s:e], contrib)
+            np.add.at(mag, idx[s:e], np.abs(contrib))
+        got = m.table(t).cpu().numpy()
+        cnt = np.bincount(idx[s:e], minlength=rows[t])
+        cold = cnt <= 256
+        assert np.array_equal(got[cold], exp[cold]), t
+        tol = np.maximum(1e-5, 3 * (256 + cnt[:, None] / 32) * 2.0 ** -24) * mag + 1e-30
+        assert (np.abs(got - truth) <= tol).all(), t
