@@ -133,6 +133,8 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
     p.out_bits = 0;
     p.stage_out = 0;
     p.stage_bags = 0;
+    p.flat_bags = 0;
+    p.flat_target = 0;
     if (forward) {
         int want = g_stage_out.load();
         if (want < 0) {
@@ -165,6 +167,20 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
             p.stage_out = op->max_dim;
         }
         p.stage_bags = p.bags_per_block;
+        // ... and those requests run the flat-walk kernel (embbag_fwd.hip): tiles sized per table on the device (~256 lookups, up
+        // to 32 bags for the pooling-1 tables), row loads in flight across bag borders.  tiles_per_table stays the count of the
+        // smallest tile (one bag per lane group): workgroups past their table's tile count leave.  Criteo tables, visit
+        // r3_criteo_flat (Zipf G lookups/s / uniform fraction; run-to-run +-1.5 %): 8-bag tiles 15.7-15.9 / 0.69-0.71; flat walk
+        // target 512 cap 64: 16.4-16.5 / 0.705-0.716; **256 / 32: 16.6 / 0.719**; 128: 16.1 / 0.695; 1024 / 128: 14.1 / 0.64.
+        // PARAM_AMD_FWD_FLAT=0 turns it off (PARAM_AMD_FLAT_TARGET / _BAGS: sweeps).
+        static const bool flat_on = [] { const char* e = getenv("PARAM_AMD_FWD_FLAT"); return !(e && e[0] == '0'); }();
+        if (flat_on && !even && !p.ordered && g_bags_per_block.load() <= 0 && bpb == NG && p.stage_out > 0) {
+            static const int cap_env = [] { const char* e = getenv("PARAM_AMD_FLAT_BAGS"); return e ? atoi(e) : 32; }();
+            static const int tgt_env = [] { const char* e = getenv("PARAM_AMD_FLAT_TARGET"); return e ? atoi(e) : 256; }();
+            p.flat_bags = cap_env < NG ? NG : (cap_env > 1024 ? 1024 : cap_env / NG * NG);
+            p.flat_target = tgt_env < 1 ? 1 : tgt_env;
+            p.bags_per_block = p.flat_bags;   // sizes the LDS offsets array; stage_bags (the burst buffer) stays at NG rows
+        }
         // Two tilings built and measured in round 3 for requests whose tables have very different pooling factors (Criteo
         // multi-hot 1 .. 100) -- both slower than the 8-bag tiles in table-major order, which stay:
         //  * WORK tiles (~640 lookups per tile whatever the pooling factor, tile boundaries derived on the device from the
@@ -317,6 +333,10 @@ int pm_embbag_fwd_quantized(const pm_embbag_batch* op, void* out, int32_t bitwid
     if (p.bag_count == 0) return PM_OK;
     if (!out) return fail(PM_ERR_INVALID, "out is NULL");
     if (reinterpret_cast<uintptr_t>(out) % 16 != 0) return fail(PM_ERR_INVALID, "out must be 16-byte aligned");
+    if (p.flat_bags > 0) {   // the quantised burst lives in the bag-per-group kernel: back to its 8-bag tiles
+        p.bags_per_block = p.stage_bags;
+        p.flat_bags = 0;
+    }
     if (!p.stage_out)
         return fail(PM_ERR_UNSUPPORTED, "quantised output needs the staged forward (fixed-pooling requests whose tile fits the staging "
                                         "buffer, staging not disabled): run pm_embbag_fwd and pm_rows_quantize instead");

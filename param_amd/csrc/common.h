@@ -54,6 +54,9 @@ struct KParams {
     int32_t stage_out;           // forward: > 0 = collect the tile's pooled rows in LDS (this many floats per row), write at tile end
     int32_t stage_bags;          // forward: rows the staging buffer holds (tiles with more bags write row by row)
     int32_t out_bits;            // forward: 0 = fp32 output; 16 / 8 / 4 / 2 = io holds row-wise quantised rows (rowquant.hip), staged only
+    int32_t flat_bags;           // forward: > 0 = the flat-walk kernel (short-bag requests): bags per tile derived per table on the
+                                 // device, at most this many (= bags_per_block, which sizes the LDS offsets array)
+    int32_t flat_target;         // ... lookups per tile aimed at
     float alpha;                 // bwd scale
 };
 

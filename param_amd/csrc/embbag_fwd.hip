@@ -300,11 +300,137 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Flat-walk forward for requests of SHORT bags whose tables differ in pooling factor (Criteo multi-hot 1 .. 100, average 8):
+//   * the tile is sized PER TABLE, on the device: every workgroup reads the two offsets that bound its table's slice, takes the
+//     table's average bag length from them and cuts the table into tiles of ~flat_target (256) lookups (NG .. flat_bags bags, a
+//     multiple of NG); the launch has the grid of the smallest tile, workgroups past a table's tile count leave after that one
+//     round trip.  With 8-bag tiles for every table (what this replaces) the twelve pooling-1 Criteo tables were a quarter of
+//     the launch's workgroup-slot time for 5.6 % of its lookups: three round trips of set-up per eight row loads.
+//   * a lane group owns a contiguous run of the tile's bags and walks their lookups as ONE sequence, UNROLL row loads in flight
+//     ACROSS bag borders (a pooling-1 bag is one load: bag by bag, a group would have one load in flight); a bag's sum leaves
+//     when the walk passes its end.  Additions happen in index order inside every bag, from zero: same bits as the other kernel.
+
+template <typename WT, int G, int UNROLL, bool WEIGHTED>
+__global__ void __launch_bounds__(kBlock) embbag_fwd_flat_kernel(const KParams p) {
+    constexpr int VEC = Elem<WT>::kVec;
+    constexpr int NG = kBlock / G;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = blockIdx.x / p.tiles_per_table;
+    const int tile = blockIdx.x % p.tiles_per_table;
+    if (t >= p.T) return;
+    const int64_t g0 = static_cast<int64_t>(t) * p.B + p.bag_begin;
+    const int64_t lo = bag_start_or_end(p, g0), hi = bag_start_or_end(p, g0 + p.bag_count);
+    const int64_t avg = p.bag_count > 0 ? (hi - lo + p.bag_count - 1) / p.bag_count : 1;
+    int bags = static_cast<int>(p.flat_target / (avg > 0 ? avg : 1));
+    bags = bags > p.flat_bags ? p.flat_bags : bags;
+    bags = bags / NG * NG;
+    if (bags < NG) bags = NG;
+    const int64_t bag0 = p.bag_begin + static_cast<int64_t>(tile) * bags;
+    const int64_t left_bags = p.bag_begin + p.bag_count - bag0;
+    if (left_bags <= 0) return;
+    const int nb = left_bags < bags ? static_cast<int>(left_bags) : bags;
+
+    int64_t* s_off;
+    int32_t* s_idx;
+    float* s_w;
+    const bool staged = stage_tile_at<WEIGHTED>(p, t, bag0, nb, smem, s_off, s_idx, s_w);
+    const int64_t base = s_off[0];
+    const int gid = threadIdx.x / G;
+    const int lig = threadIdx.x % G;
+    const int D = p.dims[t];
+    constexpr int ES = 16 / VEC;
+    const int64_t row_bytes = static_cast<int64_t>(D) * ES;
+    const char* W = reinterpret_cast<const char*>(p.tables[t]);
+    float* out_t = p.io + p.out_offsets[t];
+    const bool nt = p.nt_loads != 0;
+    float* s_out = reinterpret_cast<float*>(smem + tile_lds_bytes(p.bags_per_block, p.idx_cap, WEIGHTED));
+    const bool stage = p.stage_out > 0 && nb <= p.stage_bags;      // small tiles (long bags) leave in one burst, like the other kernel
+    const int per = (nb + NG - 1) / NG;
+    const int b_lo = gid * per;
+    const int b_hi = b_lo + per < nb ? b_lo + per : nb;
+
+    auto walk = [&](auto staged_c) {
+        constexpr bool ST = decltype(staged_c)::value;
+        for (int c = lig * VEC; c < D; c += G * VEC) {
+            const char* Wc = W + static_cast<int64_t>(c) * ES;
+            float acc[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+            auto emit = [&](int bg) {                       // the finished sum of bag bg leaves, the accumulator starts over
+                if (stage) {
+                    f32x4* o4 = reinterpret_cast<f32x4*>(s_out + static_cast<size_t>(bg) * D + c);
+#pragma unroll
+                    for (int k = 0; k < VEC; k += 4) o4[k / 4] = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+                } else {
+                    f32x4* o4 = reinterpret_cast<f32x4*>(out_t + (bag0 + bg) * p.out_stride + c);
+#pragma unroll
+                    for (int k = 0; k < VEC; k += 4) {
+                        f32x4 v = {acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+                        __builtin_nontemporal_store(v, o4 + k / 4);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+            };
+            int cur = b_lo;
+            int64_t cur_end = s_off[cur + 1];
+            const int64_t e = s_off[b_hi];
+            for (int64_t j = s_off[b_lo]; j < e; j += UNROLL) {
+                u32x4 raw[UNROLL];
+                float w[UNROLL];
+                int64_t r[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {           // straight-line: positions past the run read its last lookup again
+                    const int64_t jj = j + u < e ? j + u : e - 1;
+                    r[u] = ST ? static_cast<int64_t>(s_idx[jj - base]) : load_index(p.indices, jj, p.idx64);
+                    if (WEIGHTED) w[u] = ST ? s_w[jj - base] : as_global<float>(p.psw)[jj];
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) raw[u] = load16(Wc + r[u] * row_bytes, nt);
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    if (j + u < e) {
+                        while (j + u >= cur_end) {           // the walk passed the end of bag `cur` (and of any empty bags after it)
+                            emit(cur);
+                            ++cur;
+                            cur_end = s_off[cur + 1];
+                        }
+                        float f[VEC];
+                        Elem<WT>::widen(raw[u], f);
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) acc[k] = WEIGHTED ? fmaf(w[u], f[k], acc[k]) : acc[k] + f[k];
+                    }
+                }
+            }
+            for (; cur < b_hi; ++cur) emit(cur);            // the last bag walked, then the empty ones behind it (zeros)
+        }
+    };
+    if (b_lo < b_hi) {
+        if (staged) walk(std::true_type{}); else walk(std::false_type{});
+    }
+    if (stage) {
+        __syncthreads();
+        const int q = D / 4;
+        for (int i = threadIdx.x; i < nb * q; i += kBlock) {
+            const int bg = i / q, c4 = i % q;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(s_out + static_cast<size_t>(bg) * D + c4 * 4);
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out_t + (bag0 + bg) * p.out_stride + c4 * 4));
+        }
+    }
+}
+
 template <typename WT, int G, int UNROLL>
 hipError_t launch_w(const KParams& p, hipStream_t stream) {
     const bool weighted = p.psw != nullptr;
     const int grid = p.T * p.tiles_per_table;
     size_t lds = tile_lds_bytes(p.bags_per_block, p.idx_cap, weighted);
+    if (p.flat_bags > 0) {   // short-bag requests with per-table pooling (capi.hip decides)
+        lds += static_cast<size_t>(p.stage_bags) * p.stage_out * sizeof(float);
+        if (weighted) hipLaunchKernelGGL((embbag_fwd_flat_kernel<WT, G, UNROLL, true>), dim3(grid), dim3(kBlock), lds, stream, p);
+        else hipLaunchKernelGGL((embbag_fwd_flat_kernel<WT, G, UNROLL, false>), dim3(grid), dim3(kBlock), lds, stream, p);
+        return hipGetLastError();
+    }
 #define PM_FWD(W_, O_, S_) hipLaunchKernelGGL((embbag_fwd_kernel<WT, G, UNROLL, W_, O_, S_>), dim3(grid), dim3(kBlock), lds, stream, p)
     if (p.stage_out && !p.ordered) {   // fixed-pooling requests (capi.hip decides)
         lds += static_cast<size_t>(p.bags_per_block) * p.stage_out * sizeof(float);   // stage_out = widest row (elements)
