@@ -173,7 +173,23 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
         // r3_criteo_flat (Zipf G lookups/s / uniform fraction; run-to-run +-1.5 %): 8-bag tiles 15.7-15.9 / 0.69-0.71; flat walk
         // target 512 cap 64: 16.4-16.5 / 0.705-0.716; **256 / 32: 16.6 / 0.719**; 128: 16.1 / 0.695; 1024 / 128: 14.1 / 0.64.
         // PARAM_AMD_FWD_FLAT=0 turns it off (PARAM_AMD_FLAT_TARGET / _BAGS: sweeps).
-        static const bool flat_on = [] { const char* e = getenv("PARAM_AMD_FWD_FLAT"); return !(e && e[0] == '0'); }();
+        static const int flat_env = [] { const char* e = getenv("PARAM_AMD_FWD_FLAT"); return e ? atoi(e) : 1; }();
+        const bool flat_on = flat_env != 0;
+        // ... and so do fixed-pooling requests of one or two lookups per bag (one-hot tables): bag by bag a lane group has one or
+        // two row loads in flight.  48 x 10 M x 128 fp32, batch 65536 (tools/r3_shortbags.sh; Zipf G lookups/s / uniform fraction):
+        // pooling 1: 4.00 / 0.529 -> 5.05 / 0.624; pooling 2: 7.78 / 0.687 -> 8.75 / 0.686; pooling 4: 13.5 / 0.723 -> 13.4 / 0.679
+        // (not taken; PARAM_AMD_FWD_FLAT=2 extends the rule to 4 for that measurement).
+        if (flat_on && even && avg_l <= (flat_env == 2 ? 4 : 2) && !p.ordered && g_bags_per_block.load() <= 0 && p.stage_out > 0) {
+            const int64_t tiles_ng = (op->bag_count + NG - 1) / NG;
+            if (tiles_ng * op->num_tables <= 0x7fffffffLL) {
+                p.flat_bags = 32;
+                p.flat_target = 256;
+                p.tiles_per_table = static_cast<int32_t>(tiles_ng);
+                p.stage_bags = NG;
+                p.bags_per_block = p.flat_bags;
+                if (p.idx_cap < 1024) p.idx_cap = 1024;
+            }
+        }
         if (flat_on && !even && !p.ordered && g_bags_per_block.load() <= 0 && bpb == NG && p.stage_out > 0) {
             static const int cap_env = [] { const char* e = getenv("PARAM_AMD_FLAT_BAGS"); return e ? atoi(e) : 32; }();
             static const int tgt_env = [] { const char* e = getenv("PARAM_AMD_FLAT_TARGET"); return e ? atoi(e) : 256; }();
