@@ -179,11 +179,14 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
         // two row loads in flight.  48 x 10 M x 128 fp32, batch 65536 (tools/r3_shortbags.sh; Zipf G lookups/s / uniform fraction):
         // pooling 1: 4.00 / 0.529 -> 5.05 / 0.624; pooling 2: 7.78 / 0.687 -> 8.75 / 0.686; pooling 4: 13.5 / 0.723 -> 13.4 / 0.679
         // (not taken; PARAM_AMD_FWD_FLAT=2 extends the rule to 4 for that measurement).
-        if (flat_on && even && avg_l <= (flat_env == 2 ? 4 : 2) && !p.ordered && g_bags_per_block.load() <= 0 && p.stage_out > 0) {
+        static const int flat_maxl = [] { const char* e = getenv("PARAM_AMD_FLAT_MAXL"); return e ? atoi(e) : 0; }();   // experiments
+        if (flat_on && even && avg_l <= (flat_maxl > 0 ? flat_maxl : flat_env == 2 ? 4 : 2) && !p.ordered && g_bags_per_block.load() <= 0 &&
+            p.stage_out > 0) {
             const int64_t tiles_ng = (op->bag_count + NG - 1) / NG;
             if (tiles_ng * op->num_tables <= 0x7fffffffLL) {
+                static const int tgt2 = [] { const char* e = getenv("PARAM_AMD_FLAT_TARGET"); return e ? atoi(e) : 256; }();
                 p.flat_bags = 32;
-                p.flat_target = 256;
+                p.flat_target = tgt2;
                 p.tiles_per_table = static_cast<int32_t>(tiles_ng);
                 p.stage_bags = NG;
                 p.bags_per_block = p.flat_bags;
