@@ -9,22 +9,29 @@
 // train/comms/pt/pytorch_dist_backend.py:854-857, train/compute/python/workloads/pytorch/
 // split_table_batched_embeddings_ops.py:318-324); request layout :93-135,191-208.
 //
-// Kernels (gfx950, no inter-workgroup communication inside a kernel -- kernel boundaries are the only synchronisation, as
-// in radix_sort.hip):
+// Kernels (gfx950):
 //   seg_prep_tables_kernel   one workgroup per table: segment start / count from the offsets, pooling factor if every bag
 //                            of the (sliced) table has the same length, key bits of the table from rows[t]
 //   seg_prep_scan_kernel     workgroup 0: output start and first tile of every segment, one 32-byte descriptor per tile; the
 //                            other workgroups, only for tables WITHOUT a pooling factor (ragged, weighted): (key, bag) per
 //                            lookup at request positions (binary search over LDS-staged offsets) -- they exit at once otherwise
-//   seg_hist / seg_scan / seg_scatter   one radix pass over 4096-element tiles: per-tile digit counts, per-segment
-//                            exclusive prefix (+ absolute bucket starts), stable scatter
+//   MODE 0 (default), one kernel per pass:
+//   seg_hist_all_kernel      digit counts of ALL passes of every 4096-element tile from one read of the request
+//   seg_scan_all_kernel      grid tables x passes: the tables' bucket starts of every pass
+//   seg_lookback_pass_kernel a pass: count, publish the tile's digit counts, walk back over the predecessors' published
+//                            counts (the only inter-workgroup communication in this file: 16-byte sc1 status rows, a tile waits
+//                            for tiles of lower index only), stable scatter
+//   MODE 3 (the same order, kernel boundaries as the only synchronisation, as in radix_sort.hip; also the second level of 1 / 2):
+//   seg_hist / seg_scan / seg_scatter   one radix pass: per-tile digit counts, per-segment exclusive prefix (+ absolute
+//                            bucket starts), stable scatter
 //   MODE 1 / 2 (one global partition pass, then buckets):
 //   seg_local_kernel         every (table, digit) bucket of up to 4096 pairs is sorted by its remaining key bits inside LDS:
 //                            up to 1024 pairs by ONE WAVE (four buckets per workgroup, no workgroup barrier), up to 4096 by
 //                            the workgroup; larger buckets were put on a list by the scan kernel ...
 //   seg_l2_prep_kernel + the pass kernels again   ... and become the segments of a second-level LSD sort over their
 //                            remaining bits (persistent grids: a request without such buckets pays a few empty launches)
-// MODE 0 runs ceil(rbits / 8) global LSD passes (ascending (table, row, position) order, like round 2's segmented sort);
+// MODE 0 / 3 run ceil(rbits / 8) global LSD passes -- ceil(rbits / 9) with 9-bit digits where that is one pass fewer --
+//        (ascending (table, row, position) order, like round 2's segmented sort);
 // MODE 1 partitions on the LOW row digit (order (table, row & 255, row >> 8, position): buckets balanced under any skew, but
 //        neighbours in the sorted array are not neighbours in the table -- the apply kernel pays for that under skew);
 // MODE 2 partitions on the TOP row digit (ascending order; a skewed head makes its bucket a second-level segment).
