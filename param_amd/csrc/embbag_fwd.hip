@@ -13,7 +13,10 @@
 //     slice of the fp32 accumulator in registers and issues one global_load_dwordx4 per
 //     lookup, so a wave64 reads 64/G whole rows per instruction, fully coalesced;
 //   * UNROLL independent row loads are issued back to back before the first add
-//     (memory-level parallelism: UNROLL KiB in flight per wave at G=32/64);
+//     (memory-level parallelism: UNROLL KiB in flight per wave at G=32/64; default 2, measured -- the pooling loop is
+//     instantiated per index source so that no wait of one path serialises the other);
+//   * short-bag requests (per-table pooling such as Criteo's, one-hot tables) run embbag_fwd_flat_kernel below: tiles sized
+//     per table on the device, row loads in flight across bag borders;
 //   * adds happen in index order per lane => the pooled fp32 result is bit-identical to a
 //     sequential sum (and to torch's CPU kernel); no cross-lane reduction is needed;
 //   * output rows are written with non-temporal 16-byte stores (never re-read by this kernel);
