@@ -111,16 +111,24 @@ __device__ __forceinline__ void local_bits(int mode, int rbits, int& lo, int& hi
     if (hi < lo) hi = lo;
 }
 
+// The lanes of the wave that hold the same NB-bit digit as this lane (gfx9 has no match instruction: one ballot per bit).
+// Returns, for a valid lane, how many lower lanes share its digit (`below`) and how many lanes do in all (`total`).
+// Written on 32-bit halves: per bit, the sign-extended bit (0 / -1), one compare for the ballot and m &= ~(ballot ^ bit) on
+// either half -- as 64-bit selects (`bit ? bal : ~bal`) the compiler spent ~115 vector instructions per element here, and the
+// sixteen elements of a thread made this loop half of a pass kernel's time.
 template <int NB = 8>
-__device__ __forceinline__ uint64_t match_digit8(uint32_t d, bool valid) {
-    uint64_t m = __ballot(valid);
+__device__ __forceinline__ void match_digit(uint32_t d, bool valid, uint32_t& below, uint32_t& total) {
+    const uint64_t v = __ballot(valid);
+    uint32_t mlo = static_cast<uint32_t>(v), mhi = static_cast<uint32_t>(v >> 32);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const uint64_t bal = __ballot(bit);
-        m &= bit ? bal : ~bal;
+        const int32_t bm = static_cast<int32_t>(d << (31 - b)) >> 31;        // 0 or -1: bit b of the digit
+        const uint64_t bal = __ballot(bm != 0);
+        mlo &= ~(static_cast<uint32_t>(bal) ^ static_cast<uint32_t>(bm));
+        mhi &= ~(static_cast<uint32_t>(bal >> 32) ^ static_cast<uint32_t>(bm));
     }
-    return m;
+    below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+    total = static_cast<uint32_t>(__popc(mlo) + __popc(mhi));
 }
 
 // exclusive scan of one value per thread over the 256 threads of the workgroup; s_tmp: kWaves words
@@ -525,13 +533,13 @@ __device__ __forceinline__ void tile_count_digits(const K (&key)[ITEMS], uint32_
             const uint32_t off = static_cast<uint32_t>(r) * kWave + lane;
             const bool valid = off < chunk && wave * chunk + off < cnt;
             const uint32_t d = static_cast<uint32_t>(key[r] >> shift) & mask;
-            const uint64_t m = match_digit8<RB>(d, valid);
-            const uint32_t below = static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+            uint32_t below, total;
+            match_digit<RB>(d, valid, below, total);
             const uint32_t base = valid ? wcnt[d] : 0u;
             rank[r] = base + below;
             // the lowest lane of each match set advances the digit's counter; a wave executes its LDS operations in program
             // order, so the next round's reads see it
-            if (valid && below == 0) wcnt[d] = base + static_cast<uint32_t>(__popcll(m));
+            if (valid && below == 0) wcnt[d] = base + total;
         }
     }
     __syncthreads();
@@ -1028,11 +1036,11 @@ __device__ __forceinline__ void wave_sort_bucket(K* kb, uint32_t* vb, uint32_t s
             if (static_cast<uint32_t>(r) * kWave < n) {     // wave-uniform
                 const bool valid = static_cast<uint32_t>(r) * kWave + lane < n;
                 const uint32_t d = static_cast<uint32_t>(key[r] >> shift) & mask;
-                const uint64_t m = match_digit8(d, valid);
-                const uint32_t below = static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+                uint32_t below, total;
+                match_digit<8>(d, valid, below, total);
                 const uint32_t base = valid ? wcnt[d] : 0u;
                 rank[r] = base + below;
-                if (valid && below == 0) wcnt[d] = base + static_cast<uint32_t>(__popcll(m));
+                if (valid && below == 0) wcnt[d] = base + total;
                 wave_lds_fence();
             }
         }
