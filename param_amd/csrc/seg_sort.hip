@@ -119,14 +119,16 @@ __device__ __forceinline__ void local_bits(int mode, int rbits, int& lo, int& hi
 template <int NB = 8>
 __device__ __forceinline__ void match_digit(uint32_t d, bool valid, uint32_t& below, uint32_t& total) {
     const uint64_t v = __ballot(valid);
-    uint32_t mlo = static_cast<uint32_t>(v), mhi = static_cast<uint32_t>(v >> 32);
+    uint32_t xlo = ~static_cast<uint32_t>(v), xhi = ~static_cast<uint32_t>(v >> 32);      // lanes that do NOT match, so far
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int32_t bm = static_cast<int32_t>(d << (31 - b)) >> 31;        // 0 or -1: bit b of the digit
         const uint64_t bal = __ballot(bm != 0);
-        mlo &= ~(static_cast<uint32_t>(bal) ^ static_cast<uint32_t>(bm));
-        mhi &= ~(static_cast<uint32_t>(bal >> 32) ^ static_cast<uint32_t>(bm));
+        // x |= ballot ^ bit: one three-input bit operation per half (truth table 0xF6 = a | (b ^ c))
+        xlo = __builtin_amdgcn_bitop3_b32(xlo, static_cast<uint32_t>(bal), static_cast<uint32_t>(bm), 0xF6);
+        xhi = __builtin_amdgcn_bitop3_b32(xhi, static_cast<uint32_t>(bal >> 32), static_cast<uint32_t>(bm), 0xF6);
     }
+    const uint32_t mlo = ~xlo, mhi = ~xhi;
     below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
     total = static_cast<uint32_t>(__popc(mlo) + __popc(mhi));
 }
