@@ -325,22 +325,18 @@ struct PassSrc {
     uint32_t bag_begin;
 };
 
-// one digit histogram update of a wave: the lanes that share the digit of the wave's first (then second) remaining lane add
-// ONCE, the others one LDS atomic each.  Under skew most lanes of a wave meet on one counter (the upper digits of a Zipf head:
-// 45 of 64 lanes on digit 0, served one after the other: the all-pass histogram took 40 us on the Zipf request against 23 us
-// on the uniform one); with all-distinct digits the two peels cost four ballots.
+// one digit histogram update of a wave: a wave whose keys all share the digit adds once (top digits of a skewed head, small
+// tables); else one LDS atomic per lane.  (Peeling the two most common digits of every wave first was tried against the Zipf
+// request's conflicts on hot digits: no change, the atomics are not what bounds the histogram kernel.)
 __device__ __forceinline__ void wave_hist_add(uint32_t* h, uint32_t dg, bool valid, int lane) {
-    uint64_t todo = __ballot(valid);
-#pragma unroll
-    for (int peel = 0; peel < 2; ++peel) {
-        if (todo == 0) return;                                        // wave-uniform
-        const int leader = __builtin_ctzll(todo);
-        const uint32_t d0 = __builtin_amdgcn_readlane(dg, leader);
-        const uint64_t same = __ballot(valid && dg == d0) & todo;
-        if (lane == leader) atomicAdd(&h[d0], static_cast<uint32_t>(__popcll(same)));
-        todo &= ~same;
+    const uint64_t vmask = __ballot(valid);
+    const uint32_t firstd = __builtin_amdgcn_readfirstlane(dg);
+    const bool uniform = __ballot(valid && dg != firstd) == 0 && (vmask & 1ull);
+    if (uniform) {
+        if (lane == 0) atomicAdd(&h[firstd], static_cast<uint32_t>(__popcll(vmask)));
+    } else if (valid) {
+        atomicAdd(&h[dg], 1u);
     }
-    if ((todo >> lane) & 1ull) atomicAdd(&h[dg], 1u);
 }
 
 // the row ids (or keys: their low bits are the row) of a tile for the histogram kernels: position k * 256 + thread, all loads
