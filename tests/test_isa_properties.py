@@ -50,14 +50,14 @@ def _kernel_text(bundles, symbol_prefix):
     pytest.fail("kernel not in the library: " + symbol_prefix)
 
 
-def _row_loads_between_full_waits(text):
+def _row_loads_between_full_waits(text, what="global_load_dwordx4"):
     """largest number of plain 16-byte global loads issued without an ``s_waitcnt vmcnt(0)`` in between (the wait that follows a
     system-scope ``sc0 sc1`` load belongs to that rarely taken cache-policy path and is skipped)"""
     best = cur = 0
     after_system_scope = False
     for line in text.splitlines():
         ins = line.split("//")[0]
-        if "global_load_dwordx4" in ins:
+        if what in ins:
             if "sc0 sc1" in ins:
                 after_system_scope = True
             else:
@@ -92,3 +92,11 @@ def test_apply_main_kernel_keeps_its_batch_in_flight(bundles):
     assert _row_loads_between_full_waits(text) >= 8
     text = _kernel_text(bundles, f"{NS}22bwd_sorted_main_kernelINS0_8SDstBF16EjLi16ELb0ELi0ELi512E")
     assert _row_loads_between_full_waits(text) >= 6
+
+
+def test_sort_kernels_issue_their_tile_loads_together(bundles):
+    """a tile's 16 keys + 16 values per thread (look-back pass, three-kernel scatter) and 16 rows per thread (histograms) are all
+    requested before the first is used -- written as one loop they were waited for one by one (16 latencies per workgroup)"""
+    for sym, least in ((f"{NS}24seg_lookback_pass_kernelIjLi8E", 32), (f"{NS}18seg_scatter_kernelIjLi8E", 32),
+                       (f"{NS}19seg_hist_all_kernelIjLi8E", 16), (f"{NS}15seg_hist_kernelIjLi8E", 16)):
+        assert _row_loads_between_full_waits(_kernel_text(bundles, sym), "global_load_") >= least, sym
