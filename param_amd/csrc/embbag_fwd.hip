@@ -130,6 +130,14 @@ __device__ __forceinline__ void quantized_burst(const KParams& p, const float* s
     }
 }
 
+// byte offset of row r: staged indices are int32 (rows[t] < 2^31, the caller's contract) and a row is < 2^31 bytes, so the
+// product is ONE 32 x 32 -> 64-bit multiply (v_mad_u64_u32); as int64 x int64 it is a multiply-add, two multiplies and an add
+template <bool ST>
+__device__ __forceinline__ int64_t row_offset(int64_t r, int64_t row_bytes) {
+    if (ST) return static_cast<int64_t>(static_cast<uint64_t>(static_cast<uint32_t>(r)) * static_cast<uint32_t>(row_bytes));
+    return r * row_bytes;
+}
+
 template <typename WT, int G, int UNROLL, bool WEIGHTED, bool ORDERED, bool STAGE>
 __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
     constexpr int VEC = Elem<WT>::kVec;
@@ -232,7 +240,7 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
                         if (WEIGHTED) w[u] = ST ? s_w[jj - base] : as_global<float>(p.psw)[jj];
                     }
 #pragma unroll
-                    for (int u = 0; u < UNROLL; ++u) raw[u] = load16(Wc + r[u] * row_bytes, nt);
+                    for (int u = 0; u < UNROLL; ++u) raw[u] = load16(Wc + row_offset<ST>(r[u], row_bytes), nt);
 #pragma unroll
                     for (int u = 0; u < UNROLL; ++u) {
                         float f[VEC];
@@ -254,7 +262,7 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
                         if (WEIGHTED) w[u] = ST ? s_w[jj - base] : as_global<float>(p.psw)[jj];
                     }
 #pragma unroll
-                    for (int u = 0; u < UNROLL - 1; ++u) raw[u] = load16(Wc + r[u] * row_bytes, nt);
+                    for (int u = 0; u < UNROLL - 1; ++u) raw[u] = load16(Wc + row_offset<ST>(r[u], row_bytes), nt);
 #pragma unroll
                     for (int u = 0; u < UNROLL - 1; ++u) {
                         if (j + u < e) {
@@ -390,7 +398,7 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_flat_kernel(const KParams p
                     if (WEIGHTED) w[u] = ST ? s_w[jj - base] : as_global<float>(p.psw)[jj];
                 }
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) raw[u] = load16(Wc + r[u] * row_bytes, nt);
+                for (int u = 0; u < UNROLL; ++u) raw[u] = load16(Wc + row_offset<ST>(r[u], row_bytes), nt);
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
                     if (j + u < e) {
