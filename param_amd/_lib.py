@@ -12,8 +12,8 @@ import os
 import threading
 
 PM_F32, PM_BF16, PM_F16, PM_I32, PM_I64 = 0, 1, 2, 10, 11
-PM_OK, PM_ERR_INVALID, PM_ERR_UNSUPPORTED, PM_ERR_HIP, PM_ERR_INDEX = 0, -1, -2, -3, -4
-PM_ABI_VERSION = 4
+PM_OK, PM_ERR_INVALID, PM_ERR_UNSUPPORTED, PM_ERR_HIP, PM_ERR_INDEX, PM_ERR_SORT = 0, -1, -2, -3, -4, -5
+PM_ABI_VERSION = 5
 PM_WD_NONE, PM_WD_L2, PM_WD_DECOUPLE = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -50,6 +50,8 @@ EXPORTED_SYMBOLS = (
     "pm_set_sort_tuning",
     "pm_radix_sort_scratch_bytes",
     "pm_radix_sort_pairs",
+    "pm_embbag_sort_status",
+    "pm_set_hybrid_tuning",
 )
 
 
@@ -64,6 +66,17 @@ class pm_rowwise_adagrad(ctypes.Structure):
         ("stochastic_rounding", ctypes.c_int32),
         ("reserved", ctypes.c_int32),
         ("seed", ctypes.c_uint64),
+    ]
+
+
+class pm_sort_status(ctypes.Structure):
+    """Mirror of ``struct pm_sort_status`` (include/param_amd.h)."""
+
+    _fields_ = [
+        ("lookback_timeouts", ctypes.c_uint32),
+        ("pairs_sorted", ctypes.c_uint32),
+        ("hybrid_tables", ctypes.c_uint32),
+        ("hybrid_launched", ctypes.c_uint32),
     ]
 
 
@@ -178,6 +191,10 @@ def load() -> ctypes.CDLL:
         L.pm_radix_sort_scratch_bytes.argtypes = [i64]
         L.pm_radix_sort_pairs.restype = ctypes.c_int
         L.pm_radix_sort_pairs.argtypes = [vp, vp, vp, vp, i64, vp, i32, i32, i32, i64, vp, i64, ctypes.POINTER(ctypes.c_int32), vp]
+        L.pm_embbag_sort_status.restype = ctypes.c_int
+        L.pm_embbag_sort_status.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, vp, ctypes.POINTER(pm_sort_status), vp]
+        L.pm_set_hybrid_tuning.restype = ctypes.c_int
+        L.pm_set_hybrid_tuning.argtypes = [i32, i64]
         if L.pm_abi_version() != PM_ABI_VERSION:
             raise ImportError(f"{LIB_PATH}: ABI version {L.pm_abi_version()} != {PM_ABI_VERSION}")
         _lib = L
@@ -223,3 +240,10 @@ def set_sort_tuning(mode: int = -1) -> None:
     """``pm_set_sort_tuning``: segmented sort mode 0 LSD passes, one look-back kernel per pass / 1 low-digit partition +
     bucket-local LDS sort / 2 top-digit partition + local sort / 3 LSD passes of three kernels each; -1 = default"""
     check(load().pm_set_sort_tuning(mode))
+
+
+def set_hybrid_tuning(enable: int = -1, lookback_spin_cap: int = 0) -> None:
+    """``pm_set_hybrid_tuning``: the hybrid backward (rows looked up once are applied bag-major, only the repeats are sorted).
+    enable 0 off / 1 on (default; tables classified on the device at every sort) / 2 every structurally eligible table (tests);
+    lookback_spin_cap > 0 lowers the key sort's look-back poll limit (tests)."""
+    check(load().pm_set_hybrid_tuning(enable, lookback_spin_cap))

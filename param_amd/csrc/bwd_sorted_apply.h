@@ -4,6 +4,8 @@
 // sizes x weighted x optimizer x 3 tile sizes of main + fix-up kernels compile in parallel instead of in one 2.5-minute unit.
 #pragma once
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace pm {
@@ -55,6 +57,9 @@ struct SortedParams {
     int32_t tile;            // sorted positions per workgroup of the apply kernels (kSortTile, or smaller for small requests)
     int32_t xcd;             // 1: XCD-affine block -> tile mapping (needs seg_tiles); 2: XCD-contiguous (any request)
     const uint32_t* d_n;     // not NULL: the number of sorted pairs lives on the device (<= n), written by the segmented sort
+    int32_t unique_wgs_per_cu;   // bag-major apply: > 0 = a grid of this many workgroups per CU that loop over the tiles (0: one per tile)
+    const uint32_t* d_bad;   // not NULL: device word that is non-zero when the sort gave up (look-back time-outs): the apply kernels
+                             // then leave the tables untouched (pm_embbag_sort_status tells the host)
 };
 
 
@@ -62,5 +67,18 @@ struct SortedParams {
 hipError_t bwd_sorted_launch_f32(const SortedParams& sp, int key_bytes, int max_dim, hipStream_t stream);
 hipError_t bwd_sorted_launch_bf16(const SortedParams& sp, int key_bytes, int max_dim, hipStream_t stream);
 hipError_t bwd_sorted_launch_f16(const SortedParams& sp, int key_bytes, int max_dim, hipStream_t stream);
+// the hybrid backward's bag-major apply of rows looked up once (bwd_unique_kernel); kp = the request with the forward's tiling
+struct UniqueArgs {
+    const HybTable* hyb_tab;
+    const uint32_t* bloom;
+    void* emit_keys;             // the sort's b buffers: the flagged lookups of tile (t, i) go to the tile's own request positions
+    uint32_t* emit_vals;
+    int key_bytes;
+    uint32_t* tile_cnt;          // [table][tile_cnt_stride]
+    size_t tile_cnt_stride;
+};
+hipError_t bwd_unique_launch_f32(const SortedParams& sp, const KParams& kp, const UniqueArgs& ua, int max_dim, hipStream_t stream);
+hipError_t bwd_unique_launch_bf16(const SortedParams& sp, const KParams& kp, const UniqueArgs& ua, int max_dim, hipStream_t stream);
+hipError_t bwd_unique_launch_f16(const SortedParams& sp, const KParams& kp, const UniqueArgs& ua, int max_dim, hipStream_t stream);
 
 }  // namespace pm

@@ -260,6 +260,33 @@ int pm_set_sort_tuning(int32_t mode) {
     return PM_OK;
 }
 
+int pm_set_hybrid_tuning(int32_t enable, int64_t lookback_spin_cap) {
+    if (enable < -1 || enable > 2) return fail(PM_ERR_INVALID, "enable must be -1 .. 2");
+    if (lookback_spin_cap < 0 || lookback_spin_cap > 0xffffffffLL) return fail(PM_ERR_INVALID, "lookback_spin_cap must be in [0, 2^32)");
+    pm::set_hybrid_tuning(enable, static_cast<uint32_t>(lookback_spin_cap));
+    return PM_OK;
+}
+
+int pm_embbag_sort_status(const pm_embbag_batch* op, int64_t max_rows, const void* workspace, pm_sort_status* out, pm_stream_t stream) {
+    pm::KParams p;
+    int rc = make_params(op, op ? op->weight_dtype : -1, p);
+    if (rc != PM_OK) return rc;
+    if (max_rows < 1 || max_rows > (1LL << 31)) return fail(PM_ERR_INVALID, "max_rows must be in [1, 2^31]");
+    if (!workspace || !out) return fail(PM_ERR_INVALID, "NULL argument");
+    uint32_t v[4] = {0, 0, 0, 0};
+    const hipError_t h = pm::sort_status(p, max_rows, op->max_dim, workspace, static_cast<hipStream_t>(stream), v);
+    if (h == hipErrorInvalidValue) return fail(PM_ERR_INVALID, "no sort has been recorded for this workspace");
+    if (h != hipSuccess) return hip_fail(h, "pm_embbag_sort_status");
+    out->lookback_timeouts = v[0];
+    out->pairs_sorted = v[1];
+    out->hybrid_tables = v[2];
+    out->hybrid_launched = v[3];
+    if (v[0] != 0)
+        return fail(PM_ERR_SORT, "the key sort gave up (" + std::to_string(v[0]) + " look-back walks timed out): the apply kernels left the "
+                                 "tables untouched; sort again (pm_set_sort_tuning(3) needs no look-back) and apply again");
+    return PM_OK;
+}
+
 int64_t pm_radix_sort_scratch_bytes(int64_t n_max) {
     if (n_max < 0 || n_max > 0xffffffffLL) return fail(PM_ERR_INVALID, "n_max must be in [0, 2^32)");
     return static_cast<int64_t>(pm::rs_scratch_bytes(static_cast<size_t>(n_max)));

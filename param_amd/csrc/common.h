@@ -177,6 +177,42 @@ hipError_t rs_sort_pairs(K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_
                          int begin_bit, int end_bit, void* scratch, hipStream_t stream, size_t seg_len = 0,
                          const RsSource* src = nullptr);
 
+// Hybrid backward (round 4): tables whose lookups are (nearly) all to distinct rows skip the sort.  The sort's first kernel
+// classifies every table on the device; a HYBRID table's lookups are tested against four hashed "this row was looked up twice"
+// bitmaps (Bloom-style: built in LDS by hyb_mark_kernel, no false negatives); rows looked up once are read-modify-written
+// bag-major with the bag's gradient slice in registers (bwd_unique_kernel), only the flagged lookups are compacted into the
+// sort's input.  Everything else about the sort and the sorted apply is unchanged.
+constexpr int kHybMaxTables = 128;              // tables eligible for the hybrid path (256 KB of bitmaps each)
+// The dup test is a BLOCKED Bloom filter: a row owns ONE 32-bit word of its table's map (multiplicative hash) and up to four
+// bit positions inside it (second hash), so testing a lookup is one 4-byte gather and marking it one LDS atomic.  Measured
+// against four independent 2^19-bit maps (round 4, visit 3): the emit kernel's four gathers per lookup were 125 us of
+// address processing for the benchmark request.  Simulated at 163 840 uniform lookups into 10 M rows: 2.95 % of the lookups
+// flagged (1.65 % true repeats + 1.3 % false), 1.9 % with twice the words; no false negatives by construction.
+constexpr int kBloomK = 4;                      // slices of a table's map = mark workgroups per table
+constexpr int kBloomWords = 1 << 14;            // 32-bit words per slice (64 KB: seen + dup of a slice fill 128 KB of LDS)
+constexpr int kBloomTableWords = kBloomK * kBloomWords;   // 65 536 words = 256 KB per table
+constexpr uint32_t kHybMaxCount = 1u << 18;     // lookups per table beyond which a 2^21-bit map flags too many unique rows
+constexpr uint32_t kHybMinCount = 8192;         // ... and below which a table is not worth three extra kernels
+struct HybTable {            // one per table (device): written by the sort's first kernel and by the compaction
+    uint32_t mode;           // 0: every lookup through the sort; 1: hybrid
+    uint32_t pooling;        // the table's pooling factor (hybrid tables have one)
+    uint32_t n_dup;          // lookups left to the sort (hybrid tables: written by hyb_compact_kernel)
+    uint32_t pad;
+};
+__host__ __device__ inline uint32_t bloom_word(uint32_t row) { return (row * 0x9E3779B1u) >> 16; }     // 0 .. kBloomTableWords - 1
+__host__ __device__ inline uint32_t bloom_mask(uint32_t row) {
+    const uint32_t h = row * 0x85EBCA77u;
+    return (1u << (h >> 27)) | (1u << ((h >> 22) & 31u)) | (1u << ((h >> 17) & 31u)) | (1u << ((h >> 12) & 31u));
+}
+struct HybArgs {             // hybrid part of a sort request
+    int allow;               // 0: every table is classified "sort" and nothing else of the hybrid path runs; 1: on; 2: structural eligibility only (tests)
+};
+// (the per-table records, the dup bitmaps [min(T, kHybMaxTables)][kBloomTableWords] and the per-tile counts of flagged lookups
+// live in the sort's scratch: seg_sort_hyb_tab / seg_sort_bloom / seg_sort_tile_cnt)
+struct HybTiles {            // how the bag-major apply tiled the request when it listed the flagged lookups (part B's compaction)
+    int bags_per_tile;       // KParams::bags_per_block of the apply
+    int tiles_per_table;
+};
 // seg_sort.hip: the sorted backward's key sort over per-table segments established on the device
 constexpr int kSegSortMaxTables = 1024;
 struct SegDesc {             // one per table, written by the sort's prep kernels (device memory, inside the sort scratch)
@@ -200,6 +236,8 @@ struct SegSortRequest {
     int rbits_max;           // bits_for(max_rows): the number of global passes of mode 0
     bool weighted;           // values = lookup positions (+ bag_of), every table through the key-building kernel
     uint32_t* zero4;         // not NULL: four words the sort's first kernel sets to zero (the apply's work-list control words)
+    HybArgs hyb;
+    uint32_t spin_cap;       // look-back polls before a walk gives up (0 = default)
 };
 size_t seg_sort_scratch_bytes(size_t n_max, int T);
 int seg_sort_radix_bits(int mode, int rbits_max);   // 8, or 9 where a 9-bit digit saves a global pass (mode 0)
@@ -208,9 +246,23 @@ int seg_sort_passes(int mode, int rbits_max);
 bool seg_sort_result_in_b(int mode, int rbits_max);
 const SegDesc* seg_sort_desc(const void* scratch, size_t n_max, int T);
 const uint32_t* seg_sort_count(const void* scratch, size_t n_max, int T);   // device uint32: pairs in the sorted arrays
+// The sort in two parts: part A (the tables' segments and verdicts + the hybrid tables' dup bitmaps: all the bag-major apply
+// needs) and part B (everything else).  When the hybrid kernels are launched (rq.hyb.allow) part B runs inside the APPLY call,
+// after the bag-major kernel, which lists the flagged lookups tile by tile as a by-product of its own staging (`tiles` says how
+// it tiled); otherwise seg_sort_pairs = A then B.
+template <typename K>
+hipError_t seg_sort_part_a(const SegSortRequest& rq, void* scratch, hipStream_t stream);
+template <typename K>
+hipError_t seg_sort_part_b(const SegSortRequest& rq, int mode, K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t* bag_of,
+                           void* scratch, hipStream_t stream, HybTiles tiles = HybTiles{0, 0});
 template <typename K>
 hipError_t seg_sort_pairs(const SegSortRequest& rq, int mode, K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t* bag_of,
                           void* scratch, hipStream_t stream);
+const uint32_t* seg_sort_timeouts(const void* scratch, size_t n_max, int T);   // device uint32: look-back walks that gave up
+const HybTable* seg_sort_hyb_tab(const void* scratch, size_t n_max, int T);
+const uint32_t* seg_sort_bloom(const void* scratch, size_t n_max, int T);
+uint32_t* seg_sort_tile_cnt(const void* scratch, size_t n_max, int T);     // [T][B / 4 + 1] at most: flagged lookups per tile of the bag-major apply
+size_t seg_sort_tile_cnt_stride(size_t n_max);
 
 // rowquant.hip: row-wise quantisation of fp32 rows (bits 16 / 8 / 4 / 2), dim a multiple of 8
 int64_t rows_quantized_row_bytes(int dim, int bits);
@@ -218,6 +270,8 @@ hipError_t launch_rows_quantize(const float* src, int64_t n_rows, int dim, int b
 hipError_t launch_rows_dequantize(const void* src, int64_t n_rows, int dim, int bits, float* dst, hipStream_t stream);
 void set_backward_tuning(int sort_impl, int order, int xcd, int max_phases);   // -1 = default (environment)
 void set_sort_tuning(int mode);                                                // segmented sort: -1 default, 0 / 1 / 2
+void set_hybrid_tuning(int enable, uint32_t spin_cap);            // hybrid backward (embbag_bwd_sorted.hip); -1 = default
+hipError_t sort_status(const KParams& p, int64_t max_rows, int max_dim, const void* workspace, hipStream_t stream, uint32_t out[4]);
 
 // DLRM input redistribution (dlrm_regroup.hip)
 hipError_t launch_dlrm_regroup(const int64_t* lengths, const int64_t* indices, int W, int F, int64_t B,

@@ -26,11 +26,14 @@
 // Step 1+2 depend only on the indices, not on the gradient: pm_embbag_sort_indices() can run
 // on a side stream under the forward pass; pm_embbag_bwd_sorted() is step 3.
 #include <atomic>
+#include <climits>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -171,6 +174,20 @@ int sort_mode_knob() {
     return v;
 }
 bool table_major_order() { return knob(g_sort_order, env_is("PARAM_AMD_SORT_ORDER", "row") ? 0 : 1) == 1; }
+// hybrid backward (pm_set_hybrid_tuning; common.h "Hybrid backward"):
+//   enable   0 off; 1 (default) on: every table is classified on the device at every sort, from the request alone; 2 every
+//            structurally eligible table takes the hybrid path whatever its indices look like (tests)   PARAM_AMD_BWD_HYBRID=0..2
+//   spin_cap look-back polls before a walk gives up (0 = default 2^20; tests: 1, 0xFFFFFFFF)
+// (Round 4 also built the rest of the sort + the sorted apply of the flagged lookups on a second, library-owned stream beside
+//  the bag-major apply -- disjoint rows -- and measured it: the small kernels do run concurrently, and starve: the 54 us emit
+//  pass took 1.26 ms beside the chip-filling kernel, which itself went from 1.45 to 1.72 ms.  Removed; profiles/r04_*.)
+std::atomic<int> g_hyb_enable{-1};
+std::atomic<uint32_t> g_spin_cap{0};
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && e[0] >= '0' && e[0] <= '9') ? atoi(e) : dflt;
+}
+int hyb_enable_knob() { return knob(g_hyb_enable, env_int("PARAM_AMD_BWD_HYBRID", 1)); }
 bool want_xcd() { return knob(g_bwd_xcd, env_is("PARAM_AMD_BWD_XCD", "0") ? 0 : 1) == 1; }
 //   max_phases 1 (default): one apply launch; 2: a phases = 2 sort lays a fixed-pooling request out for the two-phase
 //              apply (measured at benchmark size: uniform indices 1.60 -> 1.58 ms, Zipf 0.97 -> 1.12 ms: rows looked up in
@@ -234,6 +251,8 @@ struct SortPlan {
     int32_t T;
     bool v2;             // sorted by seg_sort.hip: segments, pooling and the pair count live on the device
     int mode;            // seg_sort mode (0 / 3 LSD passes, 1 / 2 partition + bucket-local sort)
+    int hyb;             // hybrid backward: 0 not launched for this sort, else the `allow` value its kernels ran with (part B of the
+                         // sort then runs inside the apply call, after the bag-major kernel)
     // what the sort was issued for: the apply must follow with the same request on the same workspace
     const void* indices;
     const void* offsets;
@@ -257,6 +276,7 @@ SortPlan make_plan(const KParams& p, int64_t max_rows, int64_t fixed_pooling, in
     g.stamp = 0;
     g.v2 = sort_impl_knob() == 0 && p.T <= kSegSortMaxTables;
     g.mode = sort_mode_knob();
+    g.hyb = 0;
     if (g.v2) {
         // one plan for every request: the device establishes segments, per-table pooling and (for slices) the pair count
         g.H = 1;
@@ -301,6 +321,27 @@ std::unordered_map<const void*, SortPlan> g_plans;   // workspace -> the plan of
 uint64_t g_plan_stamp = 0;
 
 template <typename K>
+SegSortRequest seg_request(const KParams& p, const SortPlan& g, SortWs& ws) {
+    SegSortRequest rq;
+    rq.indices = p.indices;
+    rq.offsets = p.offsets;
+    rq.rows = p.rows;
+    rq.idx64 = p.idx64;
+    rq.T = p.T;
+    rq.B = p.B;
+    rq.N = p.N;
+    rq.bag_begin = p.bag_begin;
+    rq.bag_count = p.bag_count;
+    rq.tshift = g.tshift;
+    rq.rbits_max = g.rbits;
+    rq.weighted = g.weighted;
+    rq.zero4 = ws.fix_ctl;
+    rq.hyb.allow = g.hyb;
+    rq.spin_cap = g_spin_cap.load();
+    return rq;
+}
+
+template <typename K>
 hipError_t sort_impl(const KParams& p, const SortPlan& g, SortWs& ws, hipStream_t stream) {
     KParams q = p;
     q.bag_begin = 0;
@@ -312,21 +353,10 @@ hipError_t sort_impl(const KParams& p, const SortPlan& g, SortWs& ws, hipStream_
     K* ka = reinterpret_cast<K*>(ws.keys_a);
     K* kb = reinterpret_cast<K*>(ws.keys_b);
     if (g.v2) {
-        SegSortRequest rq;
-        rq.indices = p.indices;
-        rq.offsets = p.offsets;
-        rq.rows = p.rows;
-        rq.idx64 = p.idx64;
-        rq.T = p.T;
-        rq.B = p.B;
-        rq.N = p.N;
-        rq.bag_begin = p.bag_begin;
-        rq.bag_count = p.bag_count;
-        rq.tshift = g.tshift;
-        rq.rbits_max = g.rbits;
-        rq.weighted = g.weighted;
-        rq.zero4 = ws.fix_ctl;
-        return seg_sort_pairs<K>(rq, g.mode, ka, kb, ws.vals_a, ws.vals_b, ws.bag_of, ws.temp, stream);
+        const SegSortRequest rq = seg_request<K>(p, g, ws);
+        const hipError_t rc = seg_sort_part_a<K>(rq, ws.temp, stream);
+        if (rc != hipSuccess || g.hyb) return rc;      // hybrid: the rest of the sort follows the bag-major kernel, in the apply call
+        return seg_sort_part_b<K>(rq, g.mode, ka, kb, ws.vals_a, ws.vals_b, ws.bag_of, ws.temp, stream);
     }
     // the apply's work-list control words start at zero (the segmented sort's first kernel does this itself)
     hipError_t zrc = hipMemsetAsync(ws.fix_ctl, 0, 4 * sizeof(uint32_t), stream);
@@ -383,11 +413,19 @@ hipError_t sorted_workspace_bytes(const KParams& p, int64_t max_rows, int max_di
 
 hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, int64_t fixed_pooling, int phases, void* workspace,
                         hipStream_t stream) {
-    const SortPlan g = make_plan(p, max_rows, fixed_pooling, phases);
+    SortPlan g = make_plan(p, max_rows, fixed_pooling, phases);
     SortWs ws;
     hipError_t rc = ws_layout(workspace, p.N, p.T, ws_key_bytes(p, max_rows), ws_kbits_sort(p, max_rows), g.weighted, max_dim, ws);
     if (rc != hipSuccess) return rc;
     {
+        // Hybrid backward: launched for every unweighted request of the segmented sort large enough to hold an eligible table; which
+        // tables take it is decided on the device, from the request alone (a host-side hint fed by the previous sort's verdicts
+        // would save ~15 us of empty launches on skewed requests -- and make the bits of rows looked up more than 256 times depend
+        // on the history of the workspace: the chunk boundaries of their partial sums follow what else is in the sorted arrays).
+        // (The compaction scans one count per tile of the bag-major apply, kCompactMaxTiles = 4096 per table; the apply may tile
+        // twice as fine as this call's geometry when its element type differs.)
+        const int en = hyb_enable_knob();
+        if (g.v2 && en > 0 && !g.weighted && p.N >= static_cast<int64_t>(kHybMinCount) && p.tiles_per_table <= 2048) g.hyb = en >= 2 ? 2 : 1;
         std::lock_guard<std::mutex> lock(g_plan_mutex);
         // bound the record table: the OLDEST record goes (a clear() would also drop plans of workspaces that are sorted
         // but not yet applied)
@@ -515,13 +553,85 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
     sp.phase = 0;
     sp.xcd = g.xcd ? (g.v2 ? 2 : 1) : 0;
     sp.d_n = g.v2 ? seg_sort_count(ws.temp, static_cast<size_t>(p.N), p.T) : nullptr;
+    sp.d_bad = g.v2 ? seg_sort_timeouts(ws.temp, static_cast<size_t>(p.N), p.T) : nullptr;
     sp.tile = g.v2 ? apply_tile(p.N) : kSortTile;      // round 2's plans (segments per table, phases) are laid out for 1024
-    if (sp.n == 0) return hipSuccess;
-    switch (dst_dtype) {
-        case PM_F32: return bwd_sorted_launch_f32(sp, g.key_bytes, max_dim, stream);
-        case PM_BF16: return bwd_sorted_launch_bf16(sp, g.key_bytes, max_dim, stream);
-        default: return bwd_sorted_launch_f16(sp, g.key_bytes, max_dim, stream);
+    {
+        static const int wgs = env_int("PARAM_AMD_UNIQUE_WGS_PER_CU", 0);      // experiments: the bag-major kernel as a looping grid
+        sp.unique_wgs_per_cu = wgs;
     }
+    if (sp.n == 0) return hipSuccess;
+    // (Hybrid sorts leave a few per cent of the lookups to this apply.  Measured on what is left of the uniform benchmark request
+    // (225 K pairs): 66 us with 256-position tiles, 60 us with 512 -- the same ~5 G pairs/s as at full size, not a latency chain;
+    // a looping grid of 4096 workgroups changed nothing for the small launch and cost the full-size one its XCD-contiguous tile
+    // order (Zipf apply +13 %).  So: the request-sized tile, one workgroup per possible tile, as for every other sort.)
+    auto sorted_apply = [&](hipStream_t s_) {
+        switch (dst_dtype) {
+            case PM_F32: return bwd_sorted_launch_f32(sp, g.key_bytes, max_dim, s_);
+            case PM_BF16: return bwd_sorted_launch_bf16(sp, g.key_bytes, max_dim, s_);
+            default: return bwd_sorted_launch_f16(sp, g.key_bytes, max_dim, s_);
+        }
+    };
+    if (!g.hyb) return sorted_apply(stream);
+    // Hybrid: the bag-major kernel applies the rows looked up once and lists the other lookups; then the rest of the sort
+    // (compaction of the lists, prep 2, the passes) and the sorted apply of what is left -- a few per cent of the request
+    // under uniform indices, everything if no table qualified.
+    UniqueArgs ua;
+    ua.hyb_tab = seg_sort_hyb_tab(ws.temp, static_cast<size_t>(p.N), p.T);
+    ua.bloom = seg_sort_bloom(ws.temp, static_cast<size_t>(p.N), p.T);
+    ua.emit_keys = ws.keys_b;
+    ua.emit_vals = ws.vals_b;
+    ua.key_bytes = g.key_bytes;
+    ua.tile_cnt = seg_sort_tile_cnt(ws.temp, static_cast<size_t>(p.N), p.T);
+    ua.tile_cnt_stride = seg_sort_tile_cnt_stride(static_cast<size_t>(p.N));
+    switch (dst_dtype) {
+        case PM_F32: rc = bwd_unique_launch_f32(sp, p, ua, max_dim, stream); break;
+        case PM_BF16: rc = bwd_unique_launch_bf16(sp, p, ua, max_dim, stream); break;
+        default: rc = bwd_unique_launch_f16(sp, p, ua, max_dim, stream); break;
+    }
+    if (rc != hipSuccess) return rc;
+    const HybTiles tiles{p.bags_per_block, p.tiles_per_table};
+    if (g.key_bytes == 4) {
+        const SegSortRequest rq = seg_request<uint32_t>(p, g, ws);
+        rc = seg_sort_part_b<uint32_t>(rq, g.mode, reinterpret_cast<uint32_t*>(ws.keys_a), reinterpret_cast<uint32_t*>(ws.keys_b), ws.vals_a,
+                                       ws.vals_b, ws.bag_of, ws.temp, stream, tiles);
+    } else {
+        const SegSortRequest rq = seg_request<uint64_t>(p, g, ws);
+        rc = seg_sort_part_b<uint64_t>(rq, g.mode, reinterpret_cast<uint64_t*>(ws.keys_a), reinterpret_cast<uint64_t*>(ws.keys_b), ws.vals_a,
+                                       ws.vals_b, ws.bag_of, ws.temp, stream, tiles);
+    }
+    if (rc != hipSuccess) return rc;
+    return sorted_apply(stream);
+}
+
+void set_hybrid_tuning(int enable, uint32_t spin_cap) {
+    g_hyb_enable.store(enable);
+    g_spin_cap.store(spin_cap);
+}
+
+// synchronous: what the last sort on this workspace left on the device
+hipError_t sort_status(const KParams& p, int64_t max_rows, int max_dim, const void* workspace, hipStream_t stream, uint32_t out[4]) {
+    SortPlan g;
+    {
+        std::lock_guard<std::mutex> lock(g_plan_mutex);
+        auto it = g_plans.find(workspace);
+        if (it == g_plans.end()) return hipErrorInvalidValue;
+        g = it->second;
+    }
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (!g.v2) return hipSuccess;
+    SortWs ws;
+    hipError_t rc = ws_layout(const_cast<void*>(workspace), p.N, p.T, ws_key_bytes(p, max_rows), ws_kbits_sort(p, max_rows), g.weighted,
+                              max_dim, ws);
+    if (rc != hipSuccess) return rc;
+    if ((rc = hipMemcpyAsync(&out[0], seg_sort_timeouts(ws.temp, static_cast<size_t>(p.N), p.T), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return rc;
+    if ((rc = hipMemcpyAsync(&out[1], seg_sort_count(ws.temp, static_cast<size_t>(p.N), p.T), 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return rc;
+    std::vector<HybTable> tab(static_cast<size_t>(p.T));
+    if ((rc = hipMemcpyAsync(tab.data(), seg_sort_hyb_tab(ws.temp, static_cast<size_t>(p.N), p.T), sizeof(HybTable) * tab.size(),
+                             hipMemcpyDeviceToHost, stream)) != hipSuccess) return rc;
+    if ((rc = hipStreamSynchronize(stream)) != hipSuccess) return rc;
+    for (const HybTable& h : tab) out[2] += h.mode == 1u ? 1u : 0u;
+    out[3] = static_cast<uint32_t>(g.hyb);
+    return hipSuccess;
 }
 
 }  // namespace pm

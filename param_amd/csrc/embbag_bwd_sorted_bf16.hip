@@ -11,4 +11,8 @@ hipError_t bwd_sorted_launch_bf16(const SortedParams& sp, int key_bytes, int max
     return key_bytes == 4 ? launch_apply_g<SDstBF16, uint32_t>(sp, max_dim, stream) : launch_apply_g<SDstBF16, uint64_t>(sp, max_dim, stream);
 }
 
+hipError_t bwd_unique_launch_bf16(const SortedParams& sp, const KParams& kp, const UniqueArgs& ua, int max_dim, hipStream_t stream) {
+    return launch_unique_g<SDstBF16>(sp, kp, ua, max_dim, stream);
+}
+
 }  // namespace pm

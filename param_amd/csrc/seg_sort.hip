@@ -53,13 +53,14 @@ constexpr uint32_t kWaveCap = 1024;     // bucket-local sort by one wave: 16 pai
 constexpr uint32_t kLocalCap = kTile;   // ... by one workgroup; larger buckets go to the second level
 constexpr int kL2Grid = 512;            // persistent grid of the second-level passes
 constexpr int kBuildBags = 1024;        // bags per workgroup of the key-building kernel
+constexpr int kMaxLbPasses = 5;         // passes the look-back form of mode 0 takes at most
 
 struct SegHeader {
     uint32_t n_total;    // pairs in all segments (= length of the sorted arrays)
     uint32_t n_tiles;    // radix tiles of the first level
     uint32_t n_l2;       // buckets on the second-level list (= second-level segments)
     uint32_t n_tiles2;   // radix tiles of the second level
-    uint32_t lookback_timeouts;   // look-back walks that gave up (never, unless workgroups are not dispatched in index order)
+    uint32_t lookback_timeouts;   // look-back walks that gave up (a predecessor stalled for ~a second: the apply kernels refuse such a sort)
     uint32_t pad[11];
 };
 
@@ -159,9 +160,11 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // prep 1: one workgroup (1024 threads) per table
-__global__ void __launch_bounds__(1024) seg_prep_tables_kernel(const void* offsets, int idx64, const int64_t* rows, int T, int64_t B,
-                                                               int64_t N, int64_t bag_begin, int64_t bag_count, int force_ragged,
-                                                               SegDesc* desc, uint32_t* zero4) {
+__global__ void __launch_bounds__(1024) seg_prep_tables_kernel(const void* indices, const void* offsets, int idx64, const int64_t* rows, int T,
+                                                               int64_t B, int64_t N, int64_t bag_begin, int64_t bag_count, int force_ragged,
+                                                               SegDesc* desc, uint32_t* zero4, const HybArgs hyb, HybTable* hyb_tab) {
+    __shared__ uint32_t s_sample[2048];      // classification: 2^16 hashed bits
+    __shared__ uint32_t s_rep;
     const int t = blockIdx.x;
     if (zero4 && t == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0u;
     const int64_t TB = static_cast<int64_t>(T) * B;
@@ -172,6 +175,20 @@ __global__ void __launch_bounds__(1024) seg_prep_tables_kernel(const void* offse
     const int64_t cnt = e > s ? e - s : 0;
     const int64_t L = (bag_count > 0 && cnt > 0 && cnt % bag_count == 0) ? cnt / bag_count : 0;
     int bad = (L == 0 || force_ragged) ? 1 : 0;
+    // Classification for the hybrid backward (common.h), first half: is the table structurally eligible -- a size the dup map
+    // separates, a row count that makes repeats rare under uniform indices -- and if so, request a sample of 2048 lookups spread
+    // over the table's slice now, so that their latency passes under the check of the offsets below.
+    const int64_t n_rows = rows[t];
+    bool cand = t < kHybMaxTables && !bad && cnt >= kHybMinCount && cnt <= kHybMaxCount && cnt * 8 <= n_rows;     // workgroup-uniform
+    const bool sample = cand && hyb.allow != 2;                // allow == 2 (tests): structural eligibility is enough
+    uint32_t sr[2] = {0u, 0u};
+    if (sample) {
+        const int64_t stride = cnt / 2048;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) sr[u] = static_cast<uint32_t>(load_index(indices, s + (threadIdx.x + u * 1024) * stride, idx64));
+        for (int i = threadIdx.x; i < 2048; i += 1024) s_sample[i] = 0u;
+        if (threadIdx.x == 0) s_rep = 0u;
+    }
     if (!bad) {
         // every bag of the (sliced) table must start where a pooling factor of L puts it; 8 independent loads per round trip
         for (int64_t i0 = threadIdx.x; i0 < bag_count; i0 += 8 * 1024) {
@@ -187,6 +204,29 @@ __global__ void __launch_bounds__(1024) seg_prep_tables_kernel(const void* offse
         }
     }
     bad = __syncthreads_or(bad);
+    // ... second half: the sample must not repeat itself (2^16 hashed bits: uniform indices collide ~32 times in 2048, a
+    // Zipf(1.05) head hundreds of times).  A wrong verdict costs speed only: every lookup is applied exactly once either way.
+    {
+        cand = cand && !bad;
+        if (sample) {
+            uint32_t rep = 0;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t h = (sr[u] * 0x9E3779B1u) >> 16;
+                rep += (atomicOr(&s_sample[h >> 5], 1u << (h & 31u)) >> (h & 31u)) & 1u;
+            }
+            if (rep) atomicAdd(&s_rep, rep);
+            __syncthreads();
+            cand = cand && s_rep * 8u <= 2048u;
+        }
+        if (threadIdx.x == 0) {
+            HybTable h;
+            h.mode = (cand && hyb.allow) ? 1u : 0u;
+            h.pooling = bad ? 0u : static_cast<uint32_t>(L);
+            h.n_dup = h.pad = 0u;
+            hyb_tab[t] = h;
+        }
+    }
     if (threadIdx.x == 0) {
         SegDesc d;
         d.in_start = static_cast<uint32_t>(s);
@@ -221,7 +261,7 @@ __device__ __forceinline__ void build_keys_chunk(int t, int chunk, const void* i
                                                  int64_t N, int64_t bag_begin, int64_t bag_count, const SegDesc* desc, int tshift, K* keys,
                                                  uint32_t* vals, uint32_t* bag_of, int64_t* s_off) {
     constexpr int kBags = kBuildBags;
-    if (!WEIGHTED && desc[t].pooling > 0) return;
+    if (!WEIGHTED && (desc[t].pooling > 0 || desc[t].pad)) return;      // pad: a hybrid table, its pairs are compacted already
     const int64_t bag0 = bag_begin + static_cast<int64_t>(chunk) * kBags;
     const int64_t left = bag_begin + bag_count - bag0;
     if (left <= 0) return;
@@ -252,7 +292,7 @@ __device__ __forceinline__ void build_keys_chunk(int t, int chunk, const void* i
 // workgroups of the launch build the (key, bag) pairs of the tables without a pooling factor (one workgroup per 1024 bags of a
 // table; they exit at once for tables that have one) -- the two jobs need only prep 1's results, and a launch saved is ~6 us.
 template <typename K, bool WEIGHTED>
-__global__ void __launch_bounds__(1024) seg_prep_scan_kernel(SegDesc* desc, int T, SegHeader* hdr, TileDesc* tiles, uint32_t tiles_cap,
+__global__ void __launch_bounds__(1024) seg_prep_scan_kernel(SegDesc* desc, int T, SegHeader* hdr, uint32_t* tickets, TileDesc* tiles, uint32_t tiles_cap,
                                                              const void* indices, const void* offsets, int idx64, int64_t B, int64_t N,
                                                              int64_t bag_begin, int64_t bag_count, int tshift, K* keys, uint32_t* vals,
                                                              uint32_t* bag_of, int chunks_per_table) {
@@ -287,6 +327,10 @@ __global__ void __launch_bounds__(1024) seg_prep_scan_kernel(SegDesc* desc, int 
         hdr->n_l2 = 0;
         hdr->n_tiles2 = 0;
         hdr->lookback_timeouts = 0;
+    }
+    if (t < T) {
+#pragma unroll
+        for (int i = 0; i < kMaxLbPasses; ++i) tickets[i * T + t] = 0u;       // look-back passes: next tile of table t to hand out
     }
     __syncthreads();
     const uint32_t n_write = n_tiles < tiles_cap ? n_tiles : tiles_cap;
@@ -345,8 +389,10 @@ template <typename K>
 __device__ __forceinline__ void load_tile_rows(const TileDesc& td, const PassSrc<K>& src, uint64_t (&row)[kTileItems]) {
     const uint32_t cnt = td.cnt, last = cnt - 1u;       // cnt >= 1; positions past the end re-read the last element (and are ignored)
     auto at = [&](int k) { const uint32_t q = k * kT + threadIdx.x; return q < cnt ? q : last; };
-    if (src.first) {
-        // the row digits of request-order tiles can always be taken from the index array (built keys carry the same row bits)
+    if (src.first && td.pooling > 0) {
+        // request-order tiles of a table with a pooling factor: the rows are the index array's (tables whose pairs were built --
+        // ragged bags, weighted requests, hybrid tables' compacted repeats -- read the built keys below: same row bits, and a
+        // hybrid table's pairs are not at their request positions any more)
         if (src.idx64) {
             const PM_GLOBAL int64_t* ip = as_global<int64_t>(src.indices) + td.in_base;
 #pragma unroll
@@ -360,7 +406,7 @@ __device__ __forceinline__ void load_tile_rows(const TileDesc& td, const PassSrc
             for (int k = 0; k < kTileItems; ++k) row[k] = raw[k];
         }
     } else {
-        const K* kp = src.keys + td.out_base;
+        const K* kp = src.keys + (src.first ? td.in_base : td.out_base);
         K raw[kTileItems];
 #pragma unroll
         for (int k = 0; k < kTileItems; ++k) raw[k] = kp[at(k)];
@@ -516,13 +562,15 @@ __global__ void __launch_bounds__(kRadix * kScanChunks) seg_scan_kernel(SegHeade
 // holds tile positions wave * chunk + r * 64 + lane, r = 0 .. ITEMS-1 (valid: r * 64 + lane < chunk and position < cnt),
 // so waves own consecutive runs of the tile and (wave, r, lane) order = position order.  On return s_key / s_val hold
 // the tile reordered by digit (stable), s_dstart[d] = first staged position of digit d.
-template <typename K, int ITEMS, int RB>
+template <typename K, int ITEMS, int RB, bool ZEROED = false>
 __device__ __forceinline__ void tile_count_digits(const K (&key)[ITEMS], uint32_t (&rank)[ITEMS], uint32_t cnt, uint32_t chunk, int shift,
                                                   uint32_t mask, uint32_t* s_wcnt) {
     constexpr int RAD = 1 << RB;
     const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
-    for (int i = threadIdx.x; i < kWaves * RAD; i += kT) s_wcnt[i] = 0;
-    __syncthreads();
+    if (!ZEROED) {                             // (ZEROED: the caller cleared the counters and passed a barrier)
+        for (int i = threadIdx.x; i < kWaves * RAD; i += kT) s_wcnt[i] = 0;
+        __syncthreads();
+    }
     uint32_t* wcnt = s_wcnt + wave * RAD;
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
@@ -731,7 +779,6 @@ __global__ void __launch_bounds__(kT) seg_scatter_loop_kernel(const TileDesc* ti
 // (the poll is bounded all the same: a stuck walk gives up, counts in hdr->lookback_timeouts, and the result is wrong
 // rather than the device hung).
 constexpr uint32_t kStAggregate = 1u << 30, kStInclusive = 2u << 30, kStValue = (1u << 30) - 1u;
-constexpr int kMaxLbPasses = 5;
 constexpr size_t kLbRowWords = 4 * 512;   // passes x digit values of any plan the look-back form takes (seg_sort_lookback): 4 x 9 bits, 5 x 8 bits
 constexpr uint32_t kLbSpinCap = 1u << 20;
 
@@ -752,8 +799,10 @@ __device__ __forceinline__ void load_status_batch(const uint32_t* const (&p)[kLb
         : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3])
         : "memory");
 }
+// `s_nop 1`: the data registers of a store wider than 64 bits must not be written by the next VALU instruction (the wait state the
+// compiler pads for stores it can see; it cannot see this one)
 __device__ __forceinline__ void store_status(uint32_t* p, u32x4 v) {   // write-through
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 
 // all passes' digit counts of every tile of the REQUEST: status rows st[pass][tile][digit] = count, flagged as published for
@@ -867,35 +916,57 @@ __global__ void __launch_bounds__(kRadix * kScanChunks) seg_scan_all_kernel(cons
 template <typename K, int RB>
 __global__ void __launch_bounds__(kT) seg_lookback_pass_kernel(const TileDesc* tiles, SegHeader* hdr, const PassSrc<K> src, int pass, int T,
                                                                uint32_t tiles_cap, uint32_t* st_all, const uint32_t* bstart_all, K* kout,
-                                                               uint32_t* vout) {
+                                                               uint32_t* vout, uint32_t spin_cap, uint32_t* tickets) {
     constexpr int RAD = 1 << RB;
     constexpr int LW = RAD / 256;            // waves that publish and walk back: 256 digits each, four per lane
+    __shared__ uint32_t s_ticket;
     __shared__ K s_key[kTile];
     __shared__ uint32_t s_val[kTile];
     __shared__ uint32_t s_wcnt[kWaves << RB];
     __shared__ uint32_t s_dstart[1 << RB];
     __shared__ __attribute__((aligned(16))) uint32_t s_gbase[1 << RB];
     __shared__ uint32_t s_tmp[kWaves];
-    const TileDesc td = tiles[blockIdx.x];
+    // Tiles are handed out by TICKET, per table: a workgroup reads the descriptor of "its" tile (blockIdx: which table), draws
+    // the table's next ticket (one returning atomic; a table's ~40 tiles share a counter, so no word is contended -- one counter
+    // for the whole pass queued ~2000 atomics on a word, ~11 ns each: +9 us per pass) and takes the table's tile of that number --
+    // its own, if workgroups start in index order, which they do in practice: no second descriptor load then.  A tile waits only
+    // for tiles of lower number in its table, whose tickets were drawn earlier by workgroups that are therefore running: forward
+    // progress does not rest on the dispatch order of workgroups, which HIP does not promise (rocPRIM's ordered block id).
+    // Exactly ntiles(table) workgroups draw from a table's counter, so every ticket is a valid tile.
+    TileDesc td = tiles[blockIdx.x];
     if (blockIdx.x >= hdr->n_tiles) return;
+    uint32_t ticket = 0;
+    if (threadIdx.x == 0) ticket = atomicAdd(&tickets[pass * T + td.seg], 1u);
+    // ... and while the ticket is on its way, the pairs of the tile the workgroup will almost certainly get are requested and the
+    // digit counters cleared; the ticket reaches the other threads through LDS at the barrier the counting needs anyway.  The
+    // atomic's round trip passes under the tile's loads: no barrier, no latency of its own.
     const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
     constexpr uint32_t chunk = kTile / kWaves;
-    const uint32_t g = blockIdx.x, t = td.seg, cnt = td.cnt, first = td.first;
-    const uint32_t j = first / static_cast<uint32_t>(kTile);                  // this tile's index inside its table
-    int shift;
-    uint32_t mask;
-    pass_digit(0, pass, td.rbits, RB, shift, mask);
+    const uint32_t t = td.seg;
+    const bool from_idx = src.first && td.pooling > 0;    // keys formed from the index array, bag = position / pooling (per table)
+    K key[kTileItems];
+    uint32_t val[kTileItems];
+    load_tile_pairs<K>(td, src, src.first ? td.in_base : td.out_base, from_idx, key, val);
     uint32_t* st = st_all + static_cast<uint64_t>(pass) * tiles_cap * RAD;
     const int dq = (wave * 256 + lane * 4) & (RAD - 1);                       // the look-back waves' first digit
     u32x4 tb = {0u, 0u, 0u, 0u};
     if (wave < LW) tb = *reinterpret_cast<const u32x4*>(bstart_all + (static_cast<uint64_t>(pass) * T + t) * RAD + dq);
-    const uint64_t base = src.first ? td.in_base : td.out_base;
-    const bool from_idx = src.first && td.pooling > 0;    // keys formed from the index array, bag = position / pooling
-    K key[kTileItems];
-    uint32_t val[kTileItems];
-    load_tile_pairs<K>(td, src, base, from_idx, key, val);
+    for (int i = threadIdx.x; i < kWaves * RAD; i += kT) s_wcnt[i] = 0;
+    if (threadIdx.x == 0) s_ticket = ticket;
+    __syncthreads();
+    const uint32_t j_static = td.first / static_cast<uint32_t>(kTile);
+    const uint32_t g = blockIdx.x - j_static + s_ticket;
+    if (s_ticket != j_static) {                                               // workgroup-uniform; rare: workgroups start in index order
+        td = tiles[g];
+        load_tile_pairs<K>(td, src, src.first ? td.in_base : td.out_base, from_idx, key, val);
+    }
+    const uint32_t cnt = td.cnt, first = td.first;
+    const uint32_t j = first / static_cast<uint32_t>(kTile);                  // this tile's index inside its table
+    int shift;
+    uint32_t mask;
+    pass_digit(0, pass, td.rbits, RB, shift, mask);
     uint32_t rank[kTileItems];
-    tile_count_digits<K, kTileItems, RB>(key, rank, cnt, chunk, shift, mask, s_wcnt);
+    tile_count_digits<K, kTileItems, RB, true>(key, rank, cnt, chunk, shift, mask, s_wcnt);
     tile_digit_starts<RB>(s_wcnt, s_dstart, s_tmp, s_gbase);                  // s_gbase: the tile's count of every digit, for now
     u32x4 mine = {0u, 0u, 0u, 0u};
     if (wave < LW) {
@@ -927,7 +998,7 @@ __global__ void __launch_bounds__(kT) seg_lookback_pass_kernel(const TileDesc* t
                     u32x4 v = s4[b];
                     uint32_t spins = 0;
                     while (__any(((v[0] >> 30) == 0u) | ((v[1] >> 30) == 0u) | ((v[2] >> 30) == 0u) | ((v[3] >> 30) == 0u))) {
-                        if (++spins > kLbSpinCap) {
+                        if (++spins > spin_cap) {
                             if (lane == 0) atomicAdd(&hdr->lookback_timeouts, 1u);
                             break;
                         }
@@ -943,6 +1014,7 @@ __global__ void __launch_bounds__(kT) seg_lookback_pass_kernel(const TileDesc* t
                 }
             }
         }
+        if (spin_cap == 0xffffffffu && j > 0 && threadIdx.x == 0) atomicAdd(&hdr->lookback_timeouts, 1u);   // tests: the failure channel, on demand
         if (j > 0) store_status(st + static_cast<uint64_t>(g) * RAD + dq, ((ex + mine) & kStValue) | kStInclusive);
         *reinterpret_cast<u32x4*>(s_gbase + dq) = tb + ex;                    // where this tile's run of each digit starts
     }
@@ -1188,9 +1260,14 @@ __global__ void __launch_bounds__(1024) seg_l2_prep_kernel(SegHeader* hdr, const
     if (t == 0) hdr->n_tiles2 = s_carry < tiles2_cap ? s_carry : tiles2_cap;
 }
 
+#include "seg_hybrid.inc"
+
 inline size_t a256(size_t x) { return (x + 255) / 256 * 256; }
 inline size_t tiles_max(size_t n, int T) { return n / kTile + static_cast<size_t>(T) + 1; }
-inline size_t seg2_max(size_t n) { return n / kTile + 1; }                 // every second-level segment holds more than a tile
+inline size_t seg2_max(size_t n) { return n / kTile + 1; }
+// per-tile counts of the bag-major apply: a hybrid table has at most kHybMaxCount lookups, a tile at least 4 bags of >= 1 lookup;
+// tables of more tiles than this are not compacted (the launcher falls back to "no hybrid tables")
+inline size_t tile_cnt_stride(size_t) { return kCompactMaxTiles; }                 // every second-level segment holds more than a tile
 inline size_t tiles2_max(size_t n) {
     const size_t t2 = n / kTile + seg2_max(n) + 1;
     return t2 < static_cast<size_t>(kL2Grid) ? static_cast<size_t>(kL2Grid) : t2;   // the persistent grid reads tiles2[blockIdx.x] before it knows the count
@@ -1211,6 +1288,10 @@ struct Scratch {
     uint32_t* bcnt2;
     uint32_t* st_all;        // look-back form: status rows [pass][tile][digit]
     uint32_t* bstart_all;    // ... bucket starts [pass][table][digit]
+    uint32_t* tickets;       // ... ticket counters [pass][table]
+    HybTable* hyb_tab;       // hybrid backward: per-table records
+    uint32_t* bloom;         // ... dup bitmaps of the first kHybMaxTables tables
+    uint32_t* tile_cnt;      // ... flagged lookups per tile of the bag-major apply, [T_h][tile_cnt_stride]
     size_t total;
 };
 
@@ -1234,6 +1315,11 @@ Scratch scratch_layout(void* base, size_t n, int T) {
     s.bcnt2 = reinterpret_cast<uint32_t*>(take(4 * s2 * kRadix));
     s.st_all = reinterpret_cast<uint32_t*>(take(4 * tm * kLbRowWords));
     s.bstart_all = reinterpret_cast<uint32_t*>(take(4 * static_cast<size_t>(T) * kLbRowWords));
+    s.tickets = reinterpret_cast<uint32_t*>(take(4 * static_cast<size_t>(T) * kMaxLbPasses));
+    const size_t th = static_cast<size_t>(T < kHybMaxTables ? T : kHybMaxTables);
+    s.hyb_tab = reinterpret_cast<HybTable*>(take(sizeof(HybTable) * static_cast<size_t>(T)));
+    s.bloom = reinterpret_cast<uint32_t*>(take(4 * th * kBloomTableWords));
+    s.tile_cnt = reinterpret_cast<uint32_t*>(take(4 * th * tile_cnt_stride(n)));
     s.total = off;
     return s;
 }
@@ -1247,6 +1333,13 @@ const SegDesc* seg_sort_desc(const void* scratch, size_t n_max, int T) { return 
 const uint32_t* seg_sort_count(const void* scratch, size_t n_max, int T) {
     return &scratch_layout(const_cast<void*>(scratch), n_max, T).hdr->n_total;
 }
+const uint32_t* seg_sort_timeouts(const void* scratch, size_t n_max, int T) {
+    return &scratch_layout(const_cast<void*>(scratch), n_max, T).hdr->lookback_timeouts;
+}
+const HybTable* seg_sort_hyb_tab(const void* scratch, size_t n_max, int T) { return scratch_layout(const_cast<void*>(scratch), n_max, T).hyb_tab; }
+const uint32_t* seg_sort_bloom(const void* scratch, size_t n_max, int T) { return scratch_layout(const_cast<void*>(scratch), n_max, T).bloom; }
+uint32_t* seg_sort_tile_cnt(const void* scratch, size_t n_max, int T) { return scratch_layout(const_cast<void*>(scratch), n_max, T).tile_cnt; }
+size_t seg_sort_tile_cnt_stride(size_t n_max) { return tile_cnt_stride(n_max); }
 
 // mode 0 sorts 9 bits per pass where that saves a global pass over the pairs: 25 .. 27 row bits (the 40 M-row Criteo tables:
 // 3 passes instead of 4), 17 / 18 bits (2 instead of 3), 9 bits.  Everywhere else 8: a 512-value digit costs LDS (three
@@ -1272,7 +1365,7 @@ bool seg_sort_lookback(int mode, int rbits_max, int64_t n) {
 namespace {
 template <typename K, int RB>
 void launch_lookback(const Scratch& s, unsigned tm, int T, PassSrc<K> src, int total, K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b,
-                     hipStream_t stream) {
+                     uint32_t spin_cap, hipStream_t stream) {
     src.first = 1;
     src.keys = keys_a;
     src.vals = vals_a;
@@ -1285,7 +1378,7 @@ void launch_lookback(const Scratch& s, unsigned tm, int T, PassSrc<K> src, int t
         K* kout = (p % 2 == 0) ? keys_b : keys_a;
         uint32_t* vout = (p % 2 == 0) ? vals_b : vals_a;
         hipLaunchKernelGGL((seg_lookback_pass_kernel<K, RB>), dim3(tm), dim3(kT), 0, stream, s.tiles, s.hdr, src, p, T, tm, s.st_all, s.bstart_all,
-                           kout, vout);
+                           kout, vout, spin_cap, s.tickets);
     }
 }
 template <typename K, int RB>
@@ -1297,24 +1390,52 @@ void launch_level1_pass(const Scratch& s, unsigned tm, int T, const PassSrc<K>& 
 }
 }  // namespace
 
+// part A: the tables' segments, pooling factors and verdicts; the dup bitmaps of the hybrid tables
 template <typename K>
-hipError_t seg_sort_pairs(const SegSortRequest& rq, int mode, K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t* bag_of,
-                          void* scratch, hipStream_t stream) {
+hipError_t seg_sort_part_a(const SegSortRequest& rq, void* scratch, hipStream_t stream) {
+    if (rq.N == 0) return hipSuccess;
+    if (rq.T < 1 || rq.T > kSegSortMaxTables || rq.N > 0xffffffffLL) return hipErrorInvalidValue;
+    const size_t n = static_cast<size_t>(rq.N);
+    const Scratch s = scratch_layout(scratch, n, rq.T);
+    HybArgs hyb = rq.hyb;
+    if (rq.weighted) hyb.allow = 0;
+    hipLaunchKernelGGL(seg_prep_tables_kernel, dim3(rq.T), dim3(1024), 0, stream, rq.indices, rq.offsets, rq.idx64, rq.rows, rq.T, rq.B, rq.N,
+                       rq.bag_begin, rq.bag_count, rq.weighted ? 1 : 0, s.desc, rq.zero4, hyb, s.hyb_tab);
+    if (hyb.allow) {
+        static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(hyb_mark_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       2 * kBloomWords * 4) == hipSuccess;
+        if (!lds_ok) return hipErrorInvalidValue;
+        const int th = rq.T < kHybMaxTables ? rq.T : kHybMaxTables;
+        const unsigned grid = static_cast<unsigned>(kXcds * kBloomK * ((th + kXcds - 1) / kXcds));
+        hipLaunchKernelGGL(hyb_mark_kernel, dim3(grid), dim3(kMarkThreads), 2 * kBloomWords * 4, stream, s.desc, s.hyb_tab, rq.indices, rq.idx64, th,
+                           s.bloom);
+    }
+    return hipGetLastError();
+}
+
+template <typename K>
+hipError_t seg_sort_part_b(const SegSortRequest& rq, int mode, K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t* bag_of,
+                           void* scratch, hipStream_t stream, HybTiles tiles) {
     if (rq.N == 0) return hipSuccess;
     if (rq.T < 1 || rq.T > kSegSortMaxTables || rq.N > 0xffffffffLL) return hipErrorInvalidValue;
     const size_t n = static_cast<size_t>(rq.N);
     const Scratch s = scratch_layout(scratch, n, rq.T);
     const unsigned tm = static_cast<unsigned>(tiles_max(n, rq.T));
-    hipLaunchKernelGGL(seg_prep_tables_kernel, dim3(rq.T), dim3(1024), 0, stream, rq.offsets, rq.idx64, rq.rows, rq.T, rq.B, rq.N,
-                       rq.bag_begin, rq.bag_count, rq.weighted ? 1 : 0, s.desc, rq.zero4);
+    if (rq.hyb.allow && !rq.weighted) {
+        // the flagged lookups of the hybrid tables (listed per tile by the bag-major apply) become those tables' segments of built pairs
+        if (tiles.tiles_per_table < 1 || tiles.tiles_per_table > kCompactMaxTiles) return hipErrorInvalidValue;
+        const int th = rq.T < kHybMaxTables ? rq.T : kHybMaxTables;
+        hipLaunchKernelGGL((hyb_compact_kernel<K>), dim3(th * kCompactParts), dim3(kT), 0, stream, s.desc, s.hyb_tab, th, s.tile_cnt,
+                           tile_cnt_stride(n), tiles, keys_b, vals_b, keys_a, vals_a);
+    }
     {
         const int chunks = rq.bag_count > 0 ? static_cast<int>((rq.bag_count + kBuildBags - 1) / kBuildBags) : 0;
         const dim3 gp(1u + static_cast<unsigned>(chunks) * static_cast<unsigned>(rq.T));
         if (rq.weighted)
-            hipLaunchKernelGGL((seg_prep_scan_kernel<K, true>), gp, dim3(1024), 0, stream, s.desc, rq.T, s.hdr, s.tiles, tm, rq.indices,
+            hipLaunchKernelGGL((seg_prep_scan_kernel<K, true>), gp, dim3(1024), 0, stream, s.desc, rq.T, s.hdr, s.tickets, s.tiles, tm, rq.indices,
                                rq.offsets, rq.idx64, rq.B, rq.N, rq.bag_begin, rq.bag_count, rq.tshift, keys_a, vals_a, bag_of, chunks);
         else
-            hipLaunchKernelGGL((seg_prep_scan_kernel<K, false>), gp, dim3(1024), 0, stream, s.desc, rq.T, s.hdr, s.tiles, tm, rq.indices,
+            hipLaunchKernelGGL((seg_prep_scan_kernel<K, false>), gp, dim3(1024), 0, stream, s.desc, rq.T, s.hdr, s.tickets, s.tiles, tm, rq.indices,
                                rq.offsets, rq.idx64, rq.B, rq.N, rq.bag_begin, rq.bag_count, rq.tshift, keys_a, vals_a, bag_of, chunks);
     }
     // pass 0 reads the request (or the built keys in the a buffers) and writes the b buffers; later passes alternate, so the
@@ -1329,8 +1450,9 @@ hipError_t seg_sort_pairs(const SegSortRequest& rq, int mode, K* keys_a, K* keys
     src.tshift = rq.tshift;
     src.bag_begin = static_cast<uint32_t>(rq.bag_begin);
     if (lookback) {
-        if (rb == 9) launch_lookback<K, 9>(s, tm, rq.T, src, total, keys_a, keys_b, vals_a, vals_b, stream);
-        else launch_lookback<K, 8>(s, tm, rq.T, src, total, keys_a, keys_b, vals_a, vals_b, stream);
+        const uint32_t cap = rq.spin_cap ? rq.spin_cap : kLbSpinCap;
+        if (rb == 9) launch_lookback<K, 9>(s, tm, rq.T, src, total, keys_a, keys_b, vals_a, vals_b, cap, stream);
+        else launch_lookback<K, 8>(s, tm, rq.T, src, total, keys_a, keys_b, vals_a, vals_b, cap, stream);
         return hipGetLastError();
     }
     for (int p = 0; p < total; ++p) {
@@ -1367,9 +1489,21 @@ hipError_t seg_sort_pairs(const SegSortRequest& rq, int mode, K* keys_a, K* keys
     return hipGetLastError();
 }
 
-template hipError_t seg_sort_pairs<uint32_t>(const SegSortRequest&, int, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, void*,
-                                             hipStream_t);
-template hipError_t seg_sort_pairs<uint64_t>(const SegSortRequest&, int, uint64_t*, uint64_t*, uint32_t*, uint32_t*, uint32_t*, void*,
-                                             hipStream_t);
+template <typename K>
+hipError_t seg_sort_pairs(const SegSortRequest& rq, int mode, K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t* bag_of,
+                          void* scratch, hipStream_t stream) {
+    if (rq.hyb.allow) return hipErrorInvalidValue;      // the hybrid form's part B belongs to the apply call
+    const hipError_t rc = seg_sort_part_a<K>(rq, scratch, stream);
+    if (rc != hipSuccess) return rc;
+    return seg_sort_part_b<K>(rq, mode, keys_a, keys_b, vals_a, vals_b, bag_of, scratch, stream, HybTiles{0, 0});
+}
+
+#define PM_SEG_INST(K_)                                                                                                              \
+    template hipError_t seg_sort_part_a<K_>(const SegSortRequest&, void*, hipStream_t);                                              \
+    template hipError_t seg_sort_part_b<K_>(const SegSortRequest&, int, K_*, K_*, uint32_t*, uint32_t*, uint32_t*, void*, hipStream_t, HybTiles); \
+    template hipError_t seg_sort_pairs<K_>(const SegSortRequest&, int, K_*, K_*, uint32_t*, uint32_t*, uint32_t*, void*, hipStream_t);
+PM_SEG_INST(uint32_t)
+PM_SEG_INST(uint64_t)
+#undef PM_SEG_INST
 
 }  // namespace pm

@@ -276,6 +276,18 @@ def sorted_pairs(ts: _TableSet, indices, offsets, B, psw=None, bag_begin=0, bag_
     return k, v, tsh.value
 
 
+def sort_status(ts: _TableSet, indices, offsets, B, psw=None, bag_begin=0, bag_count=None) -> dict:
+    """What the last ``_sort_indices`` / backward on this table set's workspace left on the device (``pm_embbag_sort_status``;
+    SYNCHRONISES): ``lookback_timeouts`` (non-zero raises :class:`ParamAmdError` -- the apply then left the tables untouched),
+    ``pairs_sorted``, ``hybrid_tables``, ``hybrid_launched``."""
+    op = ts.request(indices, offsets, B, psw, bag_begin, bag_count)
+    ws = _workspace(ts, op)
+    st = _lib.pm_sort_status()
+    _lib.check(_lib.load().pm_embbag_sort_status(ctypes.byref(op), max(ts.rows), ws.data_ptr(), ctypes.byref(st), _stream_ptr()))
+    return {"lookback_timeouts": st.lookback_timeouts, "pairs_sorted": st.pairs_sorted, "hybrid_tables": st.hybrid_tables,
+            "hybrid_launched": st.hybrid_launched}
+
+
 def _bwd(ts: _TableSet, grad, indices, offsets, B, dst_ptrs_dev, dst_dtype, alpha, psw=None,
          bag_begin=0, bag_count=None, method: str = "sorted", presorted: bool = False, pooling: Optional[int] = None):
     """``method="sorted"`` (default): deterministic, bit-identical to a sequential scatter-add;
@@ -550,6 +562,11 @@ class BatchedEmbeddingBagMI355(nn.Module):
         B = self._batch_of(offsets, indices) if batch is None else batch
         _bwd(ts, grad, indices, offsets, B, ts.d_ptrs, self.weights.dtype, alpha, per_sample_weights,
              bag_begin, bag_count, method, presorted, pooling)
+
+    def sort_status(self, indices, offsets, per_sample_weights=None, batch: Optional[int] = None, bag_begin=0, bag_count=None) -> dict:
+        """status of the last key sort on this module's workspace (synchronises; raises if the sort gave up)"""
+        B = self._batch_of(offsets, indices) if batch is None else batch
+        return sort_status(self._tables(), indices, offsets, B, per_sample_weights, bag_begin, bag_count)
 
     def momentum_table(self, t: int) -> torch.Tensor:
         """row-wise Adagrad state of table t (allocated zero on first use)"""

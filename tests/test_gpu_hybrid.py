@@ -1,0 +1,302 @@
+"""Hybrid backward (round 4) and the key sort's failure channel -- GPU parity tests (``pytest -m gpu``), through the C ABI.
+
+Hybrid: tables whose step touches (nearly) every row once skip the sort -- rows looked up once are applied bag-major
+(``bwd_unique_kernel``), only lookups flagged by the four hashed "looked up twice" bitmaps go through the sorted apply.  The bar
+is the sorted backward's: bit-exact against the sequential oracle for every row looked up at most 256 times.
+Reference semantics: fbgemm TBE backward / aten::_embedding_bag_dense_backward at
+train/comms/pt/pytorch_dist_backend.py:854-857, split_table_batched_embeddings_ops.py:318-324.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu_and_lib():
+    import param_amd
+
+    assert torch.cuda.is_available(), "gpu-marked tests need a ROCm device"
+    param_amd.load_library()
+    yield
+    param_amd.set_hybrid_tuning()
+    param_amd.set_sort_tuning()
+
+
+def _model(rows, D, dtype=torch.float32, layout="bd", seed=0):
+    import param_amd
+
+    return param_amd.BatchedEmbeddingBagMI355(rows, D, dtype=dtype, device=DEV, init="normal", layout=layout, seed=seed, fused_update=False)
+
+
+def _request(rows, B, pools, alpha, seed, index_dtype=torch.int64):
+    from param_amd.indices import tbe_request
+
+    return tbe_request(rows, B, pools, alpha=alpha, device=DEV, seed=seed, index_dtype=index_dtype)
+
+
+def _oracle_tables(coracle, tabs, idx, off, B, grad, D, alpha, layout="bd"):
+    out = []
+    idx_h, off_h, g_h = idx.cpu().numpy().astype(np.int64), off.cpu().numpy().astype(np.int64), grad.cpu().numpy()
+    for t, W in enumerate(tabs):
+        s = off_h[t * B]
+        e = off_h[(t + 1) * B] if (t + 1) * B < len(off_h) else len(idx_h)
+        loc = off_h[t * B:(t + 1) * B] - s
+        g = np.ascontiguousarray(g_h[:, t * D:(t + 1) * D]) if layout == "bd" else np.ascontiguousarray(g_h[t])
+        out.append(coracle.bwd_f32(W.copy(), idx_h[s:e], loc, g, alpha=alpha))
+    return out
+
+
+@pytest.mark.parametrize("layout,idt", [("bd", torch.int64), ("tbd", torch.int32)])
+def test_hybrid_uniform_tables_bit_exact_vs_oracle(coracle, layout, idt):
+    """8 uniform-index tables (20 480 lookups into 400 000 rows each: ~2.5 % repeats): every table goes hybrid, every row equals
+    the sequential oracle bit for bit; the same request with the hybrid path off gives the same bits."""
+    import param_amd
+
+    rows, D, B, L = [400_000] * 8, 128, 1024, 20
+    idx, off = _request(rows, B, L, 0.0, 3, idt)
+    gshape = (B, len(rows) * D) if layout == "bd" else (len(rows), B, D)
+    grad = torch.randn(gshape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    results = {}
+    for en in (1, 0):
+        param_amd.set_hybrid_tuning(en)
+        m = _model(rows, D, layout=layout, seed=7)
+        tabs = [m.table(t).cpu().numpy() for t in range(len(rows))]
+        m.scatter_add_(grad, idx, off, alpha=-0.05, batch=B)
+        st = m.sort_status(idx, off, batch=B)
+        torch.cuda.synchronize()
+        assert st["lookback_timeouts"] == 0
+        if en:
+            assert st["hybrid_tables"] == len(rows) and st["hybrid_launched"] == 1, st
+            assert 0 < st["pairs_sorted"] < 0.1 * idx.numel(), st           # only the flagged lookups were sorted
+        else:
+            assert st["hybrid_tables"] == 0 and st["pairs_sorted"] == idx.numel(), st
+        results[en] = [m.table(t).cpu().numpy() for t in range(len(rows))]
+        if en:
+            exp = _oracle_tables(coracle, tabs, idx, off, B, grad, D, -0.05, layout)
+            for t in range(len(rows)):
+                assert np.array_equal(results[en][t], exp[t]), t
+    for t in range(len(rows)):
+        assert np.array_equal(results[1][t], results[0][t]), t
+
+
+def test_hybrid_forced_on_skewed_and_mixed_tables(coracle):
+    """enable = 2 sends every structurally eligible table down the hybrid path whatever its indices look like: Zipf tables (most
+    lookups flagged, hot rows in long runs), a table too small to qualify, one with too many lookups per row.  Rows looked up at
+    most 256 times must equal the oracle bit for bit; the default classification (enable = 1) must give the same bits."""
+    import param_amd
+
+    rows = [300_000, 300_000, 5_000, 60_000, 300_000, 300_000]
+    pools = [20, 20, 20, 20, 9, 20]
+    alphas = [1.05, 0.0, 0.0, 0.0, 1.05, 0.0]
+    D, B = 64, 1024
+    from param_amd.indices import tbe_request
+
+    parts = [tbe_request([r], B, [p], alpha=a, device=DEV, seed=11 + i)[0] for i, (r, p, a) in enumerate(zip(rows, pools, alphas))]
+    idx = torch.cat(parts)
+    lens = torch.cat([torch.full((B,), p, dtype=torch.int64, device=DEV) for p in pools])
+    off = torch.zeros(len(rows) * B + 1, dtype=torch.int64, device=DEV)
+    torch.cumsum(lens, 0, out=off[1:])
+    grad = torch.randn((B, len(rows) * D), device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+    got = {}
+    for en in (2, 1):
+        param_amd.set_hybrid_tuning(en)
+        m = _model(rows, D, seed=9)
+        tabs = [m.table(t).cpu().numpy() for t in range(len(rows))]
+        m.scatter_add_(grad, idx, off, alpha=0.25, batch=B)
+        st = m.sort_status(idx, off, batch=B)
+        got[en] = [m.table(t).cpu().numpy() for t in range(len(rows))]
+        if en == 2:
+            assert st["hybrid_tables"] == 4, st          # tables 0, 1, 4 (9216 lookups >= 8192), 5; not 2 (tiny) nor 3 (20480 * 8 > 60000)
+            exp = _oracle_tables(coracle, tabs, idx, off, B, grad, D, 0.25)
+            idx_h, off_h = idx.cpu().numpy(), off.cpu().numpy()
+            for t in range(len(rows)):
+                cnt = np.bincount(idx_h[off_h[t * B]:off_h[(t + 1) * B]], minlength=rows[t])
+                cold = cnt <= 256
+                assert np.array_equal(got[en][t][cold], exp[t][cold]), t
+                hot = ~cold
+                if hot.any():
+                    np.testing.assert_allclose(got[en][t][hot], exp[t][hot], rtol=2e-4, atol=2e-4)
+        else:
+            assert st["hybrid_tables"] == 2, st          # the two uniform tables that qualify (1 and 5)
+    idx_h, off_h = idx.cpu().numpy(), off.cpu().numpy()
+    for t in range(len(rows)):
+        # rows looked up more than 256 times are summed as ordered chunk partials, and which lookups share a chunk depends on what
+        # else is in the sorted arrays: same value up to fp32 association (the documented contract), same bits everywhere else
+        cold = np.bincount(idx_h[off_h[t * B]:off_h[(t + 1) * B]], minlength=rows[t]) <= 256
+        assert np.array_equal(got[2][t][cold], got[1][t][cold]), t
+        np.testing.assert_allclose(got[2][t][~cold], got[1][t][~cold], rtol=2e-4, atol=2e-4)
+
+
+def test_hybrid_bf16_tables_and_batch_slices(coracle):
+    """bf16 tables (widened, one rounding per row) and a request applied as two batch slices, hybrid on vs off: same bits"""
+    import param_amd
+
+    rows, D, B, L = [250_000] * 4, 128, 2048, 10
+    idx, off = _request(rows, B, L, 0.0, 5)
+    grad = torch.randn((B, len(rows) * D), device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    res = {}
+    for en in (1, 0):
+        param_amd.set_hybrid_tuning(en)
+        m = _model(rows, D, dtype=torch.bfloat16, seed=4)
+        m.scatter_add_(grad, idx, off, alpha=-0.5, batch=B, bag_begin=0, bag_count=1500)
+        if en:
+            assert m.sort_status(idx, off, batch=B, bag_begin=0, bag_count=1500)["hybrid_tables"] == 4
+        m.scatter_add_(grad, idx, off, alpha=-0.5, batch=B, bag_begin=1500, bag_count=B - 1500)
+        res[en] = m.weights.data.view(torch.int16).cpu().numpy().copy()
+    assert np.array_equal(res[1], res[0])
+    # and against the oracle's bf16 routine for table 0, whole batch in one call
+    param_amd.set_hybrid_tuning(1)
+    m = _model(rows, D, dtype=torch.bfloat16, seed=4)
+    W0 = m.table(0).view(torch.int16).cpu().numpy().view(np.uint16).copy()
+    m.scatter_add_(grad, idx, off, alpha=-0.5, batch=B)
+    idx_h, off_h = idx.cpu().numpy(), off.cpu().numpy()
+    exp = coracle.bwd_bf16(W0, idx_h[:off_h[B]], off_h[:B], np.ascontiguousarray(grad.cpu().numpy()[:, :D]), alpha=-0.5)
+    assert np.array_equal(m.table(0).view(torch.int16).cpu().numpy().view(np.uint16), exp)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_hybrid_rowwise_adagrad_same_bits_as_sorted_path(coracle, dtype):
+    """fused row-wise Adagrad (weight decay L2, the reference's TBE optimizer settings) through the hybrid path == through the
+    sorted path, tables and optimizer state, bit for bit; fp32 also against the oracle"""
+    import param_amd
+
+    rows, D, B, L = [200_000] * 3, 128, 1024, 12
+    idx, off = _request(rows, B, L, 0.0, 8)
+    grad = torch.randn((B, len(rows) * D), device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
+    res = {}
+    for en in (1, 0):
+        param_amd.set_hybrid_tuning(en)
+        m = _model(rows, D, dtype=dtype, seed=6)
+        m.optimizer, m.learning_rate, m.eps, m.weight_decay, m.weight_decay_mode = "rowwise_adagrad", 0.05, 1e-8, 0.01, "l2"
+        W0 = m.table(0).float().cpu().numpy().copy()
+        for _ in range(2):
+            m.adagrad_step_(grad, idx, off, batch=B)
+        if en:
+            assert m.sort_status(idx, off, batch=B)["hybrid_tables"] == 3
+        res[en] = (m.weights.data.float().cpu().numpy().copy(), m.momentum.cpu().numpy().copy())
+    assert np.array_equal(res[1][0], res[0][0]) and np.array_equal(res[1][1], res[0][1])
+    if dtype == torch.float32:
+        idx_h, off_h = idx.cpu().numpy(), off.cpu().numpy()
+        g0 = np.ascontiguousarray(grad.cpu().numpy()[:, :D])
+        W, mom = W0.copy(), np.zeros(rows[0], dtype=np.float32)
+        for _ in range(2):
+            W, mom = coracle.bwd_rowwise_adagrad(W, mom, idx_h[:off_h[B]], off_h[:B], g0, lr=0.05, eps=1e-8, weight_decay=0.01,
+                                                 weight_decay_mode=1)
+        got = res[1][0].reshape(-1)[:rows[0] * D].reshape(rows[0], D)
+        np.testing.assert_allclose(got, W, rtol=2e-5, atol=1e-6)
+
+
+def test_the_path_taken_depends_on_the_request_alone():
+    """Which tables go hybrid is decided on the device from the request itself -- nothing is cached or carried over: uniform and
+    Zipf requests alternating on ONE workspace take the same paths (and leave the same bits) as each of them on a fresh one."""
+    import param_amd
+
+    rows, D, B, L = [400_000] * 8, 32, 1024, 20
+    uni = _request(rows, B, L, 0.0, 1)
+    zipf = _request(rows, B, L, 1.05, 2)
+    grad = torch.randn((B, len(rows) * D), device=DEV)
+    param_amd.set_hybrid_tuning(1)
+    m = _model(rows, D, seed=1)
+    seq = [("u", uni), ("z", zipf), ("z", zipf), ("u", uni), ("u", uni)]
+    seen = []
+    for tag, (i, o) in seq:
+        m.scatter_add_(grad, i, o, alpha=-0.01, batch=B)
+        st = m.sort_status(i, o, batch=B)
+        seen.append((tag, st["hybrid_launched"], st["hybrid_tables"]))
+    assert seen == [("u", 1, 8), ("z", 1, 0), ("z", 1, 0), ("u", 1, 8), ("u", 1, 8)], seen
+    ref = _model(rows, D, seed=1)
+    for tag, (i, o) in seq:
+        fresh = _model(rows, D, seed=1)                      # a fresh module = a fresh workspace
+        fresh.weights.data.copy_(ref.weights.data)
+        fresh.scatter_add_(grad, i, o, alpha=-0.01, batch=B)
+        ref.weights.data.copy_(fresh.weights.data)
+    assert torch.equal(m.weights.data, ref.weights.data)
+
+
+def test_forced_lookback_timeout_is_an_error_never_a_wrong_table():
+    """The failure channel of the look-back sort.  lookback_spin_cap = 0xFFFFFFFF makes every tile that looks back report a
+    time-out (deterministic); = 1 makes a walk give up at the first predecessor that is not published yet (may or may not
+    happen).  Either way: a sort that reported time-outs makes pm_embbag_sort_status fail with PM_ERR_SORT and the apply leaves
+    the table UNTOUCHED; a run without time-outs must be correct.  Never a silently wrong table."""
+    import param_amd
+    from param_amd import _lib
+
+    rows, D, B, L = [2_000_000], 16, 65536, 16          # one segment of 256 radix tiles
+    idx, off = _request(rows, B, L, 1.05, 13)
+    grad = torch.randn((B, D), device=DEV)
+    param_amd.set_hybrid_tuning(0)
+    good = _model(rows, D, seed=2)
+    good.scatter_add_(grad, idx, off, alpha=1.0, batch=B)
+    assert good.sort_status(idx, off, batch=B)["lookback_timeouts"] == 0
+    failed = 0
+    for cap in (0xFFFFFFFF, 1, 1, 1):
+        param_amd.set_hybrid_tuning(0, cap)
+        m = _model(rows, D, seed=2)
+        before = m.weights.data.clone()
+        m.scatter_add_(grad, idx, off, alpha=1.0, batch=B)
+        try:
+            m.sort_status(idx, off, batch=B)
+            assert cap == 1
+            assert torch.equal(m.weights.data, good.weights.data)
+        except param_amd.ParamAmdError as exc:
+            assert exc.code == _lib.PM_ERR_SORT
+            failed += 1
+            assert torch.equal(m.weights.data, before)          # untouched
+            # recovery: the same order from kernels that never wait for each other
+            param_amd.set_hybrid_tuning(0, 0)
+            param_amd.set_sort_tuning(3)
+            m.scatter_add_(grad, idx, off, alpha=1.0, batch=B)
+            assert m.sort_status(idx, off, batch=B)["lookback_timeouts"] == 0
+            param_amd.set_sort_tuning(-1)
+            assert torch.equal(m.weights.data, good.weights.data)
+    param_amd.set_hybrid_tuning(0, 0)
+    assert failed >= 1
+
+
+def test_lookback_sort_on_a_cu_masked_stream_beside_a_saturating_forward():
+    """The look-back sort on a 32-CU-masked stream while a full-size forward saturates the default stream, 200 times: the sorted
+    pairs equal numpy's stable order and no walk ever times out (tiles are taken by ticket, so the sort's progress does not
+    depend on how the dispatcher interleaves its workgroups with the forward's)."""
+    import param_amd
+    from bench import masked_stream
+    from param_amd.embedding_bag import _sort_indices, sorted_pairs
+
+    param_amd.set_hybrid_tuning(0)
+    big_rows, D, B, L = [4_000_000] * 8, 128, 8192, 20
+    big = _model(big_rows, D, seed=3)
+    bi, bo = _request(big_rows, B, L, 0.0, 21)
+    out = torch.empty((B, len(big_rows) * D), device=DEV)
+    rows = [1_000_000] * 4
+    sm = _model(rows, 16, seed=4)
+    si, so = _request(rows, 16384, 10, 1.05, 22)              # 4 segments of 40 tiles
+    ts = sm._tables()
+    ms = masked_stream(32, torch.device(DEV))
+    keys_h = si.cpu().numpy()
+    n1 = 16384 * 10
+    expect = []
+    for t in range(len(rows)):
+        seg = keys_h[t * n1:(t + 1) * n1]
+        order = np.argsort(seg, kind="stable")
+        expect.append(((t << 20) | seg[order], order // 10))
+    for it in range(200):
+        for _ in range(3):
+            big.lookup(bi, bo, out=out, batch=B)
+        ms.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(ms):
+            _sort_indices(ts, si, so, 16384)
+        for _ in range(3):
+            big.lookup(bi, bo, out=out, batch=B)
+        torch.cuda.current_stream().wait_stream(ms)
+        if it % 20 == 0 or it == 199:
+            st = sm.sort_status(si, so, batch=16384)
+            assert st["lookback_timeouts"] == 0, (it, st)
+            k, v, tsh = sorted_pairs(ts, si, so, 16384)
+            assert tsh == 20
+            k, v = k.cpu().numpy(), v.cpu().numpy()
+            for t in range(len(rows)):
+                assert np.array_equal(k[t * n1:(t + 1) * n1], expect[t][0]) and np.array_equal(v[t * n1:(t + 1) * n1], expect[t][1]), (it, t)

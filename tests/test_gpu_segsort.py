@@ -24,7 +24,11 @@ def _need_gpu_and_lib():
 
     assert torch.cuda.is_available(), "gpu-marked tests need a ROCm device"
     param_amd.load_library()
+    # these tests read the sorted pairs of a BARE sort; while the hybrid backward's kernels are launched the sort finishes inside
+    # the apply call (include/param_amd.h, pm_set_hybrid_tuning), so they run with it off (tests/test_gpu_hybrid.py covers it)
+    param_amd.set_hybrid_tuning(0)
     yield
+    param_amd.set_hybrid_tuning()
     param_amd.set_backward_tuning()
     param_amd.set_sort_tuning()
 
