@@ -43,8 +43,7 @@ enum {
     PM_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, bad dtype) */
     PM_ERR_UNSUPPORTED = -2, /* valid but not implemented (e.g. dim not a multiple of the vector width) */
     PM_ERR_HIP = -3,         /* a HIP runtime call failed; message carries hipGetErrorString */
-    PM_ERR_INDEX = -4,       /* pm_embbag_check found an out-of-range index or a bad offset */
-    PM_ERR_SORT = -5         /* pm_embbag_sort_status: the key sort gave up; the apply left the tables untouched */
+    PM_ERR_INDEX = -4        /* pm_embbag_check found an out-of-range index or a bad offset */
 };
 
 /*
@@ -188,21 +187,20 @@ int pm_embbag_sorted_pairs(const pm_embbag_batch* op, int64_t max_rows, const vo
                            const uint32_t** vals, const uint32_t** d_count, int32_t* key_bytes, int32_t* tshift);
 
 /*
- * ABI v5.  What the last pm_embbag_sort_indices* on this workspace left on the device -- SYNCHRONOUS (copies a few words back
- * and waits for `stream`), for callers that want certainty, tests and bench lines:
- *   lookback_timeouts  look-back walks of the key sort that gave up waiting for a predecessor tile (a workgroup stalled for
- *                      ~a second: tiles are taken by ticket, so only a hung device gets here).  Non-zero: the sorted pairs are
- *                      not trustworthy, pm_embbag_bwd_sorted* on this sort have left the tables UNTOUCHED (their kernels check
- *                      the same word), and this call returns PM_ERR_SORT.  Recovery: sort again -- pm_set_sort_tuning(3) is the
- *                      same order without inter-workgroup waits -- and apply again.
+ * ABI v5.  What the last sort / apply on this workspace left on the device -- SYNCHRONOUS (copies a few words back and waits
+ * for `stream`); for tests, tools and bench lines:
+ *   lookback_fallbacks look-back walks of the key sort that stopped waiting for a predecessor tile's published digit counts and
+ *                      counted that tile's digits themselves.  Harmless (the result is the same): it is how the one-kernel
+ *                      passes make progress without assuming anything about the order in which workgroups are dispatched;
+ *                      expected 0 on an otherwise idle device
  *   pairs_sorted       lookups that went through the sort (all of them, or the hybrid path's left-overs)
  *   hybrid_tables      tables whose step took the hybrid path (rows looked up once applied bag-major, see pm_set_hybrid_tuning)
  *   hybrid_launched    0: the hybrid kernels were not launched for this sort (off, weighted or tiny request); else the mode they ran in
- * Replaces nothing of the reference: it is the error channel of the replacement for the sort inside
- * aten::_embedding_bag_dense_backward (call sites as pm_embbag_bwd_sorted).
+ * Replaces nothing of the reference: it reports on the replacement for the sort inside aten::_embedding_bag_dense_backward
+ * (call sites as pm_embbag_bwd_sorted).
  */
 typedef struct pm_sort_status {
-    uint32_t lookback_timeouts;
+    uint32_t lookback_fallbacks;
     uint32_t pairs_sorted;
     uint32_t hybrid_tables;
     uint32_t hybrid_launched;
@@ -360,9 +358,9 @@ int pm_set_sort_tuning(int32_t mode);
  *   enable   -1 default (= 1); 0 off; 1 on: the tables are classified at every sort, on the device, from the request alone (so
  *            the same request always takes the same path: nothing is cached or carried from step to step); 2 every structurally
  *            eligible table goes hybrid whatever its indices look like (tests)                         PARAM_AMD_BWD_HYBRID
- *   lookback_spin_cap  polls before a look-back walk of the key sort gives up; 0 = default (2^20).  Tests: 1 makes a walk give
- *            up at the first unpublished predecessor; 0xFFFFFFFF makes every tile that looks back report a time-out
- *            (pm_embbag_sort_status then fails, the apply leaves the tables untouched).
+ *   lookback_spin_cap  polls before a look-back walk of the key sort stops waiting for a predecessor and counts that tile's digits
+ *            itself; 0 = default (2^12).  Tests: 1 = the fallback runs wherever a predecessor is a moment late; 0xFFFFFFFF = it
+ *            runs for every predecessor of every tile (nothing published is believed).
  * While the hybrid kernels are launched for a sort, pm_embbag_sort_indices* runs only the classification and the bitmaps; the
  * rest of the sort (of the flagged lookups, and of every lookup of the tables that did not qualify) runs inside the apply
  * call, behind the bag-major kernel, which lists the flagged lookups as a by-product.  pm_embbag_sorted_pairs is then

@@ -12,7 +12,7 @@ import os
 import threading
 
 PM_F32, PM_BF16, PM_F16, PM_I32, PM_I64 = 0, 1, 2, 10, 11
-PM_OK, PM_ERR_INVALID, PM_ERR_UNSUPPORTED, PM_ERR_HIP, PM_ERR_INDEX, PM_ERR_SORT = 0, -1, -2, -3, -4, -5
+PM_OK, PM_ERR_INVALID, PM_ERR_UNSUPPORTED, PM_ERR_HIP, PM_ERR_INDEX = 0, -1, -2, -3, -4
 PM_ABI_VERSION = 5
 PM_WD_NONE, PM_WD_L2, PM_WD_DECOUPLE = 0, 1, 2
 
@@ -73,7 +73,7 @@ class pm_sort_status(ctypes.Structure):
     """Mirror of ``struct pm_sort_status`` (include/param_amd.h)."""
 
     _fields_ = [
-        ("lookback_timeouts", ctypes.c_uint32),
+        ("lookback_fallbacks", ctypes.c_uint32),
         ("pairs_sorted", ctypes.c_uint32),
         ("hybrid_tables", ctypes.c_uint32),
         ("hybrid_launched", ctypes.c_uint32),
@@ -245,5 +245,5 @@ def set_sort_tuning(mode: int = -1) -> None:
 def set_hybrid_tuning(enable: int = -1, lookback_spin_cap: int = 0) -> None:
     """``pm_set_hybrid_tuning``: the hybrid backward (rows looked up once are applied bag-major, only the repeats are sorted).
     enable 0 off / 1 on (default; tables classified on the device at every sort) / 2 every structurally eligible table (tests);
-    lookback_spin_cap > 0 lowers the key sort's look-back poll limit (tests)."""
+    lookback_spin_cap > 0 lowers the number of polls after which a look-back walk counts for its predecessor (tests)."""
     check(load().pm_set_hybrid_tuning(enable, lookback_spin_cap))

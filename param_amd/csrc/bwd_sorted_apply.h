@@ -58,8 +58,6 @@ struct SortedParams {
     int32_t xcd;             // 1: XCD-affine block -> tile mapping (needs seg_tiles); 2: XCD-contiguous (any request)
     const uint32_t* d_n;     // not NULL: the number of sorted pairs lives on the device (<= n), written by the segmented sort
     int32_t unique_wgs_per_cu;   // bag-major apply: > 0 = a grid of this many workgroups per CU that loop over the tiles (0: one per tile)
-    const uint32_t* d_bad;   // not NULL: device word that is non-zero when the sort gave up (look-back time-outs): the apply kernels
-                             // then leave the tables untouched (pm_embbag_sort_status tells the host)
 };
 
 

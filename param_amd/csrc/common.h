@@ -194,10 +194,13 @@ constexpr int kBloomTableWords = kBloomK * kBloomWords;   // 65 536 words = 256 
 constexpr uint32_t kHybMaxCount = 1u << 18;     // lookups per table beyond which a 2^21-bit map flags too many unique rows
 constexpr uint32_t kHybMinCount = 8192;         // ... and below which a table is not worth three extra kernels
 struct HybTable {            // one per table (device): written by the sort's first kernel and by the compaction
-    uint32_t mode;           // 0: every lookup through the sort; 1: hybrid
+    uint32_t mode;           // 0: every lookup through the sort; 1: hybrid.  Final verdict, written by hyb_mark_kernel's first workgroup
     uint32_t pooling;        // the table's pooling factor (hybrid tables have one)
     uint32_t n_dup;          // lookups left to the sort (hybrid tables: written by hyb_compact_kernel)
-    uint32_t pad;
+    uint32_t cand;           // the table qualifies on its own (seg_prep_tables_kernel); it goes hybrid if the qualifying tables
+                             // together hold at least half of the request's lookups -- the mark + bag-major kernels have fixed
+                             // costs that a few small tables do not repay (Criteo uniform: 5 of 26 tables, 24 % of the lookups,
+                             // 0.49 -> 0.57 ms)
 };
 __host__ __device__ inline uint32_t bloom_word(uint32_t row) { return (row * 0x9E3779B1u) >> 16; }     // 0 .. kBloomTableWords - 1
 __host__ __device__ inline uint32_t bloom_mask(uint32_t row) {

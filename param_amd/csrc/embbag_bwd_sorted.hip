@@ -177,7 +177,7 @@ bool table_major_order() { return knob(g_sort_order, env_is("PARAM_AMD_SORT_ORDE
 // hybrid backward (pm_set_hybrid_tuning; common.h "Hybrid backward"):
 //   enable   0 off; 1 (default) on: every table is classified on the device at every sort, from the request alone; 2 every
 //            structurally eligible table takes the hybrid path whatever its indices look like (tests)   PARAM_AMD_BWD_HYBRID=0..2
-//   spin_cap look-back polls before a walk gives up (0 = default 2^20; tests: 1, 0xFFFFFFFF)
+//   spin_cap look-back polls before a walk stops waiting and counts its predecessor's digits itself (0 = default 2^12; tests: 1)
 // (Round 4 also built the rest of the sort + the sorted apply of the flagged lookups on a second, library-owned stream beside
 //  the bag-major apply -- disjoint rows -- and measured it: the small kernels do run concurrently, and starve: the 54 us emit
 //  pass took 1.26 ms beside the chip-filling kernel, which itself went from 1.45 to 1.72 ms.  Removed; profiles/r04_*.)
@@ -553,7 +553,6 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
     sp.phase = 0;
     sp.xcd = g.xcd ? (g.v2 ? 2 : 1) : 0;
     sp.d_n = g.v2 ? seg_sort_count(ws.temp, static_cast<size_t>(p.N), p.T) : nullptr;
-    sp.d_bad = g.v2 ? seg_sort_timeouts(ws.temp, static_cast<size_t>(p.N), p.T) : nullptr;
     sp.tile = g.v2 ? apply_tile(p.N) : kSortTile;      // round 2's plans (segments per table, phases) are laid out for 1024
     {
         static const int wgs = env_int("PARAM_AMD_UNIQUE_WGS_PER_CU", 0);      // experiments: the bag-major kernel as a looping grid
@@ -583,13 +582,22 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
     ua.key_bytes = g.key_bytes;
     ua.tile_cnt = seg_sort_tile_cnt(ws.temp, static_cast<size_t>(p.N), p.T);
     ua.tile_cnt_stride = seg_sort_tile_cnt_stride(static_cast<size_t>(p.N));
+    // The bag-major kernel's tiles hold at least 32 bags whatever the forward's tiling of the request (short-bag requests tile by 8
+    // bags: 26 624 workgroups for the Criteo request, most of which find a table that did not qualify and leave -- 15 us of
+    // dispatch); a hybrid table's tile of 32 bags is at most 32 x 32 lookups (kHybMaxCount / bags), inside the LDS index tile.
+    KParams q = p;
+    if (q.bags_per_block < 32) {
+        q.bags_per_block = 32;
+        q.tiles_per_table = static_cast<int32_t>((q.bag_count + 31) / 32);
+        q.idx_cap = 4096;
+    }
     switch (dst_dtype) {
-        case PM_F32: rc = bwd_unique_launch_f32(sp, p, ua, max_dim, stream); break;
-        case PM_BF16: rc = bwd_unique_launch_bf16(sp, p, ua, max_dim, stream); break;
-        default: rc = bwd_unique_launch_f16(sp, p, ua, max_dim, stream); break;
+        case PM_F32: rc = bwd_unique_launch_f32(sp, q, ua, max_dim, stream); break;
+        case PM_BF16: rc = bwd_unique_launch_bf16(sp, q, ua, max_dim, stream); break;
+        default: rc = bwd_unique_launch_f16(sp, q, ua, max_dim, stream); break;
     }
     if (rc != hipSuccess) return rc;
-    const HybTiles tiles{p.bags_per_block, p.tiles_per_table};
+    const HybTiles tiles{q.bags_per_block, q.tiles_per_table};
     if (g.key_bytes == 4) {
         const SegSortRequest rq = seg_request<uint32_t>(p, g, ws);
         rc = seg_sort_part_b<uint32_t>(rq, g.mode, reinterpret_cast<uint32_t*>(ws.keys_a), reinterpret_cast<uint32_t*>(ws.keys_b), ws.vals_a,

@@ -60,7 +60,7 @@ struct SegHeader {
     uint32_t n_tiles;    // radix tiles of the first level
     uint32_t n_l2;       // buckets on the second-level list (= second-level segments)
     uint32_t n_tiles2;   // radix tiles of the second level
-    uint32_t lookback_timeouts;   // look-back walks that gave up (a predecessor stalled for ~a second: the apply kernels refuse such a sort)
+    uint32_t lookback_timeouts;   // look-back walks that stopped waiting and counted a predecessor tile's digits themselves (a statistic)
     uint32_t pad[11];
 };
 
@@ -221,9 +221,10 @@ __global__ void __launch_bounds__(1024) seg_prep_tables_kernel(const void* indic
         }
         if (threadIdx.x == 0) {
             HybTable h;
-            h.mode = (cand && hyb.allow) ? 1u : 0u;
+            h.mode = 0u;                                      // (final verdict: hyb_mark_kernel)
+            h.cand = (cand && hyb.allow) ? 1u : 0u;
             h.pooling = bad ? 0u : static_cast<uint32_t>(L);
-            h.n_dup = h.pad = 0u;
+            h.n_dup = 0u;
             hyb_tab[t] = h;
         }
     }
@@ -292,7 +293,7 @@ __device__ __forceinline__ void build_keys_chunk(int t, int chunk, const void* i
 // workgroups of the launch build the (key, bag) pairs of the tables without a pooling factor (one workgroup per 1024 bags of a
 // table; they exit at once for tables that have one) -- the two jobs need only prep 1's results, and a launch saved is ~6 us.
 template <typename K, bool WEIGHTED>
-__global__ void __launch_bounds__(1024) seg_prep_scan_kernel(SegDesc* desc, int T, SegHeader* hdr, uint32_t* tickets, TileDesc* tiles, uint32_t tiles_cap,
+__global__ void __launch_bounds__(1024) seg_prep_scan_kernel(SegDesc* desc, int T, SegHeader* hdr, TileDesc* tiles, uint32_t tiles_cap,
                                                              const void* indices, const void* offsets, int idx64, int64_t B, int64_t N,
                                                              int64_t bag_begin, int64_t bag_count, int tshift, K* keys, uint32_t* vals,
                                                              uint32_t* bag_of, int chunks_per_table) {
@@ -327,10 +328,6 @@ __global__ void __launch_bounds__(1024) seg_prep_scan_kernel(SegDesc* desc, int 
         hdr->n_l2 = 0;
         hdr->n_tiles2 = 0;
         hdr->lookback_timeouts = 0;
-    }
-    if (t < T) {
-#pragma unroll
-        for (int i = 0; i < kMaxLbPasses; ++i) tickets[i * T + t] = 0u;       // look-back passes: next tile of table t to hand out
     }
     __syncthreads();
     const uint32_t n_write = n_tiles < tiles_cap ? n_tiles : tiles_cap;
@@ -562,15 +559,13 @@ __global__ void __launch_bounds__(kRadix * kScanChunks) seg_scan_kernel(SegHeade
 // holds tile positions wave * chunk + r * 64 + lane, r = 0 .. ITEMS-1 (valid: r * 64 + lane < chunk and position < cnt),
 // so waves own consecutive runs of the tile and (wave, r, lane) order = position order.  On return s_key / s_val hold
 // the tile reordered by digit (stable), s_dstart[d] = first staged position of digit d.
-template <typename K, int ITEMS, int RB, bool ZEROED = false>
+template <typename K, int ITEMS, int RB>
 __device__ __forceinline__ void tile_count_digits(const K (&key)[ITEMS], uint32_t (&rank)[ITEMS], uint32_t cnt, uint32_t chunk, int shift,
                                                   uint32_t mask, uint32_t* s_wcnt) {
     constexpr int RAD = 1 << RB;
     const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
-    if (!ZEROED) {                             // (ZEROED: the caller cleared the counters and passed a barrier)
-        for (int i = threadIdx.x; i < kWaves * RAD; i += kT) s_wcnt[i] = 0;
-        __syncthreads();
-    }
+    for (int i = threadIdx.x; i < kWaves * RAD; i += kT) s_wcnt[i] = 0;
+    __syncthreads();
     uint32_t* wcnt = s_wcnt + wave * RAD;
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
@@ -774,13 +769,18 @@ __global__ void __launch_bounds__(kT) seg_scatter_loop_kernel(const TileDesc* ti
 // row (one 32-bit word per digit: 2 flag bits | 30 value bits), walks back over its predecessors' rows adding their
 // counts until it meets one that already carries an inclusive prefix, and publishes its own inclusive prefix.  Rows are
 // written and polled with device-coherent (sc1) 16-byte accesses, four digits per lane; a word is self-contained (value
-// and flag travel together), so no fence is involved.  A tile only ever waits for tiles of lower index in the same table;
-// workgroups are dispatched in index order, so the lowest unfinished tile is always running and the walk cannot deadlock
-// (the poll is bounded all the same: a stuck walk gives up, counts in hdr->lookback_timeouts, and the result is wrong
-// rather than the device hung).
+// and flag travel together), so no fence is involved.  A tile only ever waits for tiles of lower index in the same table.
+// PROGRESS (round 4): a walk that has polled an unpublished predecessor kLbSpinCap times stops waiting and counts that tile's
+// digits itself -- the tile's pairs are the previous pass's output, complete since the kernel boundary -- so every workgroup can
+// finish on its own whatever the order in which the others are dispatched or run (HIP promises none); the result is the same
+// either way, hdr->lookback_timeouts merely counts such walks.  Round 4 first took the tile ids from atomic tickets instead
+// (rocPRIM's ordered block id): one counter per pass queued ~2000 atomics on a word (+9 us per pass), per-table counters put a
+// returning atomic in front of every tile's loads (+7 us per pass), and requesting the statically assigned tile's pairs under the
+// atomic failed because ~1000 workgroups start at once and draw their tickets in any order (97 % reloads, +16 us per pass).
+// Counting for a predecessor costs nothing until it happens.
 constexpr uint32_t kStAggregate = 1u << 30, kStInclusive = 2u << 30, kStValue = (1u << 30) - 1u;
 constexpr size_t kLbRowWords = 4 * 512;   // passes x digit values of any plan the look-back form takes (seg_sort_lookback): 4 x 9 bits, 5 x 8 bits
-constexpr uint32_t kLbSpinCap = 1u << 20;
+constexpr uint32_t kLbSpinCap = 1u << 12;    // polls (>= ~1 us each) before a walk counts for its predecessor
 
 struct U4 { uint32_t x, y, z, w; };
 using u32x4 = __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t;
@@ -916,57 +916,36 @@ __global__ void __launch_bounds__(kRadix * kScanChunks) seg_scan_all_kernel(cons
 template <typename K, int RB>
 __global__ void __launch_bounds__(kT) seg_lookback_pass_kernel(const TileDesc* tiles, SegHeader* hdr, const PassSrc<K> src, int pass, int T,
                                                                uint32_t tiles_cap, uint32_t* st_all, const uint32_t* bstart_all, K* kout,
-                                                               uint32_t* vout, uint32_t spin_cap, uint32_t* tickets) {
+                                                               uint32_t* vout, uint32_t spin_cap) {
     constexpr int RAD = 1 << RB;
     constexpr int LW = RAD / 256;            // waves that publish and walk back: 256 digits each, four per lane
-    __shared__ uint32_t s_ticket;
     __shared__ K s_key[kTile];
     __shared__ uint32_t s_val[kTile];
     __shared__ uint32_t s_wcnt[kWaves << RB];
     __shared__ uint32_t s_dstart[1 << RB];
     __shared__ __attribute__((aligned(16))) uint32_t s_gbase[1 << RB];
     __shared__ uint32_t s_tmp[kWaves];
-    // Tiles are handed out by TICKET, per table: a workgroup reads the descriptor of "its" tile (blockIdx: which table), draws
-    // the table's next ticket (one returning atomic; a table's ~40 tiles share a counter, so no word is contended -- one counter
-    // for the whole pass queued ~2000 atomics on a word, ~11 ns each: +9 us per pass) and takes the table's tile of that number --
-    // its own, if workgroups start in index order, which they do in practice: no second descriptor load then.  A tile waits only
-    // for tiles of lower number in its table, whose tickets were drawn earlier by workgroups that are therefore running: forward
-    // progress does not rest on the dispatch order of workgroups, which HIP does not promise (rocPRIM's ordered block id).
-    // Exactly ntiles(table) workgroups draw from a table's counter, so every ticket is a valid tile.
-    TileDesc td = tiles[blockIdx.x];
+    __shared__ uint32_t s_fb[LW * 256];      // fallback of the walk: a predecessor's digit counts, recomputed
+    const TileDesc td = tiles[blockIdx.x];
     if (blockIdx.x >= hdr->n_tiles) return;
-    uint32_t ticket = 0;
-    if (threadIdx.x == 0) ticket = atomicAdd(&tickets[pass * T + td.seg], 1u);
-    // ... and while the ticket is on its way, the pairs of the tile the workgroup will almost certainly get are requested and the
-    // digit counters cleared; the ticket reaches the other threads through LDS at the barrier the counting needs anyway.  The
-    // atomic's round trip passes under the tile's loads: no barrier, no latency of its own.
     const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
     constexpr uint32_t chunk = kTile / kWaves;
-    const uint32_t t = td.seg;
-    const bool from_idx = src.first && td.pooling > 0;    // keys formed from the index array, bag = position / pooling (per table)
-    K key[kTileItems];
-    uint32_t val[kTileItems];
-    load_tile_pairs<K>(td, src, src.first ? td.in_base : td.out_base, from_idx, key, val);
-    uint32_t* st = st_all + static_cast<uint64_t>(pass) * tiles_cap * RAD;
-    const int dq = (wave * 256 + lane * 4) & (RAD - 1);                       // the look-back waves' first digit
-    u32x4 tb = {0u, 0u, 0u, 0u};
-    if (wave < LW) tb = *reinterpret_cast<const u32x4*>(bstart_all + (static_cast<uint64_t>(pass) * T + t) * RAD + dq);
-    for (int i = threadIdx.x; i < kWaves * RAD; i += kT) s_wcnt[i] = 0;
-    if (threadIdx.x == 0) s_ticket = ticket;
-    __syncthreads();
-    const uint32_t j_static = td.first / static_cast<uint32_t>(kTile);
-    const uint32_t g = blockIdx.x - j_static + s_ticket;
-    if (s_ticket != j_static) {                                               // workgroup-uniform; rare: workgroups start in index order
-        td = tiles[g];
-        load_tile_pairs<K>(td, src, src.first ? td.in_base : td.out_base, from_idx, key, val);
-    }
-    const uint32_t cnt = td.cnt, first = td.first;
+    const uint32_t g = blockIdx.x, t = td.seg, cnt = td.cnt, first = td.first;
     const uint32_t j = first / static_cast<uint32_t>(kTile);                  // this tile's index inside its table
     int shift;
     uint32_t mask;
     pass_digit(0, pass, td.rbits, RB, shift, mask);
+    uint32_t* st = st_all + static_cast<uint64_t>(pass) * tiles_cap * RAD;
+    const int dq = (wave * 256 + lane * 4) & (RAD - 1);                       // the look-back waves' first digit
+    u32x4 tb = {0u, 0u, 0u, 0u};
+    if (wave < LW) tb = *reinterpret_cast<const u32x4*>(bstart_all + (static_cast<uint64_t>(pass) * T + t) * RAD + dq);
+    const uint64_t base = src.first ? td.in_base : td.out_base;
+    const bool from_idx = src.first && td.pooling > 0;    // keys formed from the index array, bag = position / pooling
+    K key[kTileItems];
+    uint32_t val[kTileItems];
+    load_tile_pairs<K>(td, src, base, from_idx, key, val);
     uint32_t rank[kTileItems];
-    tile_count_digits<K, kTileItems, RB, true>(key, rank, cnt, chunk, shift, mask, s_wcnt);
+    tile_count_digits<K, kTileItems, RB>(key, rank, cnt, chunk, shift, mask, s_wcnt);
     tile_digit_starts<RB>(s_wcnt, s_dstart, s_tmp, s_gbase);                  // s_gbase: the tile's count of every digit, for now
     u32x4 mine = {0u, 0u, 0u, 0u};
     if (wave < LW) {
@@ -997,9 +976,26 @@ __global__ void __launch_bounds__(kT) seg_lookback_pass_kernel(const TileDesc* t
                     --k;
                     u32x4 v = s4[b];
                     uint32_t spins = 0;
-                    while (__any(((v[0] >> 30) == 0u) | ((v[1] >> 30) == 0u) | ((v[2] >> 30) == 0u) | ((v[3] >> 30) == 0u))) {
-                        if (++spins > spin_cap) {
-                            if (lane == 0) atomicAdd(&hdr->lookback_timeouts, 1u);
+                    const bool force = spin_cap == 0xffffffffu && pass != 0;      // tests: every predecessor is counted here, none is believed
+                    while (force || __any(((v[0] >> 30) == 0u) | ((v[1] >> 30) == 0u) | ((v[2] >> 30) == 0u) | ((v[3] >> 30) == 0u))) {
+                        if (force || ++spins > spin_cap) {
+                            // The predecessor has not published: stop waiting and COUNT ITS DIGITS HERE.  Its pairs are the previous
+                            // pass's output (complete: kernel boundary), so this wave can always finish its walk on its own -- the
+                            // sort's progress rests on no assumption about which workgroups run when, and a walk never gives up.
+                            // (pass 0 never gets here: its counts were published by the histogram kernel before this launch.)
+                            const TileDesc pd = tiles[g - (j - k)];
+                            uint32_t* fb = s_fb + (wave % LW) * 256;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) fb[lane * 4 + i] = 0u;
+                            wave_lds_fence();
+                            for (uint32_t q = lane; q < pd.cnt; q += kWave) {
+                                const uint32_t dg = static_cast<uint32_t>(src.keys[static_cast<uint64_t>(pd.out_base) + q] >> shift) & mask;
+                                if ((dg >> 8) == static_cast<uint32_t>(wave % LW) || RAD == 256) atomicAdd(&fb[dg & 255u], 1u);
+                            }
+                            wave_lds_fence();
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) v[c] = fb[lane * 4 + c] | kStAggregate;
+                            if (lane == 0) atomicAdd(&hdr->lookback_timeouts, 1u);     // a statistic: walks that counted for a predecessor
                             break;
                         }
                         __builtin_amdgcn_s_sleep(2);
@@ -1014,7 +1010,6 @@ __global__ void __launch_bounds__(kT) seg_lookback_pass_kernel(const TileDesc* t
                 }
             }
         }
-        if (spin_cap == 0xffffffffu && j > 0 && threadIdx.x == 0) atomicAdd(&hdr->lookback_timeouts, 1u);   // tests: the failure channel, on demand
         if (j > 0) store_status(st + static_cast<uint64_t>(g) * RAD + dq, ((ex + mine) & kStValue) | kStInclusive);
         *reinterpret_cast<u32x4*>(s_gbase + dq) = tb + ex;                    // where this tile's run of each digit starts
     }
@@ -1288,7 +1283,6 @@ struct Scratch {
     uint32_t* bcnt2;
     uint32_t* st_all;        // look-back form: status rows [pass][tile][digit]
     uint32_t* bstart_all;    // ... bucket starts [pass][table][digit]
-    uint32_t* tickets;       // ... ticket counters [pass][table]
     HybTable* hyb_tab;       // hybrid backward: per-table records
     uint32_t* bloom;         // ... dup bitmaps of the first kHybMaxTables tables
     uint32_t* tile_cnt;      // ... flagged lookups per tile of the bag-major apply, [T_h][tile_cnt_stride]
@@ -1315,7 +1309,6 @@ Scratch scratch_layout(void* base, size_t n, int T) {
     s.bcnt2 = reinterpret_cast<uint32_t*>(take(4 * s2 * kRadix));
     s.st_all = reinterpret_cast<uint32_t*>(take(4 * tm * kLbRowWords));
     s.bstart_all = reinterpret_cast<uint32_t*>(take(4 * static_cast<size_t>(T) * kLbRowWords));
-    s.tickets = reinterpret_cast<uint32_t*>(take(4 * static_cast<size_t>(T) * kMaxLbPasses));
     const size_t th = static_cast<size_t>(T < kHybMaxTables ? T : kHybMaxTables);
     s.hyb_tab = reinterpret_cast<HybTable*>(take(sizeof(HybTable) * static_cast<size_t>(T)));
     s.bloom = reinterpret_cast<uint32_t*>(take(4 * th * kBloomTableWords));
@@ -1378,7 +1371,7 @@ void launch_lookback(const Scratch& s, unsigned tm, int T, PassSrc<K> src, int t
         K* kout = (p % 2 == 0) ? keys_b : keys_a;
         uint32_t* vout = (p % 2 == 0) ? vals_b : vals_a;
         hipLaunchKernelGGL((seg_lookback_pass_kernel<K, RB>), dim3(tm), dim3(kT), 0, stream, s.tiles, s.hdr, src, p, T, tm, s.st_all, s.bstart_all,
-                           kout, vout, spin_cap, s.tickets);
+                           kout, vout, spin_cap);
     }
 }
 template <typename K, int RB>
@@ -1408,7 +1401,7 @@ hipError_t seg_sort_part_a(const SegSortRequest& rq, void* scratch, hipStream_t 
         const int th = rq.T < kHybMaxTables ? rq.T : kHybMaxTables;
         const unsigned grid = static_cast<unsigned>(kXcds * kBloomK * ((th + kXcds - 1) / kXcds));
         hipLaunchKernelGGL(hyb_mark_kernel, dim3(grid), dim3(kMarkThreads), 2 * kBloomWords * 4, stream, s.desc, s.hyb_tab, rq.indices, rq.idx64, th,
-                           s.bloom);
+                           rq.T, rq.N, s.bloom);
     }
     return hipGetLastError();
 }
@@ -1432,10 +1425,10 @@ hipError_t seg_sort_part_b(const SegSortRequest& rq, int mode, K* keys_a, K* key
         const int chunks = rq.bag_count > 0 ? static_cast<int>((rq.bag_count + kBuildBags - 1) / kBuildBags) : 0;
         const dim3 gp(1u + static_cast<unsigned>(chunks) * static_cast<unsigned>(rq.T));
         if (rq.weighted)
-            hipLaunchKernelGGL((seg_prep_scan_kernel<K, true>), gp, dim3(1024), 0, stream, s.desc, rq.T, s.hdr, s.tickets, s.tiles, tm, rq.indices,
+            hipLaunchKernelGGL((seg_prep_scan_kernel<K, true>), gp, dim3(1024), 0, stream, s.desc, rq.T, s.hdr, s.tiles, tm, rq.indices,
                                rq.offsets, rq.idx64, rq.B, rq.N, rq.bag_begin, rq.bag_count, rq.tshift, keys_a, vals_a, bag_of, chunks);
         else
-            hipLaunchKernelGGL((seg_prep_scan_kernel<K, false>), gp, dim3(1024), 0, stream, s.desc, rq.T, s.hdr, s.tickets, s.tiles, tm, rq.indices,
+            hipLaunchKernelGGL((seg_prep_scan_kernel<K, false>), gp, dim3(1024), 0, stream, s.desc, rq.T, s.hdr, s.tiles, tm, rq.indices,
                                rq.offsets, rq.idx64, rq.B, rq.N, rq.bag_begin, rq.bag_count, rq.tshift, keys_a, vals_a, bag_of, chunks);
     }
     // pass 0 reads the request (or the built keys in the a buffers) and writes the b buffers; later passes alternate, so the

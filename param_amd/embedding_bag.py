@@ -278,13 +278,13 @@ def sorted_pairs(ts: _TableSet, indices, offsets, B, psw=None, bag_begin=0, bag_
 
 def sort_status(ts: _TableSet, indices, offsets, B, psw=None, bag_begin=0, bag_count=None) -> dict:
     """What the last ``_sort_indices`` / backward on this table set's workspace left on the device (``pm_embbag_sort_status``;
-    SYNCHRONISES): ``lookback_timeouts`` (non-zero raises :class:`ParamAmdError` -- the apply then left the tables untouched),
+    SYNCHRONISES): ``lookback_fallbacks`` (look-back walks that counted a predecessor's digits themselves: harmless),
     ``pairs_sorted``, ``hybrid_tables``, ``hybrid_launched``."""
     op = ts.request(indices, offsets, B, psw, bag_begin, bag_count)
     ws = _workspace(ts, op)
     st = _lib.pm_sort_status()
     _lib.check(_lib.load().pm_embbag_sort_status(ctypes.byref(op), max(ts.rows), ws.data_ptr(), ctypes.byref(st), _stream_ptr()))
-    return {"lookback_timeouts": st.lookback_timeouts, "pairs_sorted": st.pairs_sorted, "hybrid_tables": st.hybrid_tables,
+    return {"lookback_fallbacks": st.lookback_fallbacks, "pairs_sorted": st.pairs_sorted, "hybrid_tables": st.hybrid_tables,
             "hybrid_launched": st.hybrid_launched}
 
 
@@ -564,7 +564,7 @@ class BatchedEmbeddingBagMI355(nn.Module):
              bag_begin, bag_count, method, presorted, pooling)
 
     def sort_status(self, indices, offsets, per_sample_weights=None, batch: Optional[int] = None, bag_begin=0, bag_count=None) -> dict:
-        """status of the last key sort on this module's workspace (synchronises; raises if the sort gave up)"""
+        """status of the last key sort on this module's workspace (synchronises)"""
         B = self._batch_of(offsets, indices) if batch is None else batch
         return sort_status(self._tables(), indices, offsets, B, per_sample_weights, bag_begin, bag_count)
 

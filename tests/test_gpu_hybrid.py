@@ -69,7 +69,7 @@ def test_hybrid_uniform_tables_bit_exact_vs_oracle(coracle, layout, idt):
         m.scatter_add_(grad, idx, off, alpha=-0.05, batch=B)
         st = m.sort_status(idx, off, batch=B)
         torch.cuda.synchronize()
-        assert st["lookback_timeouts"] == 0
+        assert st["lookback_fallbacks"] == 0
         if en:
             assert st["hybrid_tables"] == len(rows) and st["hybrid_launched"] == 1, st
             assert 0 < st["pairs_sorted"] < 0.1 * idx.numel(), st           # only the flagged lookups were sorted
@@ -122,7 +122,9 @@ def test_hybrid_forced_on_skewed_and_mixed_tables(coracle):
                 if hot.any():
                     np.testing.assert_allclose(got[en][t][hot], exp[t][hot], rtol=2e-4, atol=2e-4)
         else:
-            assert st["hybrid_tables"] == 2, st          # the two uniform tables that qualify (1 and 5)
+            # the two uniform tables that qualify on their own (1 and 5) hold 37 % of the request's lookups: below one half the
+            # request stays on the sorted path (HybTable::cand, common.h)
+            assert st["hybrid_tables"] == 0, st
     idx_h, off_h = idx.cpu().numpy(), off.cpu().numpy()
     for t in range(len(rows)):
         # rows looked up more than 256 times are summed as ordered chunk partials, and which lookups share a chunk depends on what
@@ -218,13 +220,13 @@ def test_the_path_taken_depends_on_the_request_alone():
     assert torch.equal(m.weights.data, ref.weights.data)
 
 
-def test_forced_lookback_timeout_is_an_error_never_a_wrong_table():
-    """The failure channel of the look-back sort.  lookback_spin_cap = 0xFFFFFFFF makes every tile that looks back report a
-    time-out (deterministic); = 1 makes a walk give up at the first predecessor that is not published yet (may or may not
-    happen).  Either way: a sort that reported time-outs makes pm_embbag_sort_status fail with PM_ERR_SORT and the apply leaves
-    the table UNTOUCHED; a run without time-outs must be correct.  Never a silently wrong table."""
+def test_lookback_walks_that_count_for_their_predecessors_give_the_same_sort():
+    """The sort's progress guarantee: a look-back walk that has waited too long for a predecessor's published digit counts counts
+    that tile's digits itself.  lookback_spin_cap = 1 takes that path wherever a predecessor is a moment late (rare on an idle
+    device), 0xFFFFFFFF takes it for EVERY predecessor of every tile of passes 1 and 2 (nothing published is believed).  The
+    sorted pairs must be numpy's stable order and the table must equal the default run's either way."""
     import param_amd
-    from param_amd import _lib
+    from param_amd.embedding_bag import _sort_indices, sorted_pairs
 
     rows, D, B, L = [2_000_000], 16, 65536, 16          # one segment of 256 radix tiles
     idx, off = _request(rows, B, L, 1.05, 13)
@@ -232,36 +234,28 @@ def test_forced_lookback_timeout_is_an_error_never_a_wrong_table():
     param_amd.set_hybrid_tuning(0)
     good = _model(rows, D, seed=2)
     good.scatter_add_(grad, idx, off, alpha=1.0, batch=B)
-    assert good.sort_status(idx, off, batch=B)["lookback_timeouts"] == 0
-    failed = 0
-    for cap in (0xFFFFFFFF, 1, 1, 1):
+    assert good.sort_status(idx, off, batch=B)["lookback_fallbacks"] == 0
+    keys = idx.cpu().numpy()
+    order = np.argsort(keys, kind="stable")
+    for cap in (0xFFFFFFFF, 1, 1):
         param_amd.set_hybrid_tuning(0, cap)
         m = _model(rows, D, seed=2)
-        before = m.weights.data.clone()
+        ts = m._tables()
+        _sort_indices(ts, idx, off, B)
+        k, v, _ = sorted_pairs(ts, idx, off, B)
+        assert np.array_equal(k.cpu().numpy(), keys[order]) and np.array_equal(v.cpu().numpy(), order // L)
         m.scatter_add_(grad, idx, off, alpha=1.0, batch=B)
-        try:
-            m.sort_status(idx, off, batch=B)
-            assert cap == 1
-            assert torch.equal(m.weights.data, good.weights.data)
-        except param_amd.ParamAmdError as exc:
-            assert exc.code == _lib.PM_ERR_SORT
-            failed += 1
-            assert torch.equal(m.weights.data, before)          # untouched
-            # recovery: the same order from kernels that never wait for each other
-            param_amd.set_hybrid_tuning(0, 0)
-            param_amd.set_sort_tuning(3)
-            m.scatter_add_(grad, idx, off, alpha=1.0, batch=B)
-            assert m.sort_status(idx, off, batch=B)["lookback_timeouts"] == 0
-            param_amd.set_sort_tuning(-1)
-            assert torch.equal(m.weights.data, good.weights.data)
+        fb = m.sort_status(idx, off, batch=B)["lookback_fallbacks"]
+        if cap == 0xFFFFFFFF:
+            assert fb == 2 * (255 * 256 // 2), fb           # passes 1 and 2: tile j counts for its j predecessors
+        assert torch.equal(m.weights.data, good.weights.data)
     param_amd.set_hybrid_tuning(0, 0)
-    assert failed >= 1
 
 
 def test_lookback_sort_on_a_cu_masked_stream_beside_a_saturating_forward():
     """The look-back sort on a 32-CU-masked stream while a full-size forward saturates the default stream, 200 times: the sorted
-    pairs equal numpy's stable order and no walk ever times out (tiles are taken by ticket, so the sort's progress does not
-    depend on how the dispatcher interleaves its workgroups with the forward's)."""
+    pairs equal numpy's stable order (a walk that waits too long counts for its predecessor, so the sort's progress does not
+    depend on how the dispatcher interleaves its workgroups with the forward's; how often that happened is reported)."""
     import param_amd
     from bench import masked_stream
     from param_amd.embedding_bag import _sort_indices, sorted_pairs
@@ -294,7 +288,6 @@ def test_lookback_sort_on_a_cu_masked_stream_beside_a_saturating_forward():
         torch.cuda.current_stream().wait_stream(ms)
         if it % 20 == 0 or it == 199:
             st = sm.sort_status(si, so, batch=16384)
-            assert st["lookback_timeouts"] == 0, (it, st)
             k, v, tsh = sorted_pairs(ts, si, so, 16384)
             assert tsh == 20
             k, v = k.cpu().numpy(), v.cpu().numpy()
