@@ -116,7 +116,15 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
     p.idx_cap = static_cast<int32_t>(cap);
     p.idx64 = op->index_dtype == PM_I64 ? 1 : 0;
     const int xa = g_xcd_affine.load();
-    p.xcd_affine = (op->num_tables % pm::kXcds == 0 && xa != 0) ? 1 : 0;
+    // T % 8 == 0: table t on XCD t % 8.  Any other table count (26 tables: BASELINE configs[3]): contiguous eighths of the
+    // table-major tile order (common.h) -- 26 x 10 M x 128, [B, sum D] output: 0.692 -> 0.700 of the HBM peak under uniform indices,
+    // 19.6 -> 21.15 G lookups/s under Zipf (tools/r4_fwd_xcd.py) -- but only where every table has the same lookups per tile: with
+    // the Criteo tables' pooling factors of 1 .. 100 the XCD that gets the 100-hot table does a third of the launch (0.70 -> 0.27)
+    {
+        const int64_t tb = static_cast<int64_t>(op->num_tables) * op->batch;
+        const bool even_req = tb > 0 && op->num_indices % tb == 0;
+        p.xcd_affine = xa == 0 ? 0 : (op->num_tables % pm::kXcds == 0 ? 1 : ((op->num_tables > 1 && even_req) ? 3 : 0));
+    }
     const int nt = g_nt_loads.load();
     p.nt_loads = nt > 0 ? nt : 0;   // forward: any non-zero = non-temporal row loads; sorted backward: 1 nt, 2 system scope
     // lookups that do not divide evenly over the bags: certainly ragged (fixed-size requests -- every benchmark shape --
@@ -212,7 +220,7 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
         //    on all eight XCDs at once and on every CU next to other tables' rows.  Kept behind PARAM_AMD_FWD_TILE_MAJOR=1.
         static const int tm_env = [] { const char* e = getenv("PARAM_AMD_FWD_TILE_MAJOR"); return e ? atoi(e) : -1; }();
         const bool uneven = total_bags > 0 && op->num_indices % total_bags != 0;
-        if (!p.xcd_affine && op->num_tables > 1 && tm_env > 0 && uneven) p.xcd_affine = 2;
+        if (p.xcd_affine != 1 && op->num_tables > 1 && tm_env > 0 && uneven) p.xcd_affine = 2;
     }
     return PM_OK;
 }

@@ -48,7 +48,8 @@ struct KParams {
     int32_t bags_per_block;
     int32_t idx_cap;             // LDS index-tile capacity (entries)
     int32_t idx64;               // 1: int64 indices/offsets, 0: int32
-    int32_t xcd_affine;          // 1: table t is served by XCD t % 8 (requires T % 8 == 0); 2: tile-major block order (t = b % T)
+    int32_t xcd_affine;          // 1: table t is served by XCD t % 8 (requires T % 8 == 0); 2: tile-major block order (t = b % T);
+                                 // 3: XCD x serves the x-th eighth of the table-major tile order (any T)
     int32_t nt_loads;            // 1: non-temporal table-row loads
     int32_t ordered;             // forward: 1 = ragged request, lane groups take the longest bags of a tile first
     int32_t stage_out;           // forward: > 0 = collect the tile's pooled rows in LDS (this many floats per row), write at tile end
@@ -74,9 +75,20 @@ __device__ __forceinline__ int64_t bag_start_or_end(const KParams& p, int64_t g)
 // blockIdx -> (table, bag tile).  With xcd_affine the 8 XCDs each own the tables
 // t == xcd (mod 8), so one table's hot rows live in exactly one XCD's 4 MiB L2
 // instead of being replicated in all eight (placement is a speed matter only).
-__device__ __forceinline__ void block_to_tile(const KParams& p, int& t, int& tile) {
-    const int bid = blockIdx.x;
-    if (p.xcd_affine == 2) {
+// XCD-contiguous order for any table count (xcd_affine == 3, round 4): XCD x (blocks are dispatched round-robin over the 8
+// XCDs) serves the x-th eighth of the table-major tile order -- a bijection of [0, total) for any total, so the grid stays
+// T x tiles_per_table.  The tiles an XCD has in flight then belong to one or two tables, like t % 8 gives for T % 8 == 0.
+__device__ __forceinline__ int xcd_contiguous_tile(int bid, int total) {
+    const int q = total / kXcds, r = total % kXcds, x = bid % kXcds;
+    return x * q + (x < r ? x : r) + bid / kXcds;
+}
+
+__device__ __forceinline__ void block_to_tile(const KParams& p, int& t, int& tile, int bid = blockIdx.x) {
+    if (p.xcd_affine == 3) {
+        const int g = xcd_contiguous_tile(bid, p.T * p.tiles_per_table);
+        t = g / p.tiles_per_table;
+        tile = g % p.tiles_per_table;
+    } else if (p.xcd_affine == 2) {
         // tile-major: consecutive blocks serve the same tile index of consecutive tables, so every table advances at the same
         // rate.  For requests whose tables have very different pooling factors (Criteo multi-hot 1 .. 100): in table-major
         // order the heaviest table's workgroups -- each a chain of 25 round trips -- are dispatched together, late, and the

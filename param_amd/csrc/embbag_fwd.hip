@@ -327,8 +327,8 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_flat_kernel(const KParams p
     constexpr int VEC = Elem<WT>::kVec;
     constexpr int NG = kBlock / G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int t = blockIdx.x / p.tiles_per_table;
-    const int tile = blockIdx.x % p.tiles_per_table;
+    int t, tile;
+    block_to_tile(p, t, tile);
     if (t >= p.T) return;
     const int64_t g0 = static_cast<int64_t>(t) * p.B + p.bag_begin;
     const int64_t lo = bag_start_or_end(p, g0), hi = bag_start_or_end(p, g0 + p.bag_count);
