@@ -65,6 +65,7 @@ class commsParamsHolder:
         self.init_only = False
         self.use_device_time = args.use_device_time
         self.include_0B = args.include_0B
+        self.graph_launches = getattr(args, "graph_launches", 0)
         self.init_method = None
         self.use_ext_dist = False
 
@@ -125,6 +126,7 @@ class commsCollBench:
         parser.add_argument("--data-types", "--dtype", type=str, default="float32", dest="data_types")
         parser.add_argument("--use-device-time", action="store_true", default=False)
         parser.add_argument("--include-0B", action="store_true", default=False)
+        parser.add_argument("--graph-launches", type=int, default=0, help="Number of graph launches for each data-size")
         parser.add_argument("--log", type=str, default="ERROR")
         return parser.parse_args()
 
@@ -156,6 +158,12 @@ class commsCollBench:
             for c in args.collectives:
                 for d in args.dtypes:
                     comms_utils.checkQuantArgs(c, _DTYPES[d], args.b, args.quant_a2a_embedding_dim, args.z)
+        if args.graph_launches > 0 and args.device not in ("cuda", "rocm"):          # comms.py:332-334
+            logger.error("cuda graph is only supported for cuda or rocm device")
+            comms_utils.gracefulExit()
+        if args.graph_launches > 0 and args.bitwidth < 32:
+            logger.error("--graph-launches replays the plain collectives: not with --bitwidth < 32 (host-side timers in the quantised path)")
+            comms_utils.gracefulExit()
         if args.c == 1 and args.z == 0:
             logger.warning("data validation requires blocking mode: forcing --z 1")
             args.z = 1
@@ -247,6 +255,42 @@ class commsCollBench:
         bf.sync_barrier(ca, desc="runColl_end")
         return {"timeUS": avgIterNS / 1e3, "algBW": algBW, "busBW": busBW, "memSize": memSize}
 
+    def runCollGraph(self, comm_fn, dcheck=False):
+        """``--graph-launches N``: the reference's run_coll_cuda_graph (comms.py:375-450) on HIP graphs -- warm-up on a side stream,
+        ``numIters`` collectives captured into ONE hipGraph (blocking form: an async work handle cannot cross a capture), the
+        graph replayed N times, wall time over ``numIters * numCollPerIter * N`` collectives.  The launch-bound small-message end
+        of a sweep is where it matters: a replay costs one graph launch instead of ``numIters`` collective launches."""
+        ca, bf = self.collectiveArgs, self.backendFuncs
+        bf.sync_barrier(ca, desc="run_coll_cuda_graph_begin")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(ca.numWarmupIters):
+                comm_fn(ca)
+        torch.cuda.current_stream().wait_stream(side)
+        bf.complete_accel_ops(ca)            # nothing in flight that c10d's watchdog thread would query while the capture is open
+        ca.asyncOp = False
+        graph = torch.cuda.CUDAGraph()
+        # thread-local capture mode: the process group's watchdog thread polls its events with hipEventQuery, which a GLOBAL-mode
+        # capture on this thread turns into an error (and an abort) in that thread
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            for _ in range(ca.numIters):
+                if dcheck and ca.collective in ("all_reduce", "reduce"):
+                    ca.ipTensor.fill_(self.initVal)              # reset inside the graph: every replay validates (comms.py:399-401)
+                for _ in range(ca.numCollPerIter):
+                    comm_fn(ca)
+        start = time.monotonic()
+        for _ in range(ca.graph_launches):
+            graph.replay()
+        bf.complete_accel_ops(ca)
+        elapsed_ns = (time.monotonic() - start) * 1e9
+        memSize = bf.get_mem_size(ca)
+        avgIterNS, algBW = comms_utils.getAlgBW(elapsed_ns, memSize, ca.numIters * ca.numCollPerIter * ca.graph_launches)
+        busBW = bf.getBusBW(ca.collective, algBW, ca)
+        ca.group = bf.get_default_group()
+        bf.sync_barrier(ca, desc="runColl_end")
+        return {"timeUS": avgIterNS / 1e3, "algBW": algBW, "busBW": busBW, "memSize": memSize}
+
     def dcheck(self, commsParams, curSize):
         """``--c 1``: inputs are ones, so all_to_all* outputs are ones and all_reduce gives world_size
         (comms_utils.py:997-1055)."""
@@ -299,6 +343,7 @@ class commsCollBench:
         ca.collective = commsParams.collective
         ca.asyncOp = False if commsParams.blockingFlag == 1 else True
         ca.numCollPerIter = 1
+        ca.graph_launches = commsParams.graph_launches
         ca.numIters, ca.numWarmupIters = commsParams.numIters, commsParams.numWarmupIters
         ca.use_device_time = commsParams.use_device_time
         ca.comm_dev_time = paramDeviceTimer("comm_timer", bf) if (commsParams.use_device_time and ca.device.type == "cuda") else None
@@ -312,7 +357,10 @@ class commsCollBench:
                                             commsParams.stepBytes):
             numElements = self.prepComm(commsParams, curSize)
             ca.group = bf.get_default_group()
-            results = self.runColl(comm_fn, dcheck=commsParams.dcheck == 1)
+            if ca.graph_launches > 0:                                    # comms.py:548-552
+                results = self.runCollGraph(comm_fn, dcheck=commsParams.dcheck == 1)
+            else:
+                results = self.runColl(comm_fn, dcheck=commsParams.dcheck == 1)
             results["numElements"] = numElements // ca.world_size if "all_to_all" in ca.collective else numElements
             if commsParams.dcheck == 1:
                 self.dcheck(commsParams, curSize)

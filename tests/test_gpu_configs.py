@@ -95,7 +95,7 @@ def _pick_rows(counts):
     return torch.unique(torch.cat([hot, mid, once, never]))
 
 
-def _run_config(dist, rows, pools, check_tables, alpha_lr=-0.01):
+def _run_config(dist, rows, pools, check_tables, alpha_lr=-0.01, masked_cus=0):
     import param_amd
     from param_amd.comms.pt.pipeline import ShardedEmbeddingExchange
     from param_amd.indices import tbe_request
@@ -168,10 +168,24 @@ def _run_config(dist, rows, pools, check_tables, alpha_lr=-0.01):
 
     # ---- pipelined (three batches in flight) from the same start -------------------------------------------------------
     m.reset_parameters("normal", 7)                                             # counter-based fill: the same bits again
-    ex = fresh_exchange()
-    for k in range(n_batches):
-        ex.step(*reqs[k])
-    ex.drain()
+    if masked_cus:
+        # the N > 1 default of bench.py: lookups and backward on a CU-masked HIP stream (hipExtStreamCreateWithCUMask), the rest of
+        # the chip left to RCCL's kernels; c10d's stream hand-offs key on torch's current stream, which is the masked one here
+        from bench import masked_stream
+
+        ms = masked_stream(masked_cus, torch.device(DEV))
+        ms.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(ms):
+            ex = fresh_exchange()
+            for k in range(n_batches):
+                ex.step(*reqs[k])
+            ex.drain()
+        torch.cuda.current_stream().wait_stream(ms)
+    else:
+        ex = fresh_exchange()
+        for k in range(n_batches):
+            ex.step(*reqs[k])
+        ex.drain()
     torch.cuda.synchronize()
     assert _checksums(m) == serial_sums, "pipelined and serial training steps left different tables"
     for t in check_tables:
@@ -198,3 +212,9 @@ def test_configs4_criteo_tables_multi_hot_through_the_exchange(rccl_one_rank):
     assert ds.criteo_v2_dim == D
     # table 20: 40 M rows x 100-hot (the heaviest), table 0: 40 M rows x 3-hot, table 5: 3 rows (every row hot)
     _run_config(rccl_one_rank, list(ds.criteo_v2_rows), list(ds.criteo_v2_multi_hot), check_tables=[20, 0, 5])
+
+
+def test_configs3_through_the_exchange_with_the_compute_stream_on_224_cus(rccl_one_rank):
+    """the same shape with the pipelined steps on a 224-CU-masked compute stream (what ``bench.py --gpus N`` runs by default for
+    N > 1): serial (unmasked) and pipelined (masked) training steps must leave the same tables, bit for bit"""
+    _run_config(rccl_one_rank, [10_000_000] * 26, [20] * 26, check_tables=[0, 13, 25], masked_cus=224)

@@ -262,3 +262,29 @@ def test_quantised_sweep_host_logic_equals_the_reference(golden_dir):
     finally:
         sys.argv = old
     assert (a.bitwidth, a.quant_a2a_embedding_dim, a.quant_threshold) == (8, 128, 33554432)
+
+
+def test_graph_launches_flag_is_checked_like_the_reference():
+    """``--graph-launches`` (reference comms.py:196-199, 332-334): an integer flag, default 0, refused on a cpu device"""
+    import argparse
+    import sys
+
+    from param_amd.comms.pt import comms
+
+    def parse(argv):
+        bench = comms.commsCollBench()
+        old = sys.argv
+        sys.argv = ["comms.py"] + argv
+        try:
+            return bench, bench.readArgs(argparse.ArgumentParser())
+        finally:
+            sys.argv = old
+
+    bench, a = parse([])
+    assert a.graph_launches == 0
+    bench, a = parse(["--graph-launches", "7", "--device", "rocm"])
+    bench.checkArgs(a)
+    assert a.graph_launches == 7 and comms.commsParamsHolder(a, 4, torch.float32, "all_to_all").graph_launches == 7
+    bench, a = parse(["--graph-launches", "2", "--device", "cpu", "--backend", "gloo"])
+    with pytest.raises(SystemExit):
+        bench.checkArgs(a)
