@@ -150,6 +150,9 @@ int pm_embbag_bwd(const pm_embbag_batch* op, const float* grad, void* const* dst
  *                                   pm_embbag_sort_indices on the same workspace and request
  *                                   (stream-ordered before it).  16-bit destinations are
  *                                   widened, accumulated in fp32 and rounded once per row.
+ * The apply must be given THE request the sort was issued for, on the same workspace: same indices / offsets POINTERS (the
+ * segmented sort leaves its segments and pair counts on the device, keyed to the request's buffers: a copy of the arrays at
+ * another address is another request), same batch, bag_begin, bag_count and weights; otherwise PM_ERR_INVALID.
  * max_rows = max_t rows[t] (host value; sizes the sort key).  The request must satisfy
  * num_indices < 2^32 and batch < 2^32.  Replaces the sort + segmented-reduce backward of
  * aten::_embedding_bag_dense_backward and fbgemm's TBE backward (same call sites as
@@ -165,6 +168,8 @@ int pm_embbag_sort_indices(const pm_embbag_batch* op, int64_t max_rows, void* wo
  * lookups are still added in lookup order).  The fused row-wise Adagrad needs every row's lookups in one run: sort with
  * phases = 1 (what pm_embbag_sort_indices does) for pm_embbag_bwd_sorted_adagrad*, which otherwise return PM_ERR_INVALID.
  * The library remembers, per workspace, how the last sort was laid out; the apply call must follow on the same workspace.
+ * (`phases` is honoured by sort_impl 2 only: the default segmented sort, sort_impl 0, always lays the request out for a
+ * one-launch apply, whatever `phases` says.)
  */
 int pm_embbag_sort_indices_ex(const pm_embbag_batch* op, int64_t max_rows, int32_t phases, void* workspace,
                               int64_t workspace_bytes, pm_stream_t stream);

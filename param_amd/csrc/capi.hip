@@ -181,18 +181,18 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
         // r3_criteo_flat (Zipf G lookups/s / uniform fraction; run-to-run +-1.5 %): 8-bag tiles 15.7-15.9 / 0.69-0.71; flat walk
         // target 512 cap 64: 16.4-16.5 / 0.705-0.716; **256 / 32: 16.6 / 0.719**; 128: 16.1 / 0.695; 1024 / 128: 14.1 / 0.64.
         // PARAM_AMD_FWD_FLAT=0 turns it off (PARAM_AMD_FLAT_TARGET / _BAGS: sweeps).
-        static const int flat_env = [] { const char* e = getenv("PARAM_AMD_FWD_FLAT"); return e ? atoi(e) : 1; }();
+        const int flat_env = [] { const char* e = getenv("PARAM_AMD_FWD_FLAT"); return e ? atoi(e) : 1; }();       // read per call: sweeps set it between requests
         const bool flat_on = flat_env != 0;
         // ... and so do fixed-pooling requests of one or two lookups per bag (one-hot tables): bag by bag a lane group has one or
         // two row loads in flight.  48 x 10 M x 128 fp32, batch 65536 (tools/r3_shortbags.sh; Zipf G lookups/s / uniform fraction):
         // pooling 1: 4.00 / 0.529 -> 5.05 / 0.624; pooling 2: 7.78 / 0.687 -> 8.75 / 0.686; pooling 4: 13.5 / 0.723 -> 13.4 / 0.679
         // (not taken; PARAM_AMD_FWD_FLAT=2 extends the rule to 4 for that measurement).
-        static const int flat_maxl = [] { const char* e = getenv("PARAM_AMD_FLAT_MAXL"); return e ? atoi(e) : 0; }();   // experiments
+        const int flat_maxl = [] { const char* e = getenv("PARAM_AMD_FLAT_MAXL"); return e ? atoi(e) : 0; }();   // experiments
         if (flat_on && even && avg_l <= (flat_maxl > 0 ? flat_maxl : flat_env == 2 ? 4 : 2) && !p.ordered && g_bags_per_block.load() <= 0 &&
             p.stage_out > 0) {
             const int64_t tiles_ng = (op->bag_count + NG - 1) / NG;
             if (tiles_ng * op->num_tables <= 0x7fffffffLL) {
-                static const int tgt2 = [] { const char* e = getenv("PARAM_AMD_FLAT_TARGET"); return e ? atoi(e) : 256; }();
+                const int tgt2 = [] { const char* e = getenv("PARAM_AMD_FLAT_TARGET"); return e ? atoi(e) : 256; }();
                 p.flat_bags = 32;
                 p.flat_target = tgt2;
                 p.tiles_per_table = static_cast<int32_t>(tiles_ng);
@@ -202,8 +202,8 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
             }
         }
         if (flat_on && !even && !p.ordered && g_bags_per_block.load() <= 0 && bpb == NG && p.stage_out > 0) {
-            static const int cap_env = [] { const char* e = getenv("PARAM_AMD_FLAT_BAGS"); return e ? atoi(e) : 32; }();
-            static const int tgt_env = [] { const char* e = getenv("PARAM_AMD_FLAT_TARGET"); return e ? atoi(e) : 256; }();
+            const int cap_env = [] { const char* e = getenv("PARAM_AMD_FLAT_BAGS"); return e ? atoi(e) : 32; }();
+            const int tgt_env = [] { const char* e = getenv("PARAM_AMD_FLAT_TARGET"); return e ? atoi(e) : 256; }();
             p.flat_bags = cap_env < NG ? NG : (cap_env > 1024 ? 1024 : cap_env / NG * NG);
             p.flat_target = tgt_env < 1 ? 1 : tgt_env;
             p.bags_per_block = p.flat_bags;   // sizes the LDS offsets array; stage_bags (the burst buffer) stays at NG rows
@@ -218,7 +218,7 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
         //  * tile-major block order (t = b % T, so every table advances at the same rate and the heavy table's long workgroups
         //    start throughout the launch): 165 against 120 us under Zipf, 220 against 186 us uniform -- a table's tiles then run
         //    on all eight XCDs at once and on every CU next to other tables' rows.  Kept behind PARAM_AMD_FWD_TILE_MAJOR=1.
-        static const int tm_env = [] { const char* e = getenv("PARAM_AMD_FWD_TILE_MAJOR"); return e ? atoi(e) : -1; }();
+        const int tm_env = [] { const char* e = getenv("PARAM_AMD_FWD_TILE_MAJOR"); return e ? atoi(e) : -1; }();
         const bool uneven = total_bags > 0 && op->num_indices % total_bags != 0;
         if (p.xcd_affine != 1 && op->num_tables > 1 && tm_env > 0 && uneven) p.xcd_affine = 2;
     }
@@ -510,7 +510,7 @@ int pm_embbag_bwd_sorted(const pm_embbag_batch* op, const float* grad, void* con
     if (!workspace || workspace_bytes < static_cast<int64_t>(need))
         return fail(PM_ERR_INVALID, "workspace too small: need " + std::to_string(need) + " bytes");
     if (pm::bwd_sorted_plan_check(p, max_rows, workspace, false) != 0)
-        return fail(PM_ERR_INVALID, "pm_embbag_sort_indices has not been called for this request on this workspace");
+        return fail(PM_ERR_INVALID, "pm_embbag_sort_indices has not been called for this request on this workspace (same indices / offsets pointers, batch, bag slice and weights as the sort's)");
     p.io = const_cast<float*>(grad);
     p.tables = const_cast<const void* const*>(dst_tables);
     p.alpha = alpha;
@@ -547,7 +547,7 @@ int pm_embbag_bwd_sorted_adagrad_ex(const pm_embbag_batch* op, const float* grad
             return fail(PM_ERR_INVALID, "the request was sorted for a two-phase scatter-add apply; row-wise Adagrad needs "
                                         "pm_embbag_sort_indices (phases = 1)");
         if (pc != 0)
-            return fail(PM_ERR_INVALID, "pm_embbag_sort_indices has not been called for this request on this workspace");
+            return fail(PM_ERR_INVALID, "pm_embbag_sort_indices has not been called for this request on this workspace (same indices / offsets pointers, batch, bag slice and weights as the sort's)");
     }
     p.io = const_cast<float*>(grad);
     p.tables = const_cast<const void* const*>(tables);

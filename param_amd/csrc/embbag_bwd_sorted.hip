@@ -115,7 +115,7 @@ struct SortWs {
 // 1024: 1.496 / 0.815, 394 / 481.  Smaller tiles balance the tail of a launch better; larger ones cut a long run (a Zipf head,
 // a 3-row table) into fewer pieces for the fix-up kernel.  PARAM_AMD_BWD_TILE overrides (256 / 512 / 1024).
 inline int apply_tile(int64_t n) {
-    static const int env = [] { const char* e = getenv("PARAM_AMD_BWD_TILE"); return e ? atoi(e) : 0; }();
+    const int env = [] { const char* e = getenv("PARAM_AMD_BWD_TILE"); return e ? atoi(e) : 0; }();     // per call (it also sizes the workspace: max_chunks)
     if (env == 256 || env == 512 || env == 1024) return env;
     return n < (static_cast<int64_t>(3) << 18) ? 256 : 512;
 }

@@ -45,7 +45,10 @@ namespace {
 
 constexpr int kT = 256;                 // threads per workgroup
 constexpr int kWaves = kT / kWave;      // 4
-constexpr int kTile = 4096;             // elements per radix tile (16 per thread)
+#ifndef PM_SEG_TILE
+#define PM_SEG_TILE 4096
+#endif
+constexpr int kTile = PM_SEG_TILE;      // elements per radix tile (16 per thread); -DPM_SEG_TILE=2048: experiment builds
 constexpr int kTileItems = kTile / kT;  // 16
 constexpr int kRadix = 256;
 constexpr int kRadixMax = 512;          // mode 0 sorts 9 bits per pass where that saves a pass

@@ -31,7 +31,7 @@ def label_rows(rows):
     out = defaultdict(list)
     n_fwd = 0
     n_fill = 0
-    n_main = n_fix = 0
+    n_main = n_fix = n_uni = n_mark = 0
     for name, val in rows:
         if "fill_random_kernel" in name:
             n_fill += 1
@@ -48,7 +48,13 @@ def label_rows(rows):
                 out["fwd_zipf"].append(val)
         elif "embbag_bwd_kernel" in name:
             out["bwd_atomic_uniform"].append(val)
-        elif "bwd_sorted_main_kernel" in name:        # the dominant backward kernel: `reps` uniform steps, then `reps` Zipf
+        elif "bwd_unique_kernel" in name:             # round 4, hybrid backward: the bag-major apply (empty under Zipf: no table qualifies)
+            n_uni += 1
+            out["bwd_unique_uniform" if n_uni <= reps else "bwd_unique_zipf"].append(val)
+        elif "hyb_mark_kernel" in name:
+            n_mark += 1
+            out["bwd_mark_uniform" if n_mark <= reps else "bwd_mark_zipf"].append(val)
+        elif "bwd_sorted_main_kernel" in name:        # the sorted apply: `reps` uniform steps (hybrid: the flagged lookups only), then `reps` Zipf
             n_main += 1
             out["bwd_uniform" if n_main <= reps else "bwd_zipf"].append(val)
         elif "bwd_sorted_fixup_kernel" in name:
@@ -114,6 +120,16 @@ for label, c in summary.items():
     if "hbm_bytes_per_launch" in e and "algorithmic_bytes" in e:
         e["hbm_over_algorithmic"] = e["hbm_bytes_per_launch"] / e["algorithmic_bytes"]
     res["kernels"][label] = e
+
+# round 4: under uniform indices the backward's apply is the bag-major kernel + the sorted apply of the flagged lookups
+ks = res["kernels"]
+if "bwd_unique_uniform" in ks and "hbm_bytes_per_launch" in ks["bwd_unique_uniform"]:
+    parts = [ks[k] for k in ("bwd_unique_uniform", "bwd_uniform", "bwd_fixup_uniform", "bwd_mark_uniform") if "hbm_bytes_per_launch" in ks.get(k, {})]
+    tot = sum(p_["hbm_bytes_per_launch"] for p_ in parts)
+    ks["bwd_uniform_step"] = {"what": "bag-major apply + sorted apply of the flagged lookups + fix-up + mark kernel (the key sort's small kernels excluded)",
+                              "hbm_bytes_per_launch": tot, "fetch_bytes_calibrated": sum(p_.get("fetch_bytes_calibrated", 0) for p_ in parts),
+                              "write_bytes_calibrated": sum(p_.get("write_bytes_calibrated", 0) for p_ in parts),
+                              "algorithmic_bytes": man.get("alg_bytes_bwd"), "hbm_over_algorithmic": tot / man["alg_bytes_bwd"] if man.get("alg_bytes_bwd") else None}
 
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 json.dump(res, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1)
