@@ -494,9 +494,19 @@ def main():
     n_sub = max(5, a.steps // 2)   # steps of the secondary measurements
 
     compute_stream = None
+    cu_mask_note = None
     if multi and a.lookup_cus > 0:
-        compute_stream = masked_stream(a.lookup_cus, dev)
-        torch.cuda.set_stream(compute_stream)      # lookups, backward and the c10d stream hand-offs all key on it
+        try:                                        # rank-local: creating the masked stream
+            compute_stream = masked_stream(a.lookup_cus, dev)
+        except Exception as exc:
+            compute_stream, cu_mask_note = None, f"hipExtStreamCreateWithCUMask failed on a rank ({exc}): unmasked compute stream"
+        ok = torch.tensor([1 if compute_stream is not None else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # every rank masked, or none (the timed steps are collectives)
+        if int(ok[0]):
+            torch.cuda.set_stream(compute_stream)  # lookups, backward and the c10d stream hand-offs all key on it
+        else:
+            compute_stream, a.lookup_cus = None, 0
+            cu_mask_note = cu_mask_note or "hipExtStreamCreateWithCUMask failed on another rank: unmasked compute stream"
 
     # ---- the step ---------------------------------------------------------------------------------------------
     out_shape = (B_glob, T_loc * D) if (multi or a.layout == "bd") else (T_loc, B_glob, D)
@@ -728,7 +738,7 @@ def main():
 
         result["overlap"] = {"step_s": dev_s, "lookup_only_s": zipf_s, "all_to_all_only_s": a2a_s,
                              "overlap_eff": max(zipf_s, a2a_s) / dev_s, "serial_s": zipf_s + a2a_s,
-                             "lookup_cus": a.lookup_cus or 256,
+                             "lookup_cus": a.lookup_cus or 256, **({"lookup_cus_note": cu_mask_note} if cu_mask_note else {}),
                              "definition": "max(lookup, exchange) / pipelined step: 1.0 = the shorter of the two is fully hidden"}
         # the same pipelined step on the OTHER kind of compute stream (unmasked if the run's is masked, 224 CUs if it is not): whether
         # RCCL's kernels want CUs of their own shows in the difference, on a real mesh
