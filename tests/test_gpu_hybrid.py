@@ -293,3 +293,88 @@ def test_lookback_sort_on_a_cu_masked_stream_beside_a_saturating_forward():
             k, v = k.cpu().numpy(), v.cpu().numpy()
             for t in range(len(rows)):
                 assert np.array_equal(k[t * n1:(t + 1) * n1], expect[t][0]) and np.array_equal(v[t * n1:(t + 1) * n1], expect[t][1]), (it, t)
+
+
+import os  # noqa: E402
+
+_HYB_SEEDS = int(os.environ.get("PARAM_AMD_HYBRID_FUZZ_SEEDS", "10"))      # soak runs raise it
+
+
+@pytest.mark.parametrize("seed", range(_HYB_SEEDS))
+def test_random_mid_size_requests_hybrid_vs_sorted_and_oracle(seed, coracle):
+    """Random requests LARGE enough for tables to qualify (the small-request fuzz of test_gpu_fuzz.py never reaches 8192 lookups
+    per table): 1 .. 10 tables of mixed sizes, per-table pooling factors, some tables ragged, Zipf or uniform per table, dims,
+    fp32 / bf16 tables, int32 / int64 indices, both layouts, batch slices, plain update or fused Adagrad; classified (enable 1) and
+    forced (enable 2).  Bar: the hybrid result equals the hybrid-off result bit for bit on every row looked up at most 256 times
+    (everywhere else to fp32 association), and table 0 equals the oracle (fp32, plain update)."""
+    import param_amd
+    from param_amd.indices import tbe_request
+
+    rng = np.random.default_rng(7000 + seed)
+    T = int(rng.integers(1, 11))
+    B = int(rng.choice([512, 1024, 2048, 4096]))
+    wdt = torch.bfloat16 if rng.random() < 0.35 else torch.float32
+    D = int(rng.choice([32, 64, 128, 256]))
+    rows = [int(rng.choice([3, 1000, 60_000, 300_000, 1_000_000, 2_500_000])) for _ in range(T)]
+    pools = [int(rng.choice([1, 4, 9, 20, 40])) for _ in range(T)]
+    alphas = [1.05 if rng.random() < 0.35 else 0.0 for _ in range(T)]
+    idt = torch.int32 if rng.random() < 0.4 else torch.int64
+    layout = "tbd" if rng.random() < 0.4 else "bd"
+    adagrad = rng.random() < 0.3
+    parts, lens = [], []
+    for t in range(T):
+        i_t, _ = tbe_request([rows[t]], B, [pools[t]], alpha=alphas[t], device=DEV, seed=int(rng.integers(1 << 30)))
+        ln = torch.full((B,), pools[t], dtype=torch.int64, device=DEV)
+        if rng.random() < 0.25 and pools[t] > 1:              # a ragged table: same lookups, uneven bags
+            cut = torch.randint(0, pools[t], (B // 2,), device=DEV)
+            ln[0:B // 2 * 2:2] -= cut
+            ln[1:B // 2 * 2:2] += cut
+        parts.append(i_t)
+        lens.append(ln)
+    idx = torch.cat(parts).to(idt)
+    off = torch.zeros(T * B + 1, dtype=torch.int64, device=DEV)
+    torch.cumsum(torch.cat(lens), 0, out=off[1:])
+    off = off.to(idt)
+    gshape = (B, T * D) if layout == "bd" else (T, B, D)
+    grad = torch.randn(gshape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed))
+    b0 = int(rng.integers(0, B // 4)) if rng.random() < 0.3 else 0
+    bc = B - b0 - (int(rng.integers(0, B // 4)) if b0 else 0)
+    res, hyb_tables = {}, {}
+    for en in (0, 1, 2):
+        param_amd.set_hybrid_tuning(en)
+        m = _model(rows, D, dtype=wdt, layout=layout, seed=seed)
+        W0 = m.table(0).float().cpu().numpy().copy() if en == 0 else None
+        if adagrad:
+            m.optimizer, m.learning_rate, m.eps = "rowwise_adagrad", 0.05, 1e-8
+            if b0 == 0 and bc == B:
+                m.adagrad_step_(grad, idx, off, batch=B)
+            else:                                              # the fused optimizer takes whole batches: plain update for slices
+                m.scatter_add_(grad, idx, off, alpha=-0.05, batch=B, bag_begin=b0, bag_count=bc)
+        else:
+            m.scatter_add_(grad, idx, off, alpha=-0.05, batch=B, bag_begin=b0, bag_count=bc)
+        st = m.sort_status(idx, off, batch=B, bag_begin=b0, bag_count=bc)
+        hyb_tables[en] = st["hybrid_tables"]
+        res[en] = [m.table(t).float().cpu().numpy().copy() for t in range(T)]
+        if en == 0:
+            w0_after = res[0][0]
+            w0_before = W0
+    assert hyb_tables[0] == 0
+    idx_h, off_h = idx.cpu().numpy().astype(np.int64), off.cpu().numpy().astype(np.int64)
+    for t in range(T):
+        s = off_h[t * B + b0]
+        e = off_h[t * B + b0 + bc]
+        cold = np.bincount(idx_h[s:e], minlength=rows[t]) <= 256
+        for en in (1, 2):
+            assert np.array_equal(res[en][t][cold], res[0][t][cold]), (seed, en, t, hyb_tables)
+            # hotter rows: ordered chunk partials whose boundaries follow what else is in the sorted arrays -- fp32 association,
+            # and for bf16 tables one rounding of the result on top (an ulp of bf16 is 2^-8 relative)
+            tol = 3e-4 if wdt == torch.float32 else 1.6e-2
+            np.testing.assert_allclose(res[en][t][~cold], res[0][t][~cold], rtol=tol, atol=tol)
+    if wdt == torch.float32 and not adagrad:
+        s, e = off_h[b0], off_h[b0 + bc]
+        g0 = grad.cpu().numpy()
+        g0 = np.ascontiguousarray(g0[b0:b0 + bc, :D]) if layout == "bd" else np.ascontiguousarray(g0[0, b0:b0 + bc])
+        exp = coracle.bwd_f32(w0_before.copy(), idx_h[s:e], off_h[b0:b0 + bc] - s, g0, alpha=-0.05)
+        cold = np.bincount(idx_h[s:e], minlength=rows[0]) <= 256
+        assert np.array_equal(w0_after[cold], exp[cold]), seed
+    param_amd.set_hybrid_tuning()
