@@ -23,6 +23,7 @@ ap.add_argument("--settings", default="0,2", help="hybrid enable values")
 ap.add_argument("--requests", default="uniform,zipf1.05")
 ap.add_argument("--workload", default="tables")
 ap.add_argument("--batch", type=int, default=8192)
+ap.add_argument("--layout", default="bd", choices=["bd", "tbd"])
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 D, B, L = 128, a.batch, 20
@@ -35,8 +36,8 @@ else:
 T = len(rows)
 dt = {"fp32": torch.float32, "bf16": torch.bfloat16}[a.dtype]
 es = 4 if a.dtype == "fp32" else 2
-m = param_amd.BatchedEmbeddingBagMI355(rows, D, dtype=dt, device=dev, init="normal", seed=1, fused_update=False)
-grad = torch.randn((B, T * D), device=dev)
+m = param_amd.BatchedEmbeddingBagMI355(rows, D, dtype=dt, device=dev, init="normal", seed=1, fused_update=False, layout=a.layout)
+grad = torch.randn((B, T * D) if a.layout == "bd" else (T, B, D), device=dev)
 reqs = {"uniform": tbe_request(rows, B, pools, 0.0, device=dev, seed=2), "zipf1.05": tbe_request(rows, B, pools, 1.05, device=dev, seed=1)}
 reqs = {k: v for k, v in reqs.items() if k in a.requests.split(",")}
 n_lookups = B * sum(pools)
@@ -70,7 +71,7 @@ for setting in a.settings.split(","):
         both_s = timed(lambda: m.scatter_add_(grad, idx, off, alpha=-1e-6, batch=B), a.iters)
         st = m.sort_status(idx, off, batch=B) if hasattr(m, "sort_status") else {}
         print(json.dumps({"exp": "bwd_hybrid", "enable": en, "indices": name, "dtype": a.dtype, "tables": T,
-                          "workload": a.workload, "sort_call_ms": round(sort_s * 1e3, 4), "apply_call_ms": round(apply_s * 1e3, 4),
+                          "workload": a.workload, "layout": a.layout, "sort_call_ms": round(sort_s * 1e3, 4), "apply_call_ms": round(apply_s * 1e3, 4),
                           "total_ms": round(both_s * 1e3, 4), "alg_frac_total": round(bwd_bytes / both_s / 8e12, 4),
                           "alg_frac_apply": round(bwd_bytes / apply_s / 8e12, 4), **st}), flush=True)
 if hasattr(param_amd, "set_hybrid_tuning"):
