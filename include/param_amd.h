@@ -360,7 +360,8 @@ int pm_set_sort_tuning(int32_t mode);
  * to the sort; pm_embbag_bwd_sorted* apply the others bag-major (one row read-modify-write per lookup, the bag's gradient slice
  * in registers: 2 x D x e instead of 3 x D x e bytes through the CU per lookup) and the flagged ones through the sorted apply.
  * Same results, bit for bit (a row applied bag-major has no other lookup; the flagged lookups keep their order).
- *   enable   -1 default (= 1); 0 off; 1 on: the tables are classified at every sort, on the device, from the request alone (so
+ *   enable   -1 default (= 1); 0 off; 1 on for requests whose lookups divide evenly over the bags (every benchmark shape; ragged
+ *            and per-table-pooling requests keep the sorted path): the tables are classified at every sort, on the device, from the request alone (so
  *            the same request always takes the same path: nothing is cached or carried from step to step); 2 every structurally
  *            eligible table goes hybrid whatever its indices look like (tests)                         PARAM_AMD_BWD_HYBRID
  *   lookback_spin_cap  polls before a look-back walk of the key sort stops waiting for a predecessor and counts that tile's digits

@@ -424,8 +424,15 @@ hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, int64_t
         // on the history of the workspace: the chunk boundaries of their partial sums follow what else is in the sorted arrays).
         // (The compaction scans one count per tile of the bag-major apply, kCompactMaxTiles = 4096 per table; the apply may tile
         // twice as fine as this call's geometry when its element type differs.)
+        // Requests whose lookups do not divide evenly over the bags (ragged bags; per-table pooling factors such as Criteo's) are not
+        // offered: there the qualifying tables are a minority in practice (Criteo under uniform indices: 24 % of the lookups) and the
+        // launches that find nothing to do cost the 0.4 ms step 3-4 %.  A host-side rule on the request's shape, like everything
+        // else here a function of the request alone; enable = 2 (tests) offers every request.
         const int en = hyb_enable_knob();
-        if (g.v2 && en > 0 && !g.weighted && p.N >= static_cast<int64_t>(kHybMinCount) && p.tiles_per_table <= 2048) g.hyb = en >= 2 ? 2 : 1;
+        const int64_t tb = static_cast<int64_t>(p.T) * p.B;
+        const bool even_req = tb > 0 && p.N % tb == 0;
+        if (g.v2 && en > 0 && !g.weighted && p.N >= static_cast<int64_t>(kHybMinCount) && p.tiles_per_table <= 2048 && (even_req || en >= 2))
+            g.hyb = en >= 2 ? 2 : 1;
         std::lock_guard<std::mutex> lock(g_plan_mutex);
         // bound the record table: the OLDEST record goes (a clear() would also drop plans of workspaces that are sorted
         // but not yet applied)
@@ -582,14 +589,20 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
     ua.key_bytes = g.key_bytes;
     ua.tile_cnt = seg_sort_tile_cnt(ws.temp, static_cast<size_t>(p.N), p.T);
     ua.tile_cnt_stride = seg_sort_tile_cnt_stride(static_cast<size_t>(p.N));
-    // The bag-major kernel's tiles hold at least 32 bags whatever the forward's tiling of the request (short-bag requests tile by 8
-    // bags: 26 624 workgroups for the Criteo request, most of which find a table that did not qualify and leave -- 15 us of
-    // dispatch); a hybrid table's tile of 32 bags is at most 32 x 32 lookups (kHybMaxCount / bags), inside the LDS index tile.
+    // The bag-major kernel tiles the request by 128 bags whatever the forward's tiling (32 bags at L = 20; 8 for short-bag
+    // requests: 26 624 workgroups for the Criteo request, most of which find a table that did not qualify and leave -- 15 us of
+    // dispatch).  Measured at benchmark size, uniform indices, sort + apply ms, fp32 48 tables / bf16 64 tables (round 4, same box
+    // per pair): 32 bags 1.622 / --, 64: 1.597 / 1.287, 128: 1.555 / 1.184 (on the box where 64 read 1.617), 256 (8192-entry index
+    // tile): 1.676 / 1.232.  A hybrid table's tile of 128 bags is at most 128 x 32 lookups (kHybMaxCount / bags): the 4096-entry
+    // LDS index tile; longer tiles take the unstaged path.  Row loads in flight per lane group: 4 (2: same / -1 %, 8: -2.5 / -4 %).
     KParams q = p;
-    if (q.bags_per_block < 32) {
-        q.bags_per_block = 32;
-        q.tiles_per_table = static_cast<int32_t>((q.bag_count + 31) / 32);
-        q.idx_cap = 4096;
+    {
+        const int ub = env_int("PARAM_AMD_UNIQUE_BAGS", 128);      // experiments: bags per tile of the bag-major kernel
+        if (q.bags_per_block < ub || (getenv("PARAM_AMD_UNIQUE_BAGS") && q.bags_per_block != ub)) {
+            q.bags_per_block = ub;
+            q.tiles_per_table = static_cast<int32_t>((q.bag_count + ub - 1) / ub);
+            q.idx_cap = ub > 128 ? 8192 : 4096;
+        }
     }
     switch (dst_dtype) {
         case PM_F32: rc = bwd_unique_launch_f32(sp, q, ua, max_dim, stream); break;

@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(1024) seg_prep_tables_kernel(const void* indic
     // over the table's slice now, so that their latency passes under the check of the offsets below.
     const int64_t n_rows = rows[t];
     bool cand = t < kHybMaxTables && !bad && cnt >= kHybMinCount && cnt <= kHybMaxCount && cnt * 8 <= n_rows;     // workgroup-uniform
-    const bool sample = cand && hyb.allow != 2;                // allow == 2 (tests): structural eligibility is enough
+    const bool sample = cand && hyb.allow == 1;                // allow == 2 (tests): structural eligibility is enough; 0: nothing to decide
     uint32_t sr[2] = {0u, 0u};
     if (sample) {
         const int64_t stride = cnt / 2048;
