@@ -200,8 +200,11 @@ constexpr int kHybMaxTables = 128;              // tables eligible for the hybri
 // against four independent 2^19-bit maps (round 4, visit 3): the emit kernel's four gathers per lookup were 125 us of
 // address processing for the benchmark request.  Simulated at 163 840 uniform lookups into 10 M rows: 2.95 % of the lookups
 // flagged (1.65 % true repeats + 1.3 % false), 1.9 % with twice the words; no false negatives by construction.
-constexpr int kBloomK = 4;                      // slices of a table's map = mark workgroups per table
-constexpr int kBloomWords = 1 << 14;            // 32-bit words per slice (64 KB: seen + dup of a slice fill 128 KB of LDS)
+#ifndef PM_BLOOM_K
+#define PM_BLOOM_K 4
+#endif
+constexpr int kBloomK = PM_BLOOM_K;             // slices of a table's map = mark workgroups per table (-DPM_BLOOM_K=8: experiment builds)
+constexpr int kBloomWords = (1 << 16) / kBloomK;   // 32-bit words per slice (4 slices: 64 KB each, seen + dup of a slice fill 128 KB of LDS)
 constexpr int kBloomTableWords = kBloomK * kBloomWords;   // 65 536 words = 256 KB per table
 constexpr uint32_t kHybMaxCount = 1u << 18;     // lookups per table beyond which a 2^21-bit map flags too many unique rows
 constexpr uint32_t kHybMinCount = 8192;         // ... and below which a table is not worth three extra kernels
