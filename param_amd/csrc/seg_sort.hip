@@ -56,6 +56,9 @@ constexpr uint32_t kWaveCap = 1024;     // bucket-local sort by one wave: 16 pai
 constexpr uint32_t kLocalCap = kTile;   // ... by one workgroup; larger buckets go to the second level
 constexpr int kL2Grid = 512;            // persistent grid of the second-level passes
 constexpr int kBuildBags = 1024;        // bags per workgroup of the key-building kernel
+#ifndef PM_LB_EXP
+#define PM_LB_EXP 0    // experiment builds (tools/r4_sort_probe.py: the sort alone, results not applied): 1 no ranking, 2 no walk, 4 no stores, 8 no loads
+#endif
 constexpr int kMaxLbPasses = 5;         // passes the look-back form of mode 0 takes at most
 
 struct SegHeader {
@@ -578,7 +581,11 @@ __device__ __forceinline__ void tile_count_digits(const K (&key)[ITEMS], uint32_
             const bool valid = off < chunk && wave * chunk + off < cnt;
             const uint32_t d = static_cast<uint32_t>(key[r] >> shift) & mask;
             uint32_t below, total;
+#if PM_LB_EXP & 1
+            below = 0; total = 1;
+#else
             match_digit<RB>(d, valid, below, total);
+#endif
             const uint32_t base = valid ? wcnt[d] : 0u;
             rank[r] = base + below;
             // the lowest lane of each match set advances the digit's counter; a wave executes its LDS operations in program
@@ -793,14 +800,28 @@ __device__ __forceinline__ u32x4 load_status(const uint32_t* p) {      // device
     asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
     return v;
 }
-constexpr int kLbBatch = 4;
+#ifndef PM_LB_BATCH
+#define PM_LB_BATCH 4
+#endif
+constexpr int kLbBatch = PM_LB_BATCH;       // predecessors' rows requested per trip of the walk (8: measured no faster, round 4)
 __device__ __forceinline__ void load_status_batch(const uint32_t* const (&p)[kLbBatch], u32x4 (&v)[kLbBatch]) {
+#if PM_LB_BATCH == 8
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\t"
+        "global_load_dwordx4 %2, %10, off sc1\n\tglobal_load_dwordx4 %3, %11, off sc1\n\t"
+        "global_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
+        "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+        : "memory");
+#else
     asm volatile(
         "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
         "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
         : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3])
         : "memory");
+#endif
 }
 // `s_nop 1`: the data registers of a store wider than 64 bits must not be written by the next VALU instruction (the wait state the
 // compiler pads for stores it can see; it cannot see this one)
@@ -828,15 +849,70 @@ __global__ void __launch_bounds__(kT) seg_hist_all_kernel(const TileDesc* tiles,
     const int lane = threadIdx.x % kWave;
     uint64_t row[kTileItems];
     load_tile_rows<K>(td, src, row);
+    // Hot digits.  Lanes of a wave that add to the same counter are served one after the other, and under a skewed request most
+    // lanes do: the top digit of a Zipf(1.05) head is one value for ~70 % of the lookups, and the histogram then ran 40 us against
+    // 14 with the atomics alone removed from the uniform request's 20 (tools/r4_sort_probe.py, round 4).  So every wave looks at
+    // its first element of each pass -- up to three digits, those of the first lanes not yet accounted for -- and remembers up to
+    // two digits that eight lanes or more share; for the whole tile, lanes holding such a digit are counted with one ballot into a
+    // scalar register and added once, by one lane, at the end.  A wave that finds none (uniform indices: always) pays nothing per element: plain LDS atomics, which
+    // is also what the all-lanes-equal test of wave_hist_add cost the uniform request 6 us for.
+    constexpr uint32_t kNone = 0xffffffffu;
+    uint32_t hot0[kMaxLbPasses], hot1[kMaxLbPasses];
 #pragma unroll
-    for (int k = 0; k < kTileItems; ++k) {
-        const uint32_t i = static_cast<uint32_t>(k) * kT + threadIdx.x;
-        const bool valid = i < cnt;
+    for (int p = 0; p < kMaxLbPasses; ++p) {
+        hot0[p] = hot1[p] = kNone;
+        if (p < npass) {
+            const bool v0 = threadIdx.x < cnt;
+            const uint32_t dg = static_cast<uint32_t>(row[0] >> shift[p]) & mask[p];
+            uint64_t cand = __ballot(v0);
+            for (int r = 0; r < 3 && cand != 0; ++r) {
+                const int leader = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(cand)) - 1);
+                const uint32_t d0 = __builtin_amdgcn_readlane(dg, leader);
+                const uint64_t same = __ballot(v0 && dg == d0);
+                cand &= ~same;
+                if (__popcll(same) >= 8) {
+                    if (hot0[p] == kNone) hot0[p] = d0;
+                    else if (hot1[p] == kNone) hot1[p] = d0;
+                }
+            }
+        }
+    }
+    bool any_hot = false;
 #pragma unroll
-        for (int p = 0; p < kMaxLbPasses; ++p) {
-            if (p < npass) {
-                const uint32_t dg = static_cast<uint32_t>(row[k] >> shift[p]) & mask[p];
-                wave_hist_add(h + p * RAD, dg, valid, lane);
+    for (int p = 0; p < kMaxLbPasses; ++p) any_hot = any_hot || hot0[p] != kNone;
+    if (!any_hot) {                                                       // wave-uniform
+#pragma unroll
+        for (int k = 0; k < kTileItems; ++k) {
+            const bool valid = static_cast<uint32_t>(k) * kT + threadIdx.x < cnt;
+#pragma unroll
+            for (int p = 0; p < kMaxLbPasses; ++p)
+                if (p < npass && valid) atomicAdd(&h[p * RAD + (static_cast<uint32_t>(row[k] >> shift[p]) & mask[p])], 1u);
+        }
+    } else {
+        uint32_t c0[kMaxLbPasses], c1[kMaxLbPasses];                      // the wave's lanes that held a hot digit: scalar counts, added once
+#pragma unroll
+        for (int p = 0; p < kMaxLbPasses; ++p) c0[p] = c1[p] = 0u;
+#pragma unroll
+        for (int k = 0; k < kTileItems; ++k) {
+            const bool valid = static_cast<uint32_t>(k) * kT + threadIdx.x < cnt;
+#pragma unroll
+            for (int p = 0; p < kMaxLbPasses; ++p) {
+                if (p < npass) {
+                    const uint32_t dg = static_cast<uint32_t>(row[k] >> shift[p]) & mask[p];
+                    const bool e0 = dg == hot0[p], e1 = dg == hot1[p];    // kNone equals no digit
+                    c0[p] += static_cast<uint32_t>(__popcll(__ballot(valid && e0)));
+                    c1[p] += static_cast<uint32_t>(__popcll(__ballot(valid && e1)));
+                    if (valid && !e0 && !e1) atomicAdd(&h[p * RAD + dg], 1u);
+                }
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int p = 0; p < kMaxLbPasses; ++p) {
+                if (p < npass) {
+                    if (c0[p]) atomicAdd(&h[p * RAD + (hot0[p] & (RAD - 1))], c0[p]);
+                    if (c1[p]) atomicAdd(&h[p * RAD + (hot1[p] & (RAD - 1))], c1[p]);
+                }
             }
         }
     }
@@ -854,7 +930,7 @@ __global__ void __launch_bounds__(kT) seg_hist_all_kernel(const TileDesc* tiles,
 // grid (T, npass): bucket starts of table t in pass p = the table's first output position + exclusive scan over the digits of
 // the column sums of its tiles' counts
 template <int RB>
-__global__ void __launch_bounds__(kRadix * kScanChunks) seg_scan_all_kernel(const SegDesc* desc, const uint32_t* st, uint32_t tiles_cap, int T,
+__global__ void __launch_bounds__(kRadix * kScanChunks) seg_scan_all_kernel(const SegDesc* desc, uint32_t* st, uint32_t tiles_cap, int T,
                                                                             uint32_t* bstart_all) {
     constexpr int RAD = 1 << RB;
     constexpr int DPT = RAD / kRadix;
@@ -889,6 +965,36 @@ __global__ void __launch_bounds__(kRadix * kScanChunks) seg_scan_all_kernel(cons
 #pragma unroll
     for (int j = 0; j < DPT; ++j) s_sum[c][d0 + j * kRadix] = sum[j];
     __syncthreads();
+    if (p == 0) {
+        // Pass 0's tiles are the request's, so their counts are all here: leave every tile its INCLUSIVE prefix over the table's
+        // tiles (second sweep over the chunk, rewritten in place: this block is the only one that touches these rows).  Pass 0's
+        // workgroups then read their own row and walk nowhere; walking -- every tile of a table back to its first, nothing
+        // inclusive on the way since all start together -- measured 11 us of that pass's 41 (tools/r4_sort_timeline.sh, round 4).
+        uint32_t run[DPT];
+#pragma unroll
+        for (int j = 0; j < DPT; ++j) {
+            run[j] = 0;
+            for (int cc = 0; cc < c; ++cc) run[j] += s_sum[cc][d0 + j * kRadix];
+        }
+        for (uint32_t r = ra; r < rb; r += kScanU) {
+            uint32_t v[DPT][kScanU];
+#pragma unroll
+            for (int u = 0; u < kScanU; ++u) {
+                const uint32_t rr = r + u < rb ? r + u : rb - 1u;
+#pragma unroll
+                for (int j = 0; j < DPT; ++j) v[j][u] = st[(r0 + rr) * RAD + d0 + j * kRadix];
+            }
+#pragma unroll
+            for (int u = 0; u < kScanU; ++u)
+                if (r + u < rb) {
+#pragma unroll
+                    for (int j = 0; j < DPT; ++j) {
+                        run[j] += v[j][u] & kStValue;
+                        st[(r0 + r + u) * RAD + d0 + j * kRadix] = run[j] | kStInclusive;
+                    }
+                }
+        }
+    }
     uint32_t carry = 0;
 #pragma unroll
     for (int j = 0; j < DPT; ++j) {
@@ -941,12 +1047,21 @@ __global__ void __launch_bounds__(kT) seg_lookback_pass_kernel(const TileDesc* t
     uint32_t* st = st_all + static_cast<uint64_t>(pass) * tiles_cap * RAD;
     const int dq = (wave * 256 + lane * 4) & (RAD - 1);                       // the look-back waves' first digit
     u32x4 tb = {0u, 0u, 0u, 0u};
-    if (wave < LW) tb = *reinterpret_cast<const u32x4*>(bstart_all + (static_cast<uint64_t>(pass) * T + t) * RAD + dq);
+    u32x4 own = {0u, 0u, 0u, 0u};           // pass 0: this tile's inclusive prefix, left by seg_scan_all (the launch before: visible)
+    if (wave < LW) {
+        tb = *reinterpret_cast<const u32x4*>(bstart_all + (static_cast<uint64_t>(pass) * T + t) * RAD + dq);
+        if (pass == 0) own = *reinterpret_cast<const u32x4*>(st + static_cast<uint64_t>(g) * RAD + dq);
+    }
     const uint64_t base = src.first ? td.in_base : td.out_base;
     const bool from_idx = src.first && td.pooling > 0;    // keys formed from the index array, bag = position / pooling
     K key[kTileItems];
     uint32_t val[kTileItems];
+#if PM_LB_EXP & 8
+#pragma unroll
+    for (int r = 0; r < kTileItems; ++r) { key[r] = static_cast<K>((threadIdx.x * 2654435761u + r * 40503u + g) & 0xffffffu); val[r] = r; }
+#else
     load_tile_pairs<K>(td, src, base, from_idx, key, val);
+#endif
     uint32_t rank[kTileItems];
     tile_count_digits<K, kTileItems, RB>(key, rank, cnt, chunk, shift, mask, s_wcnt);
     tile_digit_starts<RB>(s_wcnt, s_dstart, s_tmp, s_gbase);                  // s_gbase: the tile's count of every digit, for now
@@ -960,7 +1075,12 @@ __global__ void __launch_bounds__(kT) seg_lookback_pass_kernel(const TileDesc* t
     if (wave < LW) {
         u32x4 ex = {0u, 0u, 0u, 0u};
         u32x4 open = {~0u, ~0u, ~0u, ~0u};                                    // digits still walking: all-ones
-        bool walking = j > 0;
+#if PM_LB_EXP & 2
+        bool walking = false;
+#else
+        bool walking = j > 0 && pass != 0;
+#endif
+        if (pass == 0) ex = (own & kStValue) - mine;                          // inclusive prefix minus this tile's own counts
         uint32_t k = j;                                                       // next predecessor: table tile k - 1
         while (walking) {
             // kLbBatch predecessors per trip, their rows requested together (short of predecessors, the table's first tile is
@@ -1013,7 +1133,7 @@ __global__ void __launch_bounds__(kT) seg_lookback_pass_kernel(const TileDesc* t
                 }
             }
         }
-        if (j > 0) store_status(st + static_cast<uint64_t>(g) * RAD + dq, ((ex + mine) & kStValue) | kStInclusive);
+        if (j > 0 && pass != 0) store_status(st + static_cast<uint64_t>(g) * RAD + dq, ((ex + mine) & kStValue) | kStInclusive);
         *reinterpret_cast<u32x4*>(s_gbase + dq) = tb + ex;                    // where this tile's run of each digit starts
     }
     __syncthreads();
@@ -1023,9 +1143,18 @@ __global__ void __launch_bounds__(kT) seg_lookback_pass_kernel(const TileDesc* t
         if (q < cnt) {
             const K kk = s_key[q];
             const uint32_t dg = static_cast<uint32_t>(kk >> shift) & mask;
+#if PM_LB_EXP
+            uint64_t o = static_cast<uint64_t>(s_gbase[dg]) + (q - s_dstart[dg]);
+            if (o >= hdr->n_total) o = q;           // experiment builds only: wrong ranks / prefixes must not leave the arrays
+#else
             const uint64_t o = static_cast<uint64_t>(s_gbase[dg]) + (q - s_dstart[dg]);
+#endif
+#if !(PM_LB_EXP & 4)
             kout[o] = kk;
             vout[o] = s_val[q];
+#else
+            asm volatile("" : : "v"(o), "v"(kk));
+#endif
         }
     }
 }
