@@ -930,7 +930,7 @@ __global__ void __launch_bounds__(kT) seg_hist_all_kernel(const TileDesc* tiles,
 // grid (T, npass): bucket starts of table t in pass p = the table's first output position + exclusive scan over the digits of
 // the column sums of its tiles' counts
 template <int RB>
-__global__ void __launch_bounds__(kRadix * kScanChunks) seg_scan_all_kernel(const SegDesc* desc, uint32_t* st, uint32_t tiles_cap, int T,
+__global__ void __launch_bounds__(kRadix * kScanChunks) seg_scan_all_kernel(const SegDesc* desc, const uint32_t* st, uint32_t tiles_cap, int T,
                                                                             uint32_t* bstart_all) {
     constexpr int RAD = 1 << RB;
     constexpr int DPT = RAD / kRadix;
@@ -965,36 +965,6 @@ __global__ void __launch_bounds__(kRadix * kScanChunks) seg_scan_all_kernel(cons
 #pragma unroll
     for (int j = 0; j < DPT; ++j) s_sum[c][d0 + j * kRadix] = sum[j];
     __syncthreads();
-    if (p == 0) {
-        // Pass 0's tiles are the request's, so their counts are all here: leave every tile its INCLUSIVE prefix over the table's
-        // tiles (second sweep over the chunk, rewritten in place: this block is the only one that touches these rows).  Pass 0's
-        // workgroups then read their own row and walk nowhere; walking -- every tile of a table back to its first, nothing
-        // inclusive on the way since all start together -- measured 11 us of that pass's 41 (tools/r4_sort_timeline.sh, round 4).
-        uint32_t run[DPT];
-#pragma unroll
-        for (int j = 0; j < DPT; ++j) {
-            run[j] = 0;
-            for (int cc = 0; cc < c; ++cc) run[j] += s_sum[cc][d0 + j * kRadix];
-        }
-        for (uint32_t r = ra; r < rb; r += kScanU) {
-            uint32_t v[DPT][kScanU];
-#pragma unroll
-            for (int u = 0; u < kScanU; ++u) {
-                const uint32_t rr = r + u < rb ? r + u : rb - 1u;
-#pragma unroll
-                for (int j = 0; j < DPT; ++j) v[j][u] = st[(r0 + rr) * RAD + d0 + j * kRadix];
-            }
-#pragma unroll
-            for (int u = 0; u < kScanU; ++u)
-                if (r + u < rb) {
-#pragma unroll
-                    for (int j = 0; j < DPT; ++j) {
-                        run[j] += v[j][u] & kStValue;
-                        st[(r0 + r + u) * RAD + d0 + j * kRadix] = run[j] | kStInclusive;
-                    }
-                }
-        }
-    }
     uint32_t carry = 0;
 #pragma unroll
     for (int j = 0; j < DPT; ++j) {
@@ -1047,11 +1017,7 @@ __global__ void __launch_bounds__(kT) seg_lookback_pass_kernel(const TileDesc* t
     uint32_t* st = st_all + static_cast<uint64_t>(pass) * tiles_cap * RAD;
     const int dq = (wave * 256 + lane * 4) & (RAD - 1);                       // the look-back waves' first digit
     u32x4 tb = {0u, 0u, 0u, 0u};
-    u32x4 own = {0u, 0u, 0u, 0u};           // pass 0: this tile's inclusive prefix, left by seg_scan_all (the launch before: visible)
-    if (wave < LW) {
-        tb = *reinterpret_cast<const u32x4*>(bstart_all + (static_cast<uint64_t>(pass) * T + t) * RAD + dq);
-        if (pass == 0) own = *reinterpret_cast<const u32x4*>(st + static_cast<uint64_t>(g) * RAD + dq);
-    }
+    if (wave < LW) tb = *reinterpret_cast<const u32x4*>(bstart_all + (static_cast<uint64_t>(pass) * T + t) * RAD + dq);
     const uint64_t base = src.first ? td.in_base : td.out_base;
     const bool from_idx = src.first && td.pooling > 0;    // keys formed from the index array, bag = position / pooling
     K key[kTileItems];
@@ -1078,9 +1044,8 @@ __global__ void __launch_bounds__(kT) seg_lookback_pass_kernel(const TileDesc* t
 #if PM_LB_EXP & 2
         bool walking = false;
 #else
-        bool walking = j > 0 && pass != 0;
+        bool walking = j > 0;
 #endif
-        if (pass == 0) ex = (own & kStValue) - mine;                          // inclusive prefix minus this tile's own counts
         uint32_t k = j;                                                       // next predecessor: table tile k - 1
         while (walking) {
             // kLbBatch predecessors per trip, their rows requested together (short of predecessors, the table's first tile is
@@ -1133,7 +1098,7 @@ __global__ void __launch_bounds__(kT) seg_lookback_pass_kernel(const TileDesc* t
                 }
             }
         }
-        if (j > 0 && pass != 0) store_status(st + static_cast<uint64_t>(g) * RAD + dq, ((ex + mine) & kStValue) | kStInclusive);
+        if (j > 0) store_status(st + static_cast<uint64_t>(g) * RAD + dq, ((ex + mine) & kStValue) | kStInclusive);
         *reinterpret_cast<u32x4*>(s_gbase + dq) = tb + ex;                    // where this tile's run of each digit starts
     }
     __syncthreads();
