@@ -811,6 +811,15 @@ def main():
             r["sort"] = model.sort_status(i, o, batch=B_glob)      # synchronous read-back, after the timed regions
             r["method"] = ("hybrid: rows looked up once applied bag-major (gradient slice in registers), flagged lookups sorted + sorted apply"
                            if r["sort"]["hybrid_tables"] else r["method"])
+            # the whole key sort of this request on its own (all lookups through the look-back radix sort: what a request that is
+            # not offered the hybrid path pays; with the hybrid kernels launched, avg_s_sort above is only their first part)
+            param_amd.set_hybrid_tuning(0)
+            try:
+                for _ in range(2):
+                    model.sort_indices(i, o, batch=B_glob)
+                _, r["avg_s_whole_key_sort"] = time_steps(lambda: model.sort_indices(i, o, batch=B_glob), n_sub, 2, barrier)
+            finally:
+                param_amd.set_hybrid_tuning(-1)          # back to the default (PARAM_AMD_BWD_HYBRID or on)
             if r["sort"]["hybrid_launched"]:
                 r["note"] = ("while the hybrid kernels are launched the sort call holds the classification + dup maps only and the rest of the "
                              "sort runs inside the apply call: avg_s_sort / apply_only split accordingly, sort + apply is the comparable number")

@@ -11,10 +11,10 @@ if "other_layout" in d:
     print("other layout", o["output_layout"], "zipf G", round(o["zipf_lookups_per_s"] / 1e9, 2), "uniform frac", round(o.get("uniform_frac", 0), 4))
 if "bwd_scatter_add" in d:
     b = d["bwd_scatter_add"]
-    print("bwd zipf ms", round(b["avg_s_sort_plus_apply"] * 1e3, 4), "apply", round(b["avg_s_apply_only"] * 1e3, 4), b.get("sort"))
+    print("bwd zipf ms", round(b["avg_s_sort_plus_apply"] * 1e3, 4), "apply", round(b["avg_s_apply_only"] * 1e3, 4), "whole key sort ms", round(b.get("avg_s_whole_key_sort", 0) * 1e3, 4), b.get("sort"))
     if "uniform" in b:
         u = b["uniform"]
-        print("bwd uniform ms", round(u["avg_s_sort_plus_apply"] * 1e3, 4), "frac", round(u["frac"], 4), "apply_only_frac", round(u["apply_only_frac"], 4), u.get("sort"))
+        print("bwd uniform ms", round(u["avg_s_sort_plus_apply"] * 1e3, 4), "frac", round(u["frac"], 4), "apply_only_frac", round(u["apply_only_frac"], 4), "whole key sort ms", round(u.get("avg_s_whole_key_sort", 0) * 1e3, 4), u.get("sort"))
     f = d["fwd_bwd_step"]
     print("fwd+bwd ms zipf", round(f["avg_s"] * 1e3, 4), "uniform", round(f.get("uniform", {}).get("avg_s", 0) * 1e3, 4), "frac", f.get("uniform", {}).get("frac"))
 for k in ("bf16_T64", "criteo"):
