@@ -33,6 +33,25 @@ namespace {
 struct bf16_t { uint16_t v; };
 struct f16_t { uint16_t v; };
 
+#ifndef PM_FWD_STORE
+#define PM_FWD_STORE 0    // how the staged burst is written: 0 nt (streaming), 1 plain, 2 sc1, 3 sc0 sc1, 4 nt sc1 (experiment builds)
+#endif
+__device__ __forceinline__ void burst_store(pm::f32x4* q, pm::f32x4 v) {
+#if PM_FWD_STORE == 0
+    __builtin_nontemporal_store(v, q);
+#elif PM_FWD_STORE == 1
+    *q = v;
+#elif PM_FWD_STORE == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(q), "v"(v) : "memory");
+#elif PM_FWD_STORE == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(q), "v"(v) : "memory");
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off nt sc1\n\ts_nop 1" : : "v"(q), "v"(v) : "memory");
+#endif
+}
+#ifndef PM_FWD_EXP
+#define PM_FWD_EXP 0      // experiment builds: 1 = the staged burst is not written (what the output costs), 2 = written onto 32 KB per table (cache-resident)
+#endif
 template <typename WT> struct Elem;
 template <> struct Elem<float> {
     static constexpr int kVec = 4;
@@ -300,10 +319,21 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
         __syncthreads();
         if (p.out_bits == 0) {
             const int q = D / 4;                       // 16-byte pieces per row
-            for (int i = threadIdx.x; i < nb * q; i += kBlock) {
-                const int bg = i / q, c4 = i % q;
+            auto piece = [&](int bg, int c4) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(s_out + static_cast<size_t>(bg) * D + c4 * 4);
-                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out_t + (bag0 + bg) * p.out_stride + c4 * 4));
+#if PM_FWD_EXP & 1
+                asm volatile("" : : "v"(v));
+#elif PM_FWD_EXP & 2
+                burst_store(reinterpret_cast<f32x4*>(out_t + ((bag0 + bg) & 63) * p.out_stride + c4 * 4), v);      // every tile onto the table's first 64 rows
+#else
+                burst_store(reinterpret_cast<f32x4*>(out_t + (bag0 + bg) * p.out_stride + c4 * 4), v);
+#endif
+            };
+            if ((q & (q - 1)) == 0) {                  // piece i is (i >> lg, i & (q - 1)): no integer division per 16 bytes
+                const int lg = 31 - __builtin_clz(static_cast<unsigned>(q));
+                for (int i = threadIdx.x; i < nb * q; i += kBlock) piece(i >> lg, i & (q - 1));
+            } else {
+                for (int i = threadIdx.x; i < nb * q; i += kBlock) piece(i / q, i % q);
             }
         } else {
             quantized_burst(p, s_out, nb, D, bag0, p.out_offsets[t]);

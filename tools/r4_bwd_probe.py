@@ -24,6 +24,7 @@ ap.add_argument("--requests", default="uniform,zipf1.05")
 ap.add_argument("--workload", default="tables")
 ap.add_argument("--batch", type=int, default=8192)
 ap.add_argument("--layout", default="bd", choices=["bd", "tbd"])
+ap.add_argument("--row-policies", default="-1", help="comma-separated pm_set_tuning nt_loads values (destination-row cache policy; -1 = the default)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 D, B, L = 128, a.batch, 20
@@ -61,17 +62,20 @@ for idx, off in reqs.values():
     for _ in range(15):
         m.scatter_add_(grad, idx, off, alpha=-1e-6, batch=B)
 torch.cuda.synchronize()
-for setting in a.settings.split(","):
+from param_amd import _lib as _pm_lib  # noqa: E402
+
+for setting, pol in [(s_, int(p_)) for s_ in a.settings.split(",") for p_ in a.row_policies.split(",")]:
     en = int(setting.split(":")[0])
     if hasattr(param_amd, "set_hybrid_tuning"):
         param_amd.set_hybrid_tuning(en)
+    _pm_lib.set_tuning(nt_loads=pol)
     for name, (idx, off) in reqs.items():
         sort_s = timed(lambda: m.sort_indices(idx, off, batch=B), a.iters)
         apply_s = timed(lambda: m.scatter_add_(grad, idx, off, alpha=-1e-6, batch=B, presorted=True), a.iters)
         both_s = timed(lambda: m.scatter_add_(grad, idx, off, alpha=-1e-6, batch=B), a.iters)
         st = m.sort_status(idx, off, batch=B) if hasattr(m, "sort_status") else {}
         print(json.dumps({"exp": "bwd_hybrid", "enable": en, "indices": name, "dtype": a.dtype, "tables": T,
-                          "workload": a.workload, "layout": a.layout, "sort_call_ms": round(sort_s * 1e3, 4), "apply_call_ms": round(apply_s * 1e3, 4),
+                          "workload": a.workload, "layout": a.layout, "row_policy": pol, "sort_call_ms": round(sort_s * 1e3, 4), "apply_call_ms": round(apply_s * 1e3, 4),
                           "total_ms": round(both_s * 1e3, 4), "alg_frac_total": round(bwd_bytes / both_s / 8e12, 4),
                           "alg_frac_apply": round(bwd_bytes / apply_s / 8e12, 4), **st}), flush=True)
 if hasattr(param_amd, "set_hybrid_tuning"):
