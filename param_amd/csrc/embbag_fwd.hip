@@ -34,7 +34,7 @@ struct bf16_t { uint16_t v; };
 struct f16_t { uint16_t v; };
 
 #ifndef PM_FWD_STORE
-#define PM_FWD_STORE 0    // how the staged burst is written: 0 nt (streaming), 1 plain, 2 sc1, 3 sc0 sc1, 4 nt sc1 (experiment builds)
+#define PM_FWD_STORE 0    // how the staged burst is written: 0 nt (streaming), 1 plain, 2 sc1, 3 sc0 sc1, 4 nt sc1, 5 sc0, 6 nt sc0, 7 nt sc0 sc1 (experiment builds)
 #endif
 __device__ __forceinline__ void burst_store(pm::f32x4* q, pm::f32x4 v) {
 #if PM_FWD_STORE == 0
@@ -45,8 +45,14 @@ __device__ __forceinline__ void burst_store(pm::f32x4* q, pm::f32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(q), "v"(v) : "memory");
 #elif PM_FWD_STORE == 3
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(q), "v"(v) : "memory");
-#else
+#elif PM_FWD_STORE == 4
     asm volatile("global_store_dwordx4 %0, %1, off nt sc1\n\ts_nop 1" : : "v"(q), "v"(v) : "memory");
+#elif PM_FWD_STORE == 5
+    asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 1" : : "v"(q), "v"(v) : "memory");
+#elif PM_FWD_STORE == 6
+    asm volatile("global_store_dwordx4 %0, %1, off nt sc0\n\ts_nop 1" : : "v"(q), "v"(v) : "memory");
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off nt sc0 sc1\n\ts_nop 1" : : "v"(q), "v"(v) : "memory");
 #endif
 }
 #ifndef PM_FWD_EXP
