@@ -372,9 +372,10 @@ struct PassSrc {
     uint32_t bag_begin;
 };
 
-// one digit histogram update of a wave: a wave whose keys all share the digit adds once (top digits of a skewed head, small
-// tables); else one LDS atomic per lane.  (Peeling the two most common digits of every wave first was tried against the Zipf
-// request's conflicts on hot digits: no change, the atomics are not what bounds the histogram kernel.)
+// one digit histogram update of a wave (the per-pass histogram kernel of mode 3): a wave whose keys all share the digit adds
+// once (top digits of a skewed head, small tables); else one LDS atomic per lane.  The all-pass histogram of mode 0 does better
+// (seg_hist_all_kernel: hot digits found once per wave, counted by ballot) -- same-address LDS atomics are served one lane after
+// the other, and that WAS what bounded it under a skewed request.
 __device__ __forceinline__ void wave_hist_add(uint32_t* h, uint32_t dg, bool valid, int lane) {
     const uint64_t vmask = __ballot(valid);
     const uint32_t firstd = __builtin_amdgcn_readfirstlane(dg);
