@@ -33,7 +33,6 @@ class commsComputeBench(commsCollBench):
         parser.add_argument("--mode", type=str, default="comms-compute", choices=["compute", "comms-compute"])
         parser.add_argument("--kernel", type=str, default="emb_lookup", choices=["emb_lookup"])
         parser.add_argument("--num-compute", "--num-compute-per-iteration", type=int, default=100, dest="num_compute")
-        parser.add_argument("--num-coll", "--num-coll-per-iteration", type=int, default=1, dest="num_coll")
         parser.add_argument("--emb-dim", type=int, default=128)
         parser.add_argument("--num-embs", type=int, default=100000)
         parser.add_argument("--batch-size", type=int, default=512)

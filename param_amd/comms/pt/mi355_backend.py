@@ -702,6 +702,8 @@ class MI355XBackend(backendFunctions):
 
     def initialize_groups(self, groupRanks=None, backend="nccl", force_new_group=False):
         groups = {}
+        if groupRanks is None:          # the reference's driver leaves the table on the object first (comms.py:1455-1456)
+            groupRanks = getattr(self, "groupRanks", None)
         for pg_id, ranks in (groupRanks or {}).items():
             if len(ranks) == self.get_world_size() and not force_new_group:
                 groups[pg_id] = self.get_default_group()

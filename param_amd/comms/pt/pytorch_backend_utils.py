@@ -18,9 +18,14 @@ logger = logging.getLogger(__name__)
 
 supportedDevices = ["cpu", "cuda", "rocm"]
 supportedC10dBackends = ["nccl", "gloo"]  # "nccl" IS RCCL on ROCm
-# collectives on (or next to) the DLRM sparse-feature path; the reference's wider list
-# (pytorch_backend_utils.py:35-53) covers benchmarks outside this build's scope
-supportedCollectives = ["all_to_all", "all_to_allv", "all_to_all_single", "all_reduce", "reduce", "barrier"]
+# the reference's list (pytorch_backend_utils.py:35-53) without all_gather_v / reduce_scatter_v, which its own c10d backend has
+# no entry for either, plus the two names its drivers also dispatch on (all_to_all_single, barrier).  The all-to-all family
+# is the DLRM sparse path; the rest is what the sweep driver and the trace replay can be asked for.
+supportedCollectives = ["all_to_all", "all_to_allv", "all_to_all_single", "all_reduce", "reduce", "barrier",
+                        "all_gather", "all_gather_base", "all_gather_object", "gather", "scatter", "broadcast",
+                        "broadcast_object_list", "reduce_scatter", "reduce_scatter_base", "incast", "multicast"]
+pt2ptPatterns = ["one2one", "pairwise"]
+supportedP2pOps = ["send", "recv", "isend", "irecv"]
 
 
 class collectiveArgsHolder:
@@ -81,6 +86,17 @@ class collectiveArgsHolder:
         self.graph_launches = 0
         self.use_device_time = False
         self.timers = {}
+        # sweep driver: process-group id of this rank (--multi-comms), point-to-point patterns, incast / multicast rank lists
+        self.pgId = 0
+        self.pt2pt = None
+        self.window = 100
+        self.src_ranks = None
+        self.dst_ranks = None
+        self.src_rank = -1
+        self.dst_rank = -1
+        self.p2pOps = []
+        self.comm_dev_time = None
+        self.profiler = None
 
 
 class backendFunctions(ABC):

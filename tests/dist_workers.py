@@ -435,6 +435,25 @@ def comms_sweep_plugin_fixture(rank, world, port, outdir, argv_json):
         f.write(buf.getvalue())
 
 
+def comms_surface_case(rank, world, port, outdir, case_json):
+    """this build's comms.py with one argument list of tests/golden/comms_surface.json (what the REFERENCE printed for it)"""
+    import contextlib
+    import io
+    import json
+
+    from param_amd.comms.pt import comms
+
+    _env(rank, world, port)
+    case = json.loads(case_json)
+    argv = ["--master-ip", "127.0.0.1", "--master-port", str(port), "--n", "3", "--w", "1", "--backend", "gloo", "--device", "cpu"]
+    argv += case["argv"] + (case["per_rank"][rank] if "per_rank" in case else [])
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        res = comms.main(argv)
+    with open(os.path.join(outdir, f"rank{rank}.json"), "w") as f:
+        json.dump({"results": res, "stdout": buf.getvalue()}, f)
+
+
 def sharded_exchange(rank, world, port, n_tables=3):
     """ShardedEmbeddingExchange on an UNEVEN table split (3 tables of mixed dims over 2 ranks -> [2, 1]; 26 mixed tables over
     4 / 8 ranks -> the reference's [7, 7, 6, 6] / [4, 4, 3, 3, 3, 3, 3, 3], dlrm.py:390-398): forward receive blocks, the

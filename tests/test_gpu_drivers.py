@@ -237,7 +237,7 @@ def test_comms_compute_overlap_bench_single_gpu():
     res = commsComputeBench.main(["--master-ip", "127.0.0.1", "--master-port", str(_port()), "--b", "4M", "--e", "4M",
                                   "--n", "3", "--w", "1", "--collective", "all_to_allv", "--device", "rocm", "--kernel", "emb_lookup",
                                   "--ntables", "4", "--num-embs", "50000", "--batch-size", "512", "--bitwidth", "8",
-                                  "--quant-a2a-embedding-dim", "128"])
+                                  "--quant-a2a-embedding-dim", "128", "--z", "1"])
     assert res[0]["bitwidth"] == 8 and res[0]["quant_us"] > 0 and res[0]["dequant_us"] > 0 and res[0]["compute_dev_us"] > 0
 
 

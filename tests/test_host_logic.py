@@ -312,3 +312,97 @@ def test_graph_launches_flag_is_checked_like_the_reference():
     bench, a = parse(["--graph-launches", "2", "--device", "cpu", "--backend", "gloo"])
     with pytest.raises(SystemExit):
         bench.checkArgs(a)
+
+
+def _parse_comms(argv):
+    import argparse
+    import sys
+
+    from param_amd.comms.pt import comms
+
+    bench = comms.commsCollBench()
+    old = sys.argv
+    sys.argv = ["comms.py"] + argv
+    try:
+        return bench, bench.readArgs(argparse.ArgumentParser())
+    finally:
+        sys.argv = old
+
+
+def test_comms_cli_defaults_equal_the_reference_parser(golden_dir):
+    """tests/golden/comms_cli_defaults.json: defaults of the REFERENCE's comms.py parser for every flag this build keeps
+    (gen_comms_surface.py ran the reference's ``readArgs`` here).  Same defaults, so a command line without a flag means the
+    same run: non-blocking (``--z 0``), all_reduce, 8 .. 64 bytes, window 100, one communicator group."""
+    gold = json.load(open(os.path.join(golden_dir, "comms_cli_defaults.json")))
+    bench, a = _parse_comms([])
+    for k, v in gold.items():
+        mine = getattr(a, k)
+        if k == "data_types":
+            mine = [d for d in mine.split(",")]
+        assert mine == v, (k, mine, v)
+    # the reference's spellings of the flags (comms.py:50-206, comms_utils.py:1713-1879) all parse
+    bench, a = _parse_comms(["--num_iters", "7", "--num-coll-per-iteration", "2", "--begin-size", "1K", "--end-size", "2K",
+                             "--in-split", "1,2", "--out-split", "3,4", "--sizes", "8,16", "--data-type", "int32",
+                             "--collectives", "all_to_allv", "--pa", "3", "--blocking", "1", "--log-level", "INFO",
+                             "--src-ranks", "0:1", "--dst-ranks", "2,3", "--root", "1", "--multi-comms", "2", "--window", "9"])
+    assert (a.n, a.num_coll, a.b, a.e, a.i, a.o, a.ss, a.data_types, a.collective, a.profiler_active_iters, a.z, a.log) == \
+           (7, 2, "1K", "2K", [1, 2], [3, 4], [8, 16], "int32", "all_to_allv", 3, 1, "INFO")
+    bench.checkArgs(a)
+    assert (a.b, a.e, a.collectives, a.dtypes, a.split_elements) == (1024, 2048, ["all_to_allv"], ["int32"], 3)
+
+
+def test_comms_cli_argument_checks():
+    """what the reference refuses (comms.py:208-243, 294-334, 761-806): --i / --o without all_to_allv, an unknown collective,
+    bfloat16 on gloo, --graph-launches with --pt2pt; --pt2pt replaces the collective list; --c 1 is dropped for non-blocking
+    reductions; pt2pt rank lists are validated per pattern"""
+    from param_amd.comms.pt import comms
+
+    bench, a = _parse_comms(["--i", "4,4", "--collective", "all_reduce"])
+    with pytest.raises(SystemExit):
+        bench.checkArgs(a)
+    bench, a = _parse_comms(["--collective", "all_to_all,nonsense"])
+    with pytest.raises(SystemExit):
+        bench.checkArgs(a)
+    bench, a = _parse_comms(["--data-types", "bfloat16", "--backend", "gloo", "--device", "cpu"])
+    with pytest.raises(SystemExit):
+        bench.checkArgs(a)
+    bench, a = _parse_comms(["--pt2pt", "one2one", "--graph-launches", "3", "--device", "rocm"])
+    with pytest.raises(SystemExit):
+        bench.checkArgs(a)
+    bench, a = _parse_comms(["--pt2pt", "pairwise", "--collective", "all_reduce", "--tag", "x", "--size-start-profiler", "1K"])
+    bench.checkArgs(a)
+    assert a.collectives == ["pt2pt"] and bench.tag == "-x" and a.size_start_profiler == 1024
+    bench, a = _parse_comms(["--c", "1", "--z", "0", "--collective", "all_to_allv,reduce_scatter"])
+    bench.checkArgs(a)
+    assert a.c == 0
+    bench, a = _parse_comms(["--c", "1", "--z", "0", "--collective", "all_to_allv,all_gather"])
+    bench.checkArgs(a)
+    assert a.c == 1
+    # pt2pt rank lists (checkPt2PtRanks): defaults 0 -> 1; one2one takes one pair; pairwise wants equal, disjoint lists
+    for pattern, src, dst, ok in (("one2one", None, None, True), ("one2one", [0, 1], [2], False), ("pairwise", [0, 1], [2, 3], True),
+                                  ("pairwise", [0, 1], [2], False), ("pairwise", [0, 1], [1, 2], False), ("one2one", [0], [9], False)):
+        bench = comms.commsCollBench()
+        bench.report, bench.comm_size = False, 4
+        ca = bench.collectiveArgs
+        ca.collective, ca.pt2pt, ca.src_ranks, ca.dst_ranks = "pt2pt", pattern, src, dst
+        if ok:
+            bench.checkPt2PtRanks()
+            assert (ca.src_ranks, ca.dst_ranks) == (src or [0], dst or [1])
+        else:
+            with pytest.raises(SystemExit):
+                bench.checkPt2PtRanks()
+    # incast / multicast: every rank but the root unless listed (checkCollectiveRanks)
+    bench = comms.commsCollBench()
+    bench.report, bench.comm_size = False, 4
+    ca = bench.collectiveArgs
+    ca.collective, ca.srcOrDst, ca.src_ranks = "incast", 2, None
+    bench.checkCollectiveRanks()
+    assert ca.src_ranks == [0, 1, 3]
+    ca.collective, ca.srcOrDst, ca.dst_ranks = "multicast", 0, [0, 1, 2]
+    bench.checkCollectiveRanks()
+    assert ca.dst_ranks == [1, 2]
+    # the pt2pt row / header text: field widths of the reference's format strings (comms.py:961, 1244)
+    hdr = comms.format_pt2pt_header()
+    row = comms.format_pt2pt_row("recv", "float32", "-t", 1024, (1.0, 2.0, 3.0), (4.0, 5.0, 6.0), 0.5, 0.75, 1.0, 1.5)
+    assert hdr.startswith("\n\tCOMMS-RES" + " " * 32 + "size (B)") and hdr.endswith("totalBiBW(GB/s)")
+    assert row.split() == ["COMMS-RES-recv-float32-t", "1024", "1.0", "2.0", "3.0", "4.0", "5.0", "6.0", "0.500", "0.750", "1.000", "1.500"]
