@@ -30,6 +30,7 @@ import argparse
 import json
 import logging
 import os
+import sys
 import time
 from typing import Callable, List, Optional, Sequence, Tuple
 
@@ -330,7 +331,44 @@ class commsDLRMBench:
                                  "seeded with the rank (dlrm.py:629) -- identical batches, host-side")
         parser.add_argument("--use-device-time", action="store_true", default=False)  # reference bug R1: never registered there
         parser.add_argument("--log", type=str, default="ERROR")
+        # sizing of the top MLP's first layer, i.e. of the first dense all_reduce (dlrm.py:583-601)
+        parser.add_argument("--arch-interaction-op", type=str, default="dot", help="dot | cat")
+        parser.add_argument("--arch-interaction-itself", action="store_true", default=False)
+        parser.add_argument("--arch-project-size", type=int, default=0, help="project size for the interaction features")
+        parser.add_argument("--model", type=str, default="dlrm", help="Model to be benchmarked (dlrm)")
+        parser.add_argument("--perf-debug", action="store_true", help="extra barriers between the regions of the backward (dlrm.py:1261-1299)")
+        # parsed by the reference for the DLRM data loader it borrows, without effect on the comms benchmark's batches
+        # (dlrm_data.py reads only --data-generation / --data-size / --round-targets): accepted so that a reference
+        # command line runs unchanged
+        parser.add_argument("--num-workers", type=int, default=0)
+        parser.add_argument("--data-size", type=int, default=1)
+        parser.add_argument("--synthetic-data-folder", type=str, default="./synthetic_data/syn_data_bs65536/")
+        parser.add_argument("--round-targets", type=bool, default=False)
+        parser.add_argument("--rand-data-dist", type=str, default="uniform")
+        parser.add_argument("--rand-data-min", type=float, default=0)
+        parser.add_argument("--rand-data-max", type=float, default=1)
+        parser.add_argument("--rand-data-mu", type=float, default=-1)
+        parser.add_argument("--rand-data-sigma", type=float, default=1)
+        parser.add_argument("--data-trace-file", type=str, default="./input/dist_emb_j.log")
+        parser.add_argument("--data-trace-enable-padding", type=bool, default=False)
         return parser.parse_args(argv)
+
+    @staticmethod
+    def top_mlp_input_size(args, n_tables: int) -> int:
+        """width of the interaction output that feeds the top MLP (dlrm.py:575-601): (tables + 1) features; ``dot`` = unique
+        pairs (with the diagonal under --arch-interaction-itself) + the bottom MLP's output, ``cat`` = every feature at the
+        bottom MLP's output width; --arch-project-size replaces either by features x project size + bottom output"""
+        num_fea = n_tables + 1
+        m_den_out = int(args.arch_mlp_bot.split("-")[-1])
+        if args.arch_interaction_op == "dot":
+            num_int = (num_fea * (num_fea + 1 if args.arch_interaction_itself else num_fea - 1)) // 2 + m_den_out
+        elif args.arch_interaction_op == "cat":
+            num_int = num_fea * m_den_out
+        else:
+            sys.exit("ERROR: --arch-interaction-op=" + args.arch_interaction_op + " is not supported")
+        if args.arch_project_size > 0:
+            num_int = num_fea * args.arch_project_size + m_den_out
+        return num_int
 
     def run(self, args, lookup_factory=None):
         """``lookup_factory(rows, dim, device, dtype) -> (lookup, update)`` overrides the HIP kernels
@@ -338,6 +376,9 @@ class commsDLRMBench:
         env = comms_utils.read_comms_env_vars()
         if env["world_size"] < 1:
             env = {"world_size": 1, "local_size": 1, "global_rank": 0, "local_rank": 0}
+        if getattr(args, "model", "dlrm") != "dlrm":                       # dlrm.py:510-555
+            print("Model " + args.model + " not supported...Abort!")
+            sys.exit(1)
         info = comms_utils.bootstrap_info_holder(args.master_ip, args.master_port, 0, env)
         device = "cuda" if args.device == "rocm" else args.device
         bf = MI355XBackend(info, {"device": device, "backend": args.backend})
@@ -369,11 +410,7 @@ class commsDLRMBench:
         def layers(spec):
             dims = [int(x) for x in spec.split("-")]
             return [torch.rand(dims[i + 1], dims[i], device=dev) for i in range(len(dims) - 1)]
-        # top MLP input = dot-interaction of (tables + 1) features, unique pairs, + bottom output
-        # (dlrm.py:575-603, --arch-interaction-op dot, not itself): num_int = f(f-1)/2 + m_den_out
-        num_fea = len(ln_emb) + 1
-        m_den_out = int(args.arch_mlp_bot.split("-")[-1])
-        num_int = (num_fea * (num_fea - 1)) // 2 + m_den_out
+        num_int = self.top_mlp_input_size(args, len(ln_emb))
         top, bot = layers(f"{num_int}-{args.arch_mlp_top}"), layers(args.arch_mlp_bot)
         gen = torch.Generator(device=dev)
         gen.manual_seed(args.numpy_rand_seed + rank)
@@ -397,12 +434,18 @@ class commsDLRMBench:
             pooled, out_split, in_split = path.alltoallv_fwd(ly)
             timers["grad_push_start"] = time.monotonic()
             bf.sync_barrier(ca)
+            if args.perf_debug:
+                bf.sync_barrier(ca)
             timers["bwd_top_ar_start"] = time.monotonic()
             self._all_reduce_layers(bf, ca, top, path)
             timers["bwd_top_ar_end"] = time.monotonic()
+            if args.perf_debug:
+                bf.sync_barrier(ca)
             grad_ly = path.alltoallv_bwd(pooled, out_split, in_split)       # C = tempB (dlrm.py:1255)
             if path.update is not None:
                 path.update(grad_ly, idx_tbe, off_tbe)
+            if args.perf_debug:
+                bf.sync_barrier(ca)
             timers["bwd_bot_ar_start"] = time.monotonic()
             self._all_reduce_layers(bf, ca, bot, path)
             timers["bwd_bot_ar_end"] = time.monotonic()

@@ -181,7 +181,7 @@ def dlrm_sparse_path(rank, world, port):
         bf.shutdown()
 
 
-def dlrm_driver(rank, world, port, outdir):
+def dlrm_driver(rank, world, port, outdir, extra_json="[]", num_batches="4"):
     import contextlib
     import io
     import json
@@ -205,9 +205,9 @@ def dlrm_driver(rank, world, port, outdir):
     import argparse
     args = bench.readArgs(argparse.ArgumentParser(), [
         "--master-ip", "127.0.0.1", "--master-port", str(port), "--backend", "gloo", "--device", "cpu",
-        "--mini-batch-size", "8", "--num-batches", "4", "--warmup-batches", "1", "--arch-mlp-bot", "16-8",
+        "--mini-batch-size", "8", "--num-batches", num_batches, "--warmup-batches", "1", "--arch-mlp-bot", "16-8",
         "--arch-mlp-top", "8-1", "--arch-sparse-feature-size", "8", "--arch-embedding-size", "100-200-300-400",
-        "--num-indices-per-lookup", "5", "--print-comms", "--data-generation", "random"])
+        "--num-indices-per-lookup", "5", "--print-comms", "--data-generation", "random"] + __import__("json").loads(extra_json))
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         rep = bench.run(args, lookup_factory=factory)

@@ -4,7 +4,10 @@
 run in the build container only -- the fixture (data) is committed, nothing of the reference travels.
 
 The harness below only pre-registers ``--use-device-time`` (reference bug R1: dlrm.py reads the attribute but
-never adds the flag) and then calls the reference's own entry points."""
+never adds the flag) and then calls the reference's own entry points.
+
+Also writes dlrm_np2_variants.json: the all_reduce message sizes of rank 0 under the flags that size the top MLP
+(``--arch-interaction-op cat``, ``--arch-interaction-itself``, ``--arch-project-size``; dlrm.py:583-601)."""
 import os
 import shutil
 import subprocess
@@ -45,3 +48,25 @@ if __name__ == "__main__":
     for r in (0, 1):
         shutil.copy(os.path.join(work, "dlrm_np2", f"rank{r}.json"), os.path.join(out, f"rank{r}.json"))
     print("wrote", out)
+    # top-MLP sizing variants (dlrm.py:583-601): the all_reduce message sizes of rank 0's records under
+    # --arch-interaction-op cat / --arch-interaction-itself / --arch-project-size
+    import json
+
+    variants = {"cat": ["--arch-interaction-op", "cat"], "dot_itself": ["--arch-interaction-itself"],
+                "project3": ["--arch-project-size", "3"], "cat_project2_perf_debug": ["--arch-interaction-op", "cat",
+                                                                                      "--arch-project-size", "2", "--perf-debug"]}
+    rec = {}
+    for k, (name, extra) in enumerate(variants.items()):
+        vport = str(29548 + k)
+        venv = dict(env, MASTER_PORT=vport)
+        flags = [f for f in FLAGS if f not in ("4",)]
+        flags = FLAGS[:FLAGS.index("--num-batches") + 1] + ["2"] + FLAGS[FLAGS.index("--num-batches") + 2:]
+        procs = [subprocess.Popen([sys.executable, os.path.join(work, "harness.py"), "--master-ip", "127.0.0.1",
+                                   "--master-port", vport] + flags + extra, cwd=work, env=dict(venv, RANK=str(r), LOCAL_RANK=str(r)),
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for r in (0, 1)]
+        assert [p.wait(timeout=600) for p in procs] == [0, 0], name
+        r0 = json.load(open(os.path.join(work, "dlrm_np2", "rank0.json")))
+        rec[name] = {"extra_flags": extra, "num_batches": 2,
+                     "rank0": [[c["comms"], c["msg_size"]] for c in r0 if c["comms"] == "all_reduce"]}
+        print(name, rec[name]["rank0"][:4])
+    json.dump(rec, open(os.path.join(HERE, "dlrm_np2_variants.json"), "w"), indent=1)
