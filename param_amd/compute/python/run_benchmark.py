@@ -21,14 +21,23 @@ Per (op, build, input) combination one JSON line ``{"op_name", "id": "<config>|<
 * ``--cuda-l2-cache off``: the reference flushes by writing a buffer the size of the L2 and has no entry for gfx950
   (``op_executor.py:16-28`` raises KeyError there); here the flush writes 2 x (8 x 4 MiB L2 + 256 MiB MALL).
 * ``--cuda-graph``: forward and backward captured once in HIP graphs and replayed (``op_executor.py:82-97``).
-Not kept: the NSight / CUPTI / kineto launchers, resume/stop run ids.
+* ``-r / --resume-id`` and ``-s / --stop_id``: run ids ``<op name>|<config>|<build id>|<input id>``; everything before the resume
+  id is skipped, the run ends in front of the stop id (``build_executor.py:72-102,449-463``); ``-a / --append``; ``-o`` writes
+  ``<prefix>.json`` headed by one line of run options + system information (``run_benchmark.py:334-344``); ``-p / --profile``
+  wraps the run in torch.profiler (``<prefix>_trace.json``), ``--et`` collects an execution trace (``<prefix>_et.json``);
+  ``-l / --log-level``, ``--version``.
+Not kept: the NSight / CUPTI launchers and their batch mode (NVIDIA tools; on this platform the same JSON runs under
+``rocprofv3 --kernel-trace --stats -- python -m param_amd.compute.python.run_benchmark ...``), ``--pt2-model``.
 """
 from __future__ import annotations
 
 import argparse
 import json
+import logging
+import os
 import sys
 import time
+from datetime import datetime
 
 import torch
 
@@ -45,6 +54,31 @@ def _clear_cache(device) -> None:
     if buf is None:
         buf = _flush_bufs[str(device)] = torch.empty(_FLUSH_BYTES // 4, dtype=torch.float32, device=device)
     buf.fill_(2.0)
+
+
+__version__ = "1.0.0-mi355x"       # the reference prints its package version for --version (lib/__init__.py)
+logger = logging.getLogger(__name__)
+
+
+class RunWindow:
+    """Which (op, config, build, input) combinations of a config file run: skip until the id given by ``--resume-id`` comes up,
+    run from there, stop IN FRONT of the id given by ``--stop_id`` (reference BuildExecutor.get_transition_state,
+    build_executor.py:72-102; ids ``<op name>|<config>|<build id>|<input id>``, ``:449``)."""
+
+    SKIP, RUN, STOP = "skip", "run", "stop"
+
+    def __init__(self, resume_id=None, stop_id=None):
+        self.resume_id, self.stop_id = resume_id, stop_id
+        self.state = self.SKIP if resume_id else self.RUN
+
+    def step(self, run_id: str) -> str:
+        if self.state == self.SKIP and run_id == self.resume_id:
+            self.state = self.RUN
+            logger.info(f"Resume benchmark check matched [{run_id}]")
+        if run_id == self.stop_id:
+            self.state = self.STOP
+            logger.info(f"Stop benchmark check matched [{run_id}]")
+        return self.state
 
 
 def _arg_values(arg_list):
@@ -182,7 +216,7 @@ class OpExecutor:
 
 
 def run_op(name: str, op_cfg: dict, device: str, warmup: int, iters: int, backward: bool, out_stream=None, alpha=1.0,
-           exec_mode: str = "discrete", l2_cache: bool = True, use_graph: bool = False):
+           exec_mode: str = "discrete", l2_cache: bool = True, use_graph: bool = False, window: RunWindow = None):
     if name not in op_map:
         raise KeyError(f"operator {name!r} is not registered (registered: {sorted(op_map)})")
     build_iter = op_cfg.get("build_iterator")
@@ -199,6 +233,13 @@ def run_op(name: str, op_cfg: dict, device: str, warmup: int, iters: int, backwa
             bkw = {k: v["value"] for k, v in (build.get("kwargs") or {}).items()}
             num_tables, rows, _dim, _pool, weighted = bargs[0], bargs[1], bargs[2], bargs[3], bargs[4]
             for input_id, (batch_size, pooling_factor) in tbe_input_iterator(cfg["input"]):
+                if window is not None:
+                    state = window.step(f"{name}|{ci}|{build_id}|{input_id}")
+                    if state == RunWindow.SKIP:
+                        continue
+                    if state == RunWindow.STOP:
+                        op.cleanup()
+                        return results
                 op.cleanup()
                 kw = dict(bkw)
                 if len(bargs) < 7:
@@ -218,28 +259,81 @@ def run_op(name: str, op_cfg: dict, device: str, warmup: int, iters: int, backwa
     return results
 
 
+def sys_info() -> dict:
+    """what the header line of an output file says about the box (reference get_sys_info, lib/pytorch/config_util.py)"""
+    info = {"pytorch_version": torch.__version__, "hip_version": getattr(torch.version, "hip", None), "device": None}
+    if torch.cuda.is_available():
+        props = torch.cuda.get_device_properties(0)
+        info.update({"device": props.name, "gcn_arch": getattr(props, "gcnArchName", None), "cu_count": props.multi_processor_count,
+                     "memory_GB": round(props.total_memory / 2**30, 1)})
+    return info
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description="operator microbenchmark from a JSON config (MI355X build)")
-    ap.add_argument("-c", "--config", type=str, required=True)
+    ap.add_argument("-c", "--config", type=str, help="The benchmark config file.")
     ap.add_argument("-d", "--device", type=str, default="cuda")
     ap.add_argument("-w", "--warmup", type=int, default=1)
     ap.add_argument("-i", "--iteration", type=int, default=1)
     ap.add_argument("-b", "--backward", action="store_true")
     ap.add_argument("-o", "--output-prefix", type=str, default=None, help="write <prefix>.json instead of stdout")
+    ap.add_argument("-r", "--resume-id", type=str, default=None,
+                    help="resume at this run id (<op name>|<config>|<build id>|<input id>), skip everything before it")
+    ap.add_argument("-s", "--stop_id", "--stop-id", type=str, default=None, dest="stop_id",
+                    help="stop in front of this run id, skip the rest")
+    ap.add_argument("-a", "--append", action="store_true", help="append to the output file rather than overwrite")
     ap.add_argument("--exec-mode", type=str, default="discrete", choices=["discrete", "continuous", "continuous_events"])
     ap.add_argument("--cuda-l2-cache", type=str, default="on", choices=["on", "off"],
                     help="off: flush the L2s and the memory-side cache before every timed call (discrete mode)")
     ap.add_argument("--cuda-graph", action="store_true", help="capture forward / backward in HIP graphs once and replay them")
     ap.add_argument("--alpha", type=float, default=1.0, help="generate_requests distribution switch (reference :93-135)")
+    ap.add_argument("-p", "--profile", action="store_true", help="torch.profiler around the run: <prefix>_trace.json")
+    ap.add_argument("--et", action="store_true", help="collect an execution trace: <prefix>_et.json")
+    ap.add_argument("-l", "--log-level", type=str, default="INFO")
+    ap.add_argument("--version", action="store_true", help="print the version and stop")
     a = ap.parse_args(argv)
+    logging.basicConfig(level=getattr(logging, a.log_level.upper(), logging.INFO))
+    if a.version:
+        print(f"PARAM train compute version: {__version__}")
+        return []
+    if not a.config:
+        ap.print_usage()
+        return []
+    if a.cuda_graph and not a.device.startswith(("cuda", "rocm")):
+        logger.warning("Cannot use --cuda-graph when not running on cuda device, cuda-graph is disabled")
+        a.cuda_graph = False
     cfg = json.load(open(a.config))
-    stream = open(a.output_prefix + ".json", "w") if a.output_prefix else None
+    stream = open(a.output_prefix + ".json", "a" if a.append else "w") if a.output_prefix else None
+    prefix = a.output_prefix or f"benchmark_result_{os.getpid()}"
+    window = RunWindow(a.resume_id, a.stop_id)
     out = []
+    et = prof = None
     try:
+        if stream:     # header line of the reference's result files (run_benchmark.py:334-344)
+            print(json.dumps({"run_options": {k: v for k, v in vars(a).items()}, "sys_info": sys_info(),
+                              "start_time": datetime.now().isoformat(timespec="seconds")}, default=str), file=stream)
+        if a.et:
+            from torch.profiler import ExecutionTraceObserver
+
+            et = ExecutionTraceObserver()
+            et.register_callback(f"{prefix}_et.json")
+            et.start()
+        if a.profile:
+            acts = [torch.profiler.ProfilerActivity.CPU] + ([torch.profiler.ProfilerActivity.CUDA] if torch.cuda.is_available() else [])
+            prof = torch.profiler.profile(activities=acts, record_shapes=True)
+            prof.start()
         for name, op_cfg in cfg.items():
             out += run_op(name, op_cfg, a.device, a.warmup, a.iteration, a.backward, out_stream=stream, alpha=a.alpha,
-                          exec_mode=a.exec_mode, l2_cache=a.cuda_l2_cache == "on", use_graph=a.cuda_graph)
+                          exec_mode=a.exec_mode, l2_cache=a.cuda_l2_cache == "on", use_graph=a.cuda_graph, window=window)
+            if window.state == RunWindow.STOP:
+                break
     finally:
+        if prof is not None:
+            prof.stop()
+            prof.export_chrome_trace(f"{prefix}_trace.json")
+        if et is not None:
+            et.stop()
+            et.unregister_callback()
         if stream:
             stream.close()
     return out

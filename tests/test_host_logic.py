@@ -406,3 +406,16 @@ def test_comms_cli_argument_checks():
     row = comms.format_pt2pt_row("recv", "float32", "-t", 1024, (1.0, 2.0, 3.0), (4.0, 5.0, 6.0), 0.5, 0.75, 1.0, 1.5)
     assert hdr.startswith("\n\tCOMMS-RES" + " " * 32 + "size (B)") and hdr.endswith("totalBiBW(GB/s)")
     assert row.split() == ["COMMS-RES-recv-float32-t", "1024", "1.0", "2.0", "3.0", "4.0", "5.0", "6.0", "0.500", "0.750", "1.000", "1.500"]
+
+
+def test_run_benchmark_resume_stop_window_equals_reference(golden_dir, capsys):
+    """``run_benchmark.py -r / -s``: skip / run / stop id by id equals the REFERENCE's BuildExecutor.get_transition_state for the
+    same id stream (tests/golden/run_window.json, gen_run_window.py); ``--version`` and a missing ``-c`` end the run"""
+    from param_amd.compute.python import run_benchmark as R
+
+    gold = json.load(open(os.path.join(golden_dir, "run_window.json")))
+    for case in gold["cases"]:
+        w = R.RunWindow(case["resume"], case["stop"])
+        assert [w.step(i) for i in gold["ids"]] == case["states"], case
+    assert R.main(["--version"]) == [] and "PARAM train compute version" in capsys.readouterr().out
+    assert R.main([]) == []
