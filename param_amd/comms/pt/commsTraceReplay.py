@@ -166,6 +166,12 @@ class commsTraceReplayBench:
         parser.add_argument("--use-timestamp", action="store_true", default=False)
         parser.add_argument("--rebalance-policy", type=str, default="")
         parser.add_argument("--num-replays", type=int, default=1)
+        parser.add_argument("--disable-parallel-read", action="store_true", default=False,
+                            help="with --use-one-trace: rank 0 reads the trace, the other ranks take it from the rendezvous store")
+        parser.add_argument("--enable-profiler", action="store_true", default=False, help="torch.profiler over the replays")
+        parser.add_argument("--profiler-num-replays-start", type=int, default=0,
+                            help="replay iteration (after the warm-up) at which the profiler starts")
+        parser.add_argument("--profiler-num-replays", type=int, default=10, help="replay iterations the profiler records")
         args, _ = parser.parse_known_args(argv)
         return args
 
@@ -173,6 +179,8 @@ class commsTraceReplayBench:
         if not os.path.isfile(args.trace_path) and not os.path.isdir(args.trace_path):
             raise ValueError(f"The specified trace path '{args.trace_path}' is neither a file nor a directory. "
                              "Please provide a valid path.")
+        if getattr(args, "disable_parallel_read", False) and not args.use_one_trace:      # commsTraceReplay.py:300-304
+            raise ValueError("--disable-parallel-read is valid only when --use-one-trace is used.")
         if args.trace_type not in VALID_TRACE_TYPES:
             raise ValueError(f"Trace type {args.trace_type} is not valid! Please specify one supported trace type from "
                              f"{VALID_TRACE_TYPES} by using --trace-type.")
@@ -202,6 +210,10 @@ class commsTraceReplayBench:
         self.rebalance_policy = getattr(args, "rebalance_policy", "").lower()
         self.num_replays = args.num_replays
         self.use_one_trace = args.use_one_trace
+        self.disable_parallel_read = getattr(args, "disable_parallel_read", False)
+        self.enable_profiler = getattr(args, "enable_profiler", False)
+        self.profiler_num_replays_start = getattr(args, "profiler_num_replays_start", 0)
+        self.profiler_num_replays = getattr(args, "profiler_num_replays", 10)
 
     # ------------------------------------------------------------------ statistics
     def initTraceStat(self) -> None:
@@ -536,20 +548,47 @@ class commsTraceReplayBench:
             self.replayTrace(commsParams=commsParams, warmup=True)
         self.resetComms()
         bf.sync_barrier(ca)
+        prof = None
+        if getattr(self, "enable_profiler", False):
+            # the reference skips warm-up + --profiler-num-replays-start replays and records at most --num-replays of them
+            # (commsTraceReplay.py:1165-1180; its profiler is unpublished, here torch.profiler writes a chrome trace per rank)
+            import torch
+
+            first = min(self.profiler_num_replays_start, max(self.num_replays - 1, 0))
+            active = max(1, min(self.profiler_num_replays, self.num_replays - first))
+            acts = [torch.profiler.ProfilerActivity.CPU] + ([torch.profiler.ProfilerActivity.CUDA] if ca.device.type == "cuda" else [])
+            out_dir = self.out_path or "."
+            os.makedirs(out_dir, exist_ok=True)
+            trace_file = os.path.join(out_dir, f"replay_profile_rank{bf.get_global_rank()}.json")
+            prof = torch.profiler.profile(activities=acts, schedule=torch.profiler.schedule(wait=first, warmup=0, active=active),
+                                          on_trace_ready=lambda p: p.export_chrome_trace(trace_file))
+            prof.start()
         t0 = time.monotonic_ns()
         for i in range(self.num_replays):
             self.replayIter = i
             self.replayTrace(commsParams=commsParams, warmup=False)
+            if prof is not None:
+                prof.step()
             bf.complete_accel_ops(ca)     # every posted operation has finished before the handles are dropped
             self.resetComms()
             bf.sync_barrier(ca)
         self.totalTraceLatency = (time.monotonic_ns() - t0) / 1e3
+        if prof is not None:
+            prof.stop()
         bf.clear_memory(ca)
 
     def readRawTrace(self, rank: int) -> None:
         path = self.trace_file
         if os.path.isdir(path):
             path = os.path.join(path, f"{0 if self.use_one_trace else rank}.json")
+        if getattr(self, "disable_parallel_read", False) and not self.is_dry_run and self.backendFuncs is not None:
+            # one reader (commsTraceReplay.py:1496-1510): rank 0 loads the file and leaves it in the rendezvous store under the
+            # path; every rank, rank 0 included, takes it from there (``store_get`` blocks until the key exists)
+            if rank == 0:
+                with open(path) as f:
+                    self.backendFuncs.store_set(path, f.read())
+            self.comms_trace = json.loads(self.backendFuncs.store_get(path))
+            return
         with open(path) as f:
             self.comms_trace = json.load(f)
 

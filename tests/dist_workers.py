@@ -321,6 +321,54 @@ def trace_replay(rank, world, port, outdir, golden_dir, blocking):
                    "total_us": bench.totalTraceLatency}, f)
 
 
+def trace_replay_one_reader(rank, world, port, outdir, golden_dir):
+    """``--use-one-trace --disable-parallel-read --enable-profiler``: only rank 0 opens the trace file (rank 1's ``open`` refuses
+    the path), both replay the same symmetric operations, each writes a profiler trace"""
+    import builtins
+    import contextlib
+    import io
+    import json
+
+    from param_amd.comms.pt import commsTraceReplay
+
+    _env(rank, world, port)
+    trace = [e for e in json.load(open(os.path.join(golden_dir, "basic_trace.json")))
+             if e.get("comms") in ("all_reduce", "barrier") or (e.get("comms") == "all_to_all" and not e.get("in_split"))]
+    assert len(trace) >= 2
+    tdir = os.path.join(outdir, "one")
+    if rank == 0:
+        os.makedirs(tdir, exist_ok=True)
+        json.dump(trace, open(os.path.join(tdir, "0.json"), "w"))
+    dist_file = os.path.join(tdir, "0.json")
+    import time as _t
+    while not os.path.exists(dist_file):
+        _t.sleep(0.05)
+    real_open = builtins.open
+
+    def guarded(path, *a, **k):
+        if rank != 0 and os.path.abspath(str(path)) == os.path.abspath(dist_file):
+            raise AssertionError("rank 1 opened the trace file although --disable-parallel-read was given")
+        return real_open(path, *a, **k)
+
+    argv = ["--trace-path", tdir, "--backend", "gloo", "--device", "cpu", "--master-ip", "127.0.0.1", "--master-port", str(port),
+            "--num-replays", "3", "--use-one-trace", "--disable-parallel-read", "--enable-profiler", "--profiler-num-replays-start", "1",
+            "--profiler-num-replays", "5", "--output-path", os.path.join(outdir, "perf1"), "--z", "1"]
+    builtins.open = guarded
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            bench = commsTraceReplay.main(argv)
+    finally:
+        builtins.open = real_open
+    with open(os.path.join(outdir, f"one{rank}.json"), "w") as f:
+        json.dump({"collLat": {k: len(v) for k, v in bench.collLat.items()}, "n": len(bench.comms_trace)}, f)
+    # the flag without --use-one-trace is refused
+    with pytest_raises(ValueError, "--disable-parallel-read is valid only when --use-one-trace is used."):
+        b2 = commsTraceReplay.commsTraceReplayBench()
+        import argparse
+        b2.checkArgs(b2.readArgs(argparse.ArgumentParser(), ["--trace-path", tdir, "--disable-parallel-read", "--device", "cpu",
+                                                             "--backend", "gloo"]))
+
+
 def plugin_table_collectives(rank, world, port):
     """The rest of the reference ABC's collective table (all_gather ... scatter, point-to-point, the pair-mode twins and
     the reference-driver call forms ``sayHello()`` with no arguments / list work handles in ``waitObj``): data checks."""
