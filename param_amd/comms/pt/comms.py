@@ -16,8 +16,9 @@ per iteration) vs non-blocking timing, ``--c 1`` validation, ``--i / --o`` split
 ``--src-ranks / --dst-ranks / --window`` (ping, ping-pong, uni- and bi-directional bandwidth), ``--tag``, the preamble lines,
 the report recomputing AlgBW from the p50 of per-rank mean latencies, busBW per collective, and the row formats -- all held
 to what the reference prints on gloo ranks by tests/golden/comms_surface.json.  Not kept: ``all_gather_v`` /
-``reduce_scatter_v`` (the reference's own backend has no entry for them either), the TPU / NVSHMEM / torchcomms stacks,
-custom perf loggers; ``--size-start-profiler`` drives torch.profiler (the reference's hook is an unpublished profiler).
+``reduce_scatter_v`` (the reference's own backend has no entry for them either), the TPU / NVSHMEM / torchcomms stacks.
+``--use-perf-logger`` hands every reported row to the loggers registered in logger_utils.py (the reference's plug-in point);
+``--size-start-profiler`` drives torch.profiler (the reference's hook is an unpublished profiler).
 """
 from __future__ import annotations
 
@@ -29,7 +30,7 @@ import time
 import numpy as np
 import torch
 
-from . import comms_utils
+from . import comms_utils, logger_utils
 from .comms_utils import paramDeviceTimer, paramStreamGuard
 from .mi355_backend import BACKEND_NAME, MI355XBackend, register
 from .pytorch_backend_utils import collectiveArgsHolder, customized_backend, pt2ptPatterns, supportedCollectives
@@ -93,7 +94,9 @@ class commsParamsHolder:
         self.use_device_time = args.use_device_time
         self.include_0B = args.include_0B
         self.graph_launches = getattr(args, "graph_launches", 0)
-        self.init_method = None
+        self.init_method = getattr(args, "init_method", None)
+        self.eager_init = getattr(args, "eager_init", False)
+        self.use_perf_logger = getattr(args, "use_perf_logger", None)
         self.use_ext_dist = False
         # round 4: the rest of the reference's holder (comms_utils.py:873-910)
         self.sizes = getattr(args, "ss", None)
@@ -217,6 +220,14 @@ class commsCollBench:
         parser.add_argument("--enable-local-report", action="store_true", default=False,
                             help="every node's local rank 0 reports too")
         parser.add_argument("--init-only", action="store_true", default=False, help="initialise the backend and stop")
+        parser.add_argument("--eager-init", action="store_true", default=False,
+                            help="pass device_id to init_process_group: the RCCL communicator is created at once")
+        parser.add_argument("--init-method", "--pg-init-method", type=str, default=None, dest="init_method",
+                            help="URL for init_process_group (env://, tcp://host:port, file://...) instead of the TCP store")
+        parser.add_argument("--enable-torch-nccl-timing", action="store_true", default=False,
+                            help="TORCH_NCCL_ENABLE_TIMING=1: c10d records start events for every collective")
+        parser.add_argument("--use-perf-logger", "--use-custom-perf-logger", nargs="+", type=str, default=None, dest="use_perf_logger",
+                            help="names of registered performance loggers (logger_utils.register_perf_logger); built in: jsonl")
         parser.add_argument("--log", "--log-level", type=str, default="ERROR", dest="log")
         return parser.parse_args()
 
@@ -664,6 +675,11 @@ class commsCollBench:
         if self.report:
             print(format_row(ca.collective, ca.data_type, self.tag, results["memSize"], results["numElements"],
                              p50, p75, p95, mn, mx, algBW, busBW))
+            logger_utils.dispatch(commsParams.use_perf_logger, "comms", logger_utils.commsCollPerfMetrics(
+                commsOp=ca.collective, Datatype=ca.data_type, Backend=commsParams.backend, Tags=self.tag, InputSize=results["memSize"],
+                OutputSize=results["memSize"], NumElements=results["numElements"], p50_latency_us=float(p50), p75_latency_us=float(p75),
+                p95_latency_us=float(p95), min_latency_us=float(mn), max_latency_us=float(mx), AlgoBW_GBs=float(algBW),
+                BusBW_GBs=float(busBW)), self.backendFuncs)
         self.results.append(rec)
         return rec
 
@@ -677,6 +693,10 @@ class commsCollBench:
         if self.report:
             print(format_quant_row(ca.collective, ca.data_type, self.tag, results["memSize"], results["numElements"],
                                    quant_p95, dequant_p95, p95))
+            logger_utils.dispatch(commsParams.use_perf_logger, "comms", logger_utils.commsQuantCollPerfMetrics(
+                commsOp=ca.collective, Datatype=ca.data_type, Backend=commsParams.backend, Tags=self.tag, InputSize=results["memSize"],
+                OutputSize=results["memSize"], NumElements=results["numElements"], p95_latency_us=p95, quant_p95_latency_us=quant_p95,
+                dequant_p95_latency_us=dequant_p95, quant_comms_p95_latency_us=p95 - quant_p95 - dequant_p95), self.backendFuncs)
         self.results.append(rec)
         return rec
 
@@ -697,6 +717,11 @@ class commsCollBench:
             # operation they issued ("recv" on a source rank) -- what the reference prints (comms.py:1245), kept for parsers
             print(format_pt2pt_row(ca.collective, ca.data_type, self.tag, results["memSize"], ping, pingpong, avgUni, avgBi,
                                    totUni, totBi))
+            logger_utils.dispatch(commsParams.use_perf_logger, "comms", logger_utils.commsPt2PtPerfMetrics(
+                commsOp=ca.collective, Datatype=ca.data_type, Backend=commsParams.backend, Tags=self.tag, InputSize=results["memSize"],
+                OutputSize=results["memSize"], NumElements=results["numElements"], p50_latency_us=ping[0], p75_latency_us=ping[1],
+                p95_latency_us=ping[2], AvgUniBW_GBs=avgUni, AvgBiBW_GBs=avgBi, TotalUniBW_GBs=totUni, TotalBiBW_GBs=totBi),
+                self.backendFuncs)
         self.results.append(rec)
         return rec
 
@@ -814,7 +839,9 @@ class commsCollBench:
         else:
             backend_cls, c10d_backend = MI355XBackend, args.backend
         self.backendFuncs = backend_cls(bootstrap_info, cp0)
-        self.backendFuncs.initialize_backend(bootstrap_info.master_ip, bootstrap_info.master_port, backend=c10d_backend)
+        os.environ["TORCH_NCCL_ENABLE_TIMING"] = "1" if getattr(args, "enable_torch_nccl_timing", False) else "0"   # comms_utils.py:1944-1947
+        self.backendFuncs.initialize_backend(bootstrap_info.master_ip, bootstrap_info.master_port, backend=c10d_backend,
+                                             eager_mode=bool(cp0.init_only or cp0.eager_init))
         self.c10d_backend = c10d_backend
         return self.backendFuncs
 

@@ -694,7 +694,9 @@ class MI355XBackend(backendFunctions):
             if self.tcp_store is None:
                 self.tcp_store = dist.TCPStore(master_ip, int(master_port), world, is_master=(rank == 0),
                                                use_libuv=True)
-            dist.init_process_group(backend, rank=rank, world_size=world, store=self.tcp_store,
+            init_method = self._cp("init_method", None)          # --init-method URL replaces the store (reference :1182-1183)
+            dist.init_process_group(backend, rank=rank, world_size=world, store=self.tcp_store if init_method is None else None,
+                                    init_method=init_method,
                                     device_id=self.get_device() if (eager_mode and self._is_gpu()) else None)
         self.groups = {0: self.get_default_group()}
         self.num_pgs = 1

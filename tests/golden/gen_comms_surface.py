@@ -8,7 +8,8 @@ Stored per case: the argument list (per rank where ranks differ), and from rank 
 the clock -- the ``[Rank   0] allSizes`` line, the ``collective=... src_ranks=... dst_ranks=...`` line, the header lines -- plus
 the deterministic columns of every COMMS-RES row (collective, dtype + tag, bytes, elements per rank where the row has that
 column, column count, field widths).  Also writes comms_cli_defaults.json: the defaults of the reference's own argument
-parser for the flags this build keeps.  Needs /root/reference (build container only); the fixture is data, nothing of the reference travels."""
+parser for the flags this build keeps, and perf_metric_fields.json: field names and defaults of the reference's performance
+records.  Needs /root/reference (build container only); the fixture is data, nothing of the reference travels."""
 import json
 import os
 import re
@@ -108,6 +109,20 @@ def main():
     defaults = json.loads(r.stdout.strip().splitlines()[-1])
     json.dump(defaults, open(os.path.join(HERE, "comms_cli_defaults.json"), "w"), indent=1)
     print("defaults", defaults)
+    # field names and defaults of the reference's performance records (logger_utils.py): the perf-logger plug-in boundary
+    code = (
+        "import dataclasses, json\n"
+        "from param_bench.train.comms.pt import logger_utils as L\n"
+        "out = {}\n"
+        "for c in (L.commsPerfMetrics, L.commsCollPerfMetrics, L.commsQuantCollPerfMetrics, L.commsPt2PtPerfMetrics):\n"
+        "    inst = c()\n"
+        "    out[c.__name__] = {f.name: (getattr(inst, f.name).name if f.name == 'BenchCommsType' and getattr(inst, f.name) is not None"
+        " else getattr(inst, f.name)) for f in dataclasses.fields(c)}\n"
+        "out['benchType'] = {m.name: m.value for m in L.benchType}\n"
+        "print(json.dumps(out))\n")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH=pb), capture_output=True, text=True, cwd=work)
+    assert r.returncode == 0, r.stderr[-2000:]
+    json.dump(json.loads(r.stdout.strip().splitlines()[-1]), open(os.path.join(HERE, "perf_metric_fields.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

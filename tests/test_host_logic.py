@@ -419,3 +419,37 @@ def test_run_benchmark_resume_stop_window_equals_reference(golden_dir, capsys):
         assert [w.step(i) for i in gold["ids"]] == case["states"], case
     assert R.main(["--version"]) == [] and "PARAM train compute version" in capsys.readouterr().out
     assert R.main([]) == []
+
+
+def test_perf_logger_records_match_reference_fields(golden_dir, tmp_path):
+    """logger_utils.py: the four record classes have the REFERENCE's field names, order and defaults
+    (tests/golden/perf_metric_fields.json, from the reference's dataclasses), so a logger written against PARAM reads them;
+    registry semantics: name -> instance, unknown names skipped, the built-in ``jsonl`` logger appends one object per record"""
+    import dataclasses
+
+    from param_amd.comms.pt import logger_utils as L
+
+    gold = json.load(open(os.path.join(golden_dir, "perf_metric_fields.json")))
+    assert {m.name: m.value for m in L.benchType} == gold["benchType"]
+    for cls in (L.commsPerfMetrics, L.commsCollPerfMetrics, L.commsQuantCollPerfMetrics, L.commsPt2PtPerfMetrics):
+        inst = cls()
+        mine = {f.name: (getattr(inst, f.name).name if f.name == "BenchCommsType" and getattr(inst, f.name) is not None
+                         else getattr(inst, f.name)) for f in dataclasses.fields(cls)}
+        assert list(mine.items()) == list(gold[cls.__name__].items()), cls.__name__
+    seen = []
+
+    class Mine(L.commsPerfLogger):
+        def logPerf(self, benchmarkName, metrics, backendFuncs, **kwargs):
+            seen.append((benchmarkName, metrics.commsOp, kwargs))
+
+    L.register_perf_logger("mine", Mine("mine"))
+    try:
+        m = L.commsCollPerfMetrics(commsOp="all_to_allv", p50_latency_us=3.0)
+        L.dispatch(["mine", "absent"], "comms", m, None, extra=1)
+        assert seen == [("comms", "all_to_allv", {"extra": 1})] and L.customized_perf_loggers["mine"].name == "mine"
+        L.JsonLinesPerfLogger(path=str(tmp_path / "x.jsonl")).logPerf("replay", m, None, note="n")
+        rec = json.loads(open(tmp_path / "x.jsonl").read())
+        assert rec["commsOp"] == "all_to_allv" and rec["BenchCommsType"] == "Collective" and rec["benchmark"] == "replay" and rec["note"] == "n"
+        L.dispatch(None, "comms", m, None)
+    finally:
+        L.customized_perf_loggers.pop("mine")
