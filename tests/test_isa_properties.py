@@ -100,3 +100,51 @@ def test_sort_kernels_issue_their_tile_loads_together(bundles):
     for sym, least in ((f"{NS}24seg_lookback_pass_kernelIjLi8E", 32), (f"{NS}18seg_scatter_kernelIjLi8E", 32),
                        (f"{NS}19seg_hist_all_kernelIjLi8E", 16), (f"{NS}15seg_hist_kernelIjLi8E", 16)):
         assert _row_loads_between_full_waits(_kernel_text(bundles, sym), "global_load_") >= least, sym
+
+
+def _kernel_resources(bundles):
+    """{mangled name: (vgprs, sgprs, scratch bytes, LDS bytes)} of every kernel of the library, from the code objects' metadata notes"""
+    d, slices = bundles
+    readelf = os.path.join(LLVM, "llvm-readelf")
+    if not os.path.exists(readelf):
+        pytest.skip("llvm-readelf not available")
+    res = {}
+    for k, sl in enumerate(slices):
+        src, co = str(d / f"r{k}.bin"), str(d / f"r{k}.co")
+        open(src, "wb").write(sl)
+        r = subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o",
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + src, "--output=" + co], capture_output=True)
+        if r.returncode != 0 or not os.path.exists(co) or os.path.getsize(co) == 0:
+            continue
+        notes = subprocess.run([readelf, "--notes", co], capture_output=True, text=True, check=True).stdout
+        for blk in notes.split("  - .agpr_count")[1:]:
+            g = lambda key: re.search(r"\." + key + r":\s+(\S+)", blk).group(1)           # noqa: E731
+            res[g("name")] = (int(g("vgpr_count")), int(g("sgpr_count")), int(g("private_segment_fixed_size")),
+                              int(g("group_segment_fixed_size")))
+    return res
+
+
+def test_no_kernel_of_the_path_spills_and_register_budgets_hold(bundles):
+    """Resource usage of the compiled kernels (code-object metadata; no GPU): none of this build's kernels uses scratch memory
+    (a spill in a row loop would cost HBM traffic that no parity test sees), and the families whose occupancy the design counts
+    on stay inside their register budgets -- forward <= 128 VGPRs in every instantiation (>= 4 waves per SIMD; the default
+    fp32 path 42), sorted apply main kernel <= 128, bag-major apply <= 128, look-back pass <= 136 and LDS under 64 KB (two
+    workgroups per CU by LDS), all-pass histogram <= 64.  The bounds are the round-4 build's values with a small margin: a
+    compiler or source change that moves them shows up here, not as an unexplained 5 % on the GPU."""
+    res = _kernel_resources(bundles)
+    own = {n: v for n, v in res.items() if n.startswith("_ZN2pm")}
+    assert len(own) > 1000, len(own)                       # every template instantiation is there
+    spilled = {n: v[2] for n, v in own.items() if v[2] != 0}
+    assert not spilled, spilled
+    budgets = {"17embbag_fwd_kernel": (128, 4096), "22embbag_fwd_flat_kernel": (128, 1024), "22bwd_sorted_main_kernel": (128, 20480),
+               "17bwd_unique_kernel": (128, 1024), "24seg_lookback_pass_kernel": (136, 65536), "19seg_hist_all_kernel": (64, 16384),
+               "15hyb_mark_kernel": (64, 16384)}
+    seen = {k: 0 for k in budgets}
+    for n, (vgpr, _sgpr, _scr, lds) in own.items():
+        for fam, (max_v, max_lds) in budgets.items():
+            if fam in n:
+                seen[fam] += 1
+                assert vgpr <= max_v and lds <= max_lds, (n, vgpr, lds)
+    assert all(seen.values()), seen
+    fwd = [v[0] for n, v in own.items() if "17embbag_fwd_kernel" in n]
+    assert min(fwd) <= 48, min(fwd)                       # the lean instantiations (fp32, unweighted) stay lean
