@@ -316,6 +316,8 @@ class commsTraceReplayBench:
                 n_out = n_in * cur_ws
             curComm.inMsgSize, curComm.outMsgSize, curComm.worldSize = n_in, n_out, cur_ws
         commsParams.size_from_trace = True
+        if curComm.dtype is None:               # an entry without a data type (hand-built traces): the parser's default
+            curComm.dtype = "float32"
         commsParams.dtype = self.dtypeMap[curComm.dtype]
         key = (commOp, curComm.inMsgSize, curComm.outMsgSize, curComm.dtype, str(curComm.inSplit), str(curComm.outSplit))
         if not regenerateTensors and key in self.tensorReuse:
@@ -476,7 +478,7 @@ class commsTraceReplayBench:
         coll_in_batch_num = 0
         batch_begin = 0.0
         startTime = time.monotonic_ns()
-        limit = self.max_msg_cnt if self.max_msg_cnt else len(self.comms_trace)
+        limit = self.max_msg_cnt          # initTraceStat() turns "0 = no limit" into the trace's length (reference :995)
         allow = self.allowList
         for cnt, curComm in enumerate(self.comms_trace[:limit]):
             curBlocks = curComm.markerStack if curComm.markerStack is not None else []

@@ -125,6 +125,22 @@ def clearQuantCommCtx(collectiveArgs) -> None:
     collectiveArgs.reduce_qcomm = 32
 
 
+def get_rank_details(backendFuncs):
+    """(local rank, global rank, world size, default group, device, hardware device) of this process, from the backend
+    (reference ``:255-273``)"""
+    return (backendFuncs.get_local_rank(), backendFuncs.get_global_rank(), backendFuncs.get_world_size(),
+            backendFuncs.get_default_group(), backendFuncs.get_device(), backendFuncs.get_hw_device())
+
+
+def ensureTensorFlush(tensors):
+    """read the last element of the (last) tensor back to the host: the collective that produced it has really finished
+    (reference ``:488-508``); returns that value, None for an empty list"""
+    last = tensors[-1] if isinstance(tensors, (list, tuple)) and len(tensors) > 0 else tensors
+    if last is None or isinstance(last, (list, tuple)) or last.nelement() == 0:
+        return None
+    return last.reshape(-1)[-1].item()
+
+
 def env2int(env_list, default: int = -1) -> int:
     for e in env_list:
         val = int(os.environ.get(e, -1))

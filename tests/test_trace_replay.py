@@ -172,6 +172,9 @@ def test_replay_runs_and_skips_unknown_collectives(warmup):
     b.comms_trace = _three_op_trace()
     b.collectiveArgs.world_size = 1
     b.replayTrace(_params(), warmup)
+    assert b.backendFuncs.calls == []          # max_msg_cnt 0 before initTraceStat(): nothing is replayed (reference :995)
+    b.initTraceStat()                          # the run's order (runBench): statistics first -- "0 = no limit" becomes the length
+    b.replayTrace(_params(), warmup)
     assert b.backendFuncs.calls == ["all_gather", "wait"]          # "test" is not a collective: warned and skipped
     assert len(b.traceWithPerf) == (0 if warmup else 3)
 
