@@ -33,6 +33,7 @@ import torch
 
 from . import comms_utils, commsTraceParser
 from .comms_utils import commsArgs, paramStreamGuard, paramTimer, paramToCommName
+from .param_profile import paramProfile
 from .mi355_backend import BACKEND_NAME, MI355XBackend, register
 from .pytorch_backend_utils import collectiveArgsHolder, customized_backend
 
@@ -385,13 +386,12 @@ class commsTraceReplayBench:
     def runCompute(self, func, curBlockStack: str):
         ca, bf = self.collectiveArgs, self.backendFuncs
         timer = paramTimer()
-        timer.start()
-        with paramStreamGuard(stream=ca.compute_stream, curDevice=ca.device, backendFuncs=bf, is_blocking=False):
-            for _ in range(ca.computeCount):
-                func(ca)
-        if self.is_blocking:      # blocking replay times the kernels, non-blocking replay their launch
-            bf.sync_stream(ca.compute_stream, ca.device)
-        timer.stop()
+        with paramProfile(timer=timer, description=f"# PARAM replay {getattr(self, 'replayIter', 0)}: " + curBlockStack):
+            with paramStreamGuard(stream=ca.compute_stream, curDevice=ca.device, backendFuncs=bf, is_blocking=False):
+                for _ in range(ca.computeCount):
+                    func(ca)
+            if self.is_blocking:      # blocking replay times the kernels, non-blocking replay their launch
+                bf.sync_stream(ca.compute_stream, ca.device)
         lat = timer.getTimeUS()
         return lat, lat
 
@@ -400,26 +400,30 @@ class commsTraceReplayBench:
         ca.quant_time.reset()          # per replayed collective (reference commsTraceReplay.py:769-770)
         ca.dequant_time.reset()
         timer = paramTimer()
+        it = getattr(self, "replayIter", 0)
+        # the ranges carry the reference's labels (commsTraceReplay.py:771-790, 824-830): a profiler trace of a replay shows every
+        # collective under its marker stack, the fences around it apart
         if self.is_blocking:
-            bf.sync_barrier(ca)
-        timer.start()
-        if collName in bf.collectiveFunc:
-            if curComm.req is not None:
-                ca.collectiveId = str(curComm.req)
-            retObj = bf.collectiveFunc[collName](ca, retFlag=True)
-        else:
-            retObj = None
-            logger.warning(f"Unsupported collective name: {collName}. Skipping replaying the collective")
-        if self.is_blocking:
-            bf.complete_accel_ops(ca)
-        if curComm.req is not None and not self.is_blocking and collName != "wait":
-            ca.waitObjIds[str(curComm.req)] = retObj      # a later "wait" entry names this request
-        timer.stop()
+            with paramProfile(description=f"# PARAM replay {it} pre-comm barrier # " + curBlockStack):
+                bf.sync_barrier(ca)
+        with paramProfile(timer=timer, description=f"# PARAM replay {it}:" + curBlockStack):
+            if collName in bf.collectiveFunc:
+                if curComm.req is not None:
+                    ca.collectiveId = str(curComm.req)
+                retObj = bf.collectiveFunc[collName](ca, retFlag=True)
+            else:
+                retObj = None
+                logger.warning(f"Unsupported collective name: {collName}. Skipping replaying the collective")
+            if self.is_blocking:
+                bf.complete_accel_ops(ca)
+            if curComm.req is not None and not self.is_blocking and collName != "wait":
+                ca.waitObjIds[str(curComm.req)] = retObj      # a later "wait" entry names this request
         latency = global_latency = timer.getTimeUS()
         if self.is_blocking:
-            t0 = time.monotonic_ns()
-            bf.sync_barrier(ca)
-            global_latency = latency + (time.monotonic_ns() - t0) / 1e3
+            post = paramTimer()
+            with paramProfile(timer=post, description=f"# PARAM replay {it} post-comm barrier # " + curBlockStack):
+                bf.sync_barrier(ca)
+            global_latency = latency + post.getTimeUS()
         return latency, global_latency
 
     def waitForTimestamp(self, curComm: commsArgs, startTime: float) -> None:

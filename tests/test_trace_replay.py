@@ -253,3 +253,27 @@ def test_compute_entry_fails_loudly_without_a_gpu(tmp_path):
                                            "num_emb_tables": 1, "bag_size": 1}], "basic")
     with pytest.raises(Exception):
         comms_utils.init_emb_lookup(b.collectiveArgs, cur, b.backendFuncs)
+
+
+def test_param_profile_ranges_and_timer():
+    """param_profile.paramProfile (reference param_profile.py:18-40): a named profiler range that advances a paramTimer; the
+    replay labels every collective with the reference's range names, so a torch.profiler trace shows them"""
+    import torch
+
+    from param_amd.comms.pt.param_profile import paramProfile, paramTimer
+
+    t = paramTimer()
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU]) as prof:
+        with paramProfile(timer=t, description="# PARAM unit range") as p:
+            torch.ones(8).sum()
+        with paramProfile(description="# untimed"):
+            pass
+        b = commsTraceReplayBench()
+        b.is_blocking = True
+        b.replayIter = 3
+        b.backendFuncs = MockBackend()
+        b.runComms("all_gather", commsArgs(req=0), "blockA")
+    assert t.getTimeNS() == p.intervalNS > 0
+    names = {e.name for e in prof.events()}
+    assert {"# PARAM unit range", "# untimed", "# PARAM replay 3 pre-comm barrier # blockA", "# PARAM replay 3:blockA",
+            "# PARAM replay 3 post-comm barrier # blockA"} <= names
