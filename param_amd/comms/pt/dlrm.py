@@ -307,6 +307,7 @@ class commsDLRMBench:
     def __init__(self):
         self.collectiveArgs = collectiveArgsHolder()
         self.measured = {name: [] for name, _, _ in REGIONS}
+        self.memory = {name: [] for name, _, _ in REGIONS}
 
     def readArgs(self, parser, argv=None):
         parser.add_argument("--master-ip", type=str, default="127.0.0.1")
@@ -416,6 +417,7 @@ class commsDLRMBench:
         gen.manual_seed(args.numpy_rand_seed + rank)
         timers = ca.timers
         m_den = int(args.arch_mlp_bot.split("-")[0])
+        n_records = 0
         for batch in range(args.num_batches):
             timers["iter_start"] = time.monotonic()
             if args.data_generation == "random":
@@ -449,6 +451,17 @@ class commsDLRMBench:
             timers["bwd_bot_ar_start"] = time.monotonic()
             self._all_reduce_layers(bf, ca, bot, path)
             timers["bwd_bot_ar_end"] = time.monotonic()
+            # bytes moved per region in this batch (the report's "memory (B)" column, dlrm.py:101,193,788,834,1318): the records the
+            # batch appended are, in order, lengths a2a, indices a2a, pooled a2a, top all_reduces, gradient a2a, bottom all_reduces
+            recs = path.commDetails[n_records:]
+            n_records = len(path.commDetails)
+            a2a = [r["msg_size"] for r in recs if r["comms"] == "all_to_all"]
+            k_bwd = max((k for k, r in enumerate(recs) if r["comms"] == "all_to_all"), default=0)
+            mem = dict(zip(("offset_xchg", "idx_xchg", "fwd_a2a", "bwd_a2a"), a2a))
+            mem["bwd_top_ar"] = sum(r["msg_size"] for r in recs[:k_bwd] if r["comms"] == "all_reduce")
+            mem["bwd_bot_ar"] = sum(r["msg_size"] for r in recs[k_bwd:] if r["comms"] == "all_reduce")
+            for name, _, _ in REGIONS:
+                self.memory[name].append(mem.get(name, 0))
             if batch >= args.warmup_batches:
                 for name, s, e in REGIONS:
                     self.measured[name].append((timers.get(e, 0.0) - timers.get(s, 0.0)) * 1e6)
@@ -470,23 +483,58 @@ class commsDLRMBench:
         bf.sync_barrier(ca)
 
     def report(self, bf, ca, path, args):
-        """min / p50 / p75 / p95 over iterations of the per-rank MAX... the reference gathers every rank's
-        samples (dlrm.py:1011-1198); here: all_gather of the per-region medians, rank 0 prints."""
+        """The reference's report (dlrm.py:1011-1198): every rank's per-iteration samples of the 21 regions are all-gathered; rank 0
+        prints two tables with the columns iters / region / memory (B) / Latency(us):min / p50 / p75 / p95 / sum(p50) -- the first
+        over all samples of all ranks, the second over the ranks' MEAN latencies -- each closed by a ``total_time`` row (sum of the
+        p50 of the regions that are not ``iter_*`` roll-ups).  ``memory`` is the p50 over the measured iterations of the bytes the
+        region moved (one deviation: ``bwd_top_ar`` / ``bwd_bot_ar`` show the all_reduces' bytes; the reference prints 0 there
+        because its ``getMemSizes`` reads a stale output tensor, dlrm.py:936-950).  Returns the first table as a dict (+ the pooled
+        all-to-all's bandwidth) on every rank."""
         names = [n for n, _, _ in REGIONS]
-        mine = torch.tensor([float(np.median(self.measured[n])) if self.measured[n] else 0.0 for n in names],
-                            dtype=torch.float64, device=ca.device)
-        allr = [torch.zeros_like(mine) for _ in range(ca.world_size)]
-        dist.all_gather(allr, mine, group=bf.get_default_group())
-        table = torch.stack(allr).cpu().numpy()        # [world, regions]
+        measured = max((len(self.measured[n]) for n in names), default=0)
         out = {}
-        if ca.global_rank == 0:
-            print("\n\t{:>40}{:>14}{:>14}{:>14}{:>14}".format("region (us, median per rank)", "min", "p50", "p95", "max"))
+        if measured == 0:
+            return out
+        lat = torch.tensor([self.measured[n] for n in names], dtype=torch.float64, device=ca.device)          # [regions, iters]
+        mem = torch.tensor([self.memory[n][args.warmup_batches:] for n in names], dtype=torch.float64, device=ca.device)
+        all_lat = [torch.zeros_like(lat) for _ in range(ca.world_size)]
+        all_mem = [torch.zeros_like(mem) for _ in range(ca.world_size)]
+        dist.all_gather(all_lat, lat, group=bf.get_default_group())
+        dist.all_gather(all_mem, mem, group=bf.get_default_group())
+        lat_r = torch.stack(all_lat).cpu().numpy()          # [ranks, regions, iters]
+        mem_r = torch.stack(all_mem).cpu().numpy()
+        fmt = "\t%d\t%36s\t%12s\t%12s\t%12s\t%12s\t%12s\t%12s"
+        # the "iters" column is the reference's label: (--num-batches + --warmup-batches) - --warmup-batches (comms_utils.py:845,
+        # dlrm.py:1403) = --num-batches, although --num-batches - --warmup-batches batches are measured (as here)
+        measured = args.num_batches
+        lines_all, lines_mean = [], []
+        sum_all = sum_mean = 0.0
         for k, n in enumerate(names):
-            col = table[:, k]
-            out[n] = {"min": float(col.min()), "p50": float(np.percentile(col, 50)), "p95": float(np.percentile(col, 95)),
-                      "max": float(col.max())}
-            if ca.global_rank == 0:
-                print("\t{:>40}{:>14.1f}{:>14.1f}{:>14.1f}{:>14.1f}".format(n, out[n]["min"], out[n]["p50"], out[n]["p95"], out[n]["max"]))
+            samples = lat_r[:, k, :].reshape(-1)
+            means = lat_r[:, k, :].mean(axis=1)
+            mem_p50 = np.percentile(mem_r[:, k, :].reshape(-1), 50) if mem_r.shape[2] else 0
+            p50, p75, p95 = (float(np.percentile(samples, q)) for q in (50, 75, 95))
+            m50, m75, m95 = (float(np.percentile(means, q)) for q in (50, 75, 95))
+            if "iter" not in n:
+                sum_all += p50
+                sum_mean += m50
+            out[n] = {"min": float(samples.min()), "p50": p50, "p75": p75, "p95": p95, "max": float(samples.max()),
+                      "memory": float(mem_p50), "mean_p50": m50}
+            lines_all.append(fmt % (measured, n, "%d" % mem_p50, "%.3f" % samples.min(), "%.3f" % p50, "%.3f" % p75, "%.3f" % p95,
+                                    "%.3f" % sum_all))
+            lines_mean.append(fmt % (measured, n, "%d" % mem_p50, "%.3f" % means.min(), "%.3f" % m50, "%.3f" % m75, "%.3f" % m95,
+                                     "%.3f" % sum_mean))
+        if ca.global_rank == 0:
+            rule = "\n\n " + "-" * 125 + "\n\n"
+            print("\t{}\t{:>36}\t{:>12}\t{:>12}\t{:>12}\t{:>12}\t{:>12}\t{:>12}".format(
+                "iters", "region", "memory (B)", "Latency(us):min", "p50", "p75", "p95", "sum(p50)"))
+            for lines, total in ((lines_all, sum_all), (lines_mean, sum_mean)):
+                for ln in lines:
+                    if "iter_time" in ln:
+                        print("\n")
+                    print(ln)
+                print("\t%d\t%36s\t%12s\t%12s\t%12s" % (measured, "total_time", "N/A", "N/A", "%.3f" % total))
+                print(rule)
         a2a_bytes = path.B * sum(path.dims_sum_per_rank) * 4
         if out["fwd_a2a"]["p50"] > 0:
             alg = a2a_bytes / (out["fwd_a2a"]["p50"] * 1e3)

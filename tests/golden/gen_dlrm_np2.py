@@ -41,13 +41,37 @@ if __name__ == "__main__":
                MASTER_PORT=port, WORLD_SIZE="2", LOCAL_SIZE="2")
     procs = [subprocess.Popen([sys.executable, os.path.join(work, "harness.py"), "--master-ip", "127.0.0.1",
                                "--master-port", port] + FLAGS, cwd=work, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
-                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for r in (0, 1)]
-    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for r in (0, 1)]
+    texts = [p.communicate(timeout=600)[0] for p in procs]
+    assert [p.returncode for p in procs] == [0, 0]
     out = os.path.join(HERE, "dlrm_np2")
     os.makedirs(out, exist_ok=True)
     for r in (0, 1):
         shutil.copy(os.path.join(work, "dlrm_np2", f"rank{r}.json"), os.path.join(out, f"rank{r}.json"))
     print("wrote", out)
+    # the clock-free part of rank 0's report (dlrm.py:1011-1198): header line, per table the (iterations, region, memory p50)
+    # columns of every row and the number of tab-separated fields, the total_time rows, the separator lines
+    import json as _json
+
+    tables, cur, header, seps = [], None, None, 0
+    for ln in texts[0].splitlines():
+        f = ln.split("\t")
+        if len(f) > 3 and f[1].strip() == "iters" and f[2].strip() == "region":
+            header = ln
+        elif len(f) >= 6 and f[1].strip().isdigit():
+            if f[2].strip() == "intermed_calc_length":
+                cur = []
+                tables.append(cur)
+            if cur is not None:
+                cur.append({"iters": int(f[1]), "region": f[2].strip(), "memory": f[3].strip(), "fields": len(f),
+                            "widths": [len(x) for x in f]})
+        elif ln.strip().startswith("-----"):
+            seps += 1
+    assert header is not None and len(tables) == 2 and len(tables[0]) == 22, (header, [len(t) for t in tables])
+    _json.dump({"flags": FLAGS, "header": header, "tables": tables, "separator_lines": seps,
+                "rank1_prints_table": any("intermed_calc_length" in ln for ln in texts[1].splitlines())},
+               open(os.path.join(out, "report_rank0.json"), "w"), indent=1)
+    print("report rows:", [(r["region"], r["memory"]) for r in tables[0]])
     # top-MLP sizing variants (dlrm.py:583-601): the all_reduce message sizes of rank 0's records under
     # --arch-interaction-op cat / --arch-interaction-itself / --arch-project-size
     import json
