@@ -28,6 +28,53 @@ from .comms_utils import paramDeviceTimer, paramStreamGuard
 logger = logging.getLogger(__name__)
 
 
+CC_HEADER_FMT = "{:>40}{:>18}{:>18}{:>12}{:>12}{:>12}{:>12}{:>15}{:>12}"
+CC_QUANT_HEADER_FMT = "-QUANT\t{:>40}{:>18}{:>25}{:>15}{:>15}{:>15}"
+CC_ROW_FMT = "\tCOMMS-RES-{}-{}{}{:>18}{:>18}{:>18}{:>12}{:>12}{:>12}{:>12}{:>15}{:>12}"
+CC_DEV_TIME_FMT = "{:>20}{:>20}"        # TotalLatency(us):p50, CompLatency(us):p50 -- comms-compute mode only
+
+
+def format_cc_header(mode: str, bitwidth: int = 32) -> str:
+    """the reference's preamble (commsComputeBench.py:361-433): the collective sweep's titles with ``Latency(us):p50`` for the
+    collective's DEVICE time and, in comms-compute mode, two more columns: host time per iteration and the compute kernel's device
+    time (``str.format`` drops the surplus titles, as in the reference)"""
+    dev = CC_DEV_TIME_FMT if mode == "comms-compute" else ""
+    if bitwidth < 32:
+        return "\n\tCOMMS-RES" + (CC_QUANT_HEADER_FMT + dev).format(
+            "size (B)", "nElementsPerRank", "P95 Latency(us): Quant", "Comms", "De-Quant", "Overall", "TotalLatency(us):p50",
+            "CompLatency(us):p50", "TFlops")
+    return "\n\tCOMMS-RES" + (CC_HEADER_FMT + dev).format(
+        "total-size (B)", "nElementsPerRank", "Latency(us):p50", "p75", "p95", "Min", "Max", "AlgBW(GB/s)", "BusBW(GB/s)",
+        "TotalLatency(us):p50", "CompLatency(us):p50", "TFlops")
+
+
+def cc_report(collective, world_size, memSize, lat_us, comm_us, comp_us, getBusBW, bitwidth: int = 32):
+    """the numbers of one report row (commsComputeBench.py:499-577): with device times, the percentiles are the collective's
+    device time across ranks, ``total_p50`` the host time per iteration and ``compute_p50`` the compute kernel's device time;
+    without (compute-only mode), the host time alone.  AlgBW is recomputed from the final p50."""
+    import numpy as np
+
+    lat = np.asarray(lat_us, dtype=np.float64)
+    total_p50 = compute_p50 = 0.0
+    if len(comp_us):
+        compute_p50 = float(np.percentile(np.asarray(comp_us, dtype=np.float64), 50))
+    if len(comm_us):
+        total_p50 = float(np.percentile(lat, 50))
+        lat = np.asarray(comm_us, dtype=np.float64)
+    p50, p75, p95 = (float(np.percentile(lat, q)) for q in (50, 75, 95))
+    _, algBW = comms_utils.getAlgBW(p50 * 1e3, memSize, 1)
+    busBW = getBusBW(collective, algBW, world_size) * (bitwidth / 32.0)
+    return {"p50": p50, "p75": p75, "p95": p95, "min": float(lat.min()), "max": float(lat.max()), "algBW": algBW, "busBW": busBW,
+            "total_p50": total_p50, "compute_p50": compute_p50}
+
+
+def format_cc_row(collective, data_type, tag, memSize, numElements, rep: dict, mode: str) -> str:
+    dev = CC_DEV_TIME_FMT if mode == "comms-compute" else ""
+    return (CC_ROW_FMT + dev).format(collective, data_type, tag, memSize, "%d" % numElements, "%.1f" % rep["p50"], "%.1f" % rep["p75"],
+                                     "%.1f" % rep["p95"], "%.1f" % rep["min"], "%.1f" % rep["max"], "%.3f" % rep["algBW"],
+                                     "%.3f" % rep["busBW"], "%.1f" % rep["total_p50"], "%.1f" % rep["compute_p50"])
+
+
 class commsComputeBench(commsCollBench):
     def readArgs(self, parser):
         parser.add_argument("--mode", type=str, default="comms-compute", choices=["compute", "comms-compute"])
@@ -108,6 +155,11 @@ class commsComputeBench(commsCollBench):
             comms_utils.initQuantCommCtx(ca, commsParams)
         lookups = args.ntables * args.batch_size * args.bag_size * args.num_compute
         out = []
+        self.comm_size = ca.world_size
+        if ca.global_rank == 0:            # the reference's preamble lines (commsComputeBench.py:308-311, 361-433)
+            print(f"[Rank {ca.global_rank:>3}] mode: {args.mode}, num_coll: {args.num_coll}, kernel: {args.kernel}, num_compute {args.num_compute}, "
+                  f"emb_dim {args.emb_dim}, num_embs {args.num_embs}, batch_size {args.batch_size}")
+            print(format_cc_header(args.mode, commsParams.bitwidth if comm_fn is not None else 32))
         for curSize in comms_utils.getSizes(commsParams.beginSize, commsParams.endSize, commsParams.stepFactor,
                                             commsParams.stepBytes):
             self.prepComm(commsParams, curSize)
@@ -121,6 +173,18 @@ class commsComputeBench(commsCollBench):
             if commsParams.bitwidth < 32 and comm_fn is not None:
                 r.update({"bitwidth": commsParams.bitwidth, "quant_us": ca.quant_time.getTimeUS() / ca.numIters,
                           "dequant_us": ca.dequant_time.getTimeUS() / ca.numIters})
+            # the reference's row: every rank's host time / collective device time / compute device time gathered, percentiles
+            # across ranks (commsComputeBench.py:682-700, 499-577)
+            across = self.gatherBenchTime([r["timeUS"], r.get("comm_dev_us", 0.0), r.get("compute_dev_us", 0.0)])
+            across = across.reshape(-1, 3)
+            with_dev = args.mode == "comms-compute" and "comm_dev_us" in r
+            rep = cc_report(ca.collective, ca.world_size, r["memSize"], across[:, 0], across[:, 1] if with_dev else [],
+                            across[:, 2] if ("compute_dev_us" in r and args.mode == "comms-compute") else [],
+                            lambda c, bw, n: bf.getBusBW(c, bw, ca), commsParams.bitwidth if comm_fn is not None else 32)
+            r["report"] = rep
+            n_el = ca.numElements // ca.world_size if "all_to_all" in ca.collective else ca.numElements
+            if ca.global_rank == 0:
+                print(format_cc_row(ca.collective, ca.data_type, self.tag, r["memSize"], n_el, rep, args.mode))
             if ca.global_rank == 0:
                 print("\tCOMMS-COMPUTE-RES-{}-{}  size {:>12}  iter {:>10.1f} us  comm(dev) {:>10.1f} us  compute(dev) {:>10.1f} us"
                       "  algBW {:>8.3f}  busBW {:>8.3f} GB/s".format(ca.collective, args.kernel, curSize, r["timeUS"],

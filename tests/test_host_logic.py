@@ -453,3 +453,41 @@ def test_perf_logger_records_match_reference_fields(golden_dir, tmp_path):
         L.dispatch(None, "comms", m, None)
     finally:
         L.customized_perf_loggers.pop("mine")
+
+
+def test_comms_compute_bench_report_equals_reference_text(golden_dir, monkeypatch, capsys):
+    """commsComputeBench.py prints the reference's preamble and COMMS-RES rows (device time of the collective as the latency
+    columns, host time per iteration and compute device time as the two extra columns in comms-compute mode):
+    tests/golden/commscompute_rows.json holds what the REFERENCE's printPreamble / reportBenchTimeColl print for fixed
+    latencies.  Then the driver end to end on one gloo rank with the lookup kernel stubbed out (the product kernel has no CPU
+    path): header, row and the build's own COMMS-COMPUTE-RES line per size."""
+    from param_amd.comms.pt import comms_utils, commsComputeBench as C
+    from param_amd.comms.pt.mi355_backend import MI355XBackend
+    from param_amd.comms.pt.pytorch_backend_utils import backendFunctions
+
+    gold = json.load(open(os.path.join(golden_dir, "commscompute_rows.json")))
+    for key, text in gold["headers"].items():
+        mode, bw = key.split("/")
+        assert C.format_cc_header(mode, int(bw)) + "\n" == text, key
+    for g in gold["rows"]:
+        ca = types.SimpleNamespace(world_size=g["world_size"])
+        rep = C.cc_report("all_to_allv", g["world_size"], g["results"]["memSize"], g["lat"], g["comm"], g["comp"],
+                          lambda c, bw, n: backendFunctions.getBusBW(None, c, bw, ca))
+        assert C.format_cc_row("all_to_allv", "float32", g["tag"], g["results"]["memSize"], g["results"]["numElements"], rep,
+                               g["mode"]) + "\n" == g["row"], g["mode"]
+    # end to end on the host: stub kernel, one rank
+    monkeypatch.setattr(comms_utils, "init_emb_lookup", lambda ca, args, bf: None)
+    monkeypatch.setattr(MI355XBackend, "emb_lookup", lambda self, ca: None)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    from tests.dist_workers import free_port
+
+    res = C.main(["--master-ip", "127.0.0.1", "--master-port", str(free_port()), "--b", "1K", "--e", "4K", "--f", "4", "--n", "3",
+                  "--w", "1", "--collective", "all_to_allv", "--device", "cpu", "--backend", "gloo", "--num-compute", "2",
+                  "--ntables", "2", "--batch-size", "8", "--bag-size", "3", "--tag", "x"])
+    out = capsys.readouterr().out
+    assert [r["size"] for r in res] == [1024, 4096] and all(r["report"]["p50"] > 0 and r["lookups_per_iter"] == 2 * 8 * 3 * 2 for r in res)
+    assert C.format_cc_header("comms-compute", 32) in out and "mode: comms-compute, num_coll: 1, kernel: emb_lookup" in out
+    rows = [ln for ln in out.splitlines() if ln.startswith("\tCOMMS-RES-all_to_allv-float32-x")]
+    assert len(rows) == 2 and [int(ln.split()[1]) for ln in rows] == [1024, 4096] and len(rows[0].split()) == 12
+    assert out.count("COMMS-COMPUTE-RES-all_to_allv-emb_lookup") == 2
