@@ -716,6 +716,16 @@ class MI355XBackend(backendFunctions):
         self.num_pgs = len(self.groups)
         self.round_robin_group = cycle(list(self.groups.values()))     # reference :1251: get_next_group() walks the groups
 
+    def get_new_pg(self, group_ranks, backend="nccl", pg_desc=""):
+        """a new process group over ``group_ranks`` (every rank of the job calls it; reference ``:1136-1138``)"""
+        return dist.new_group(ranks=group_ranks, backend=self._pg_backend(backend))
+
+    def initialize_tcpstore(self, master_ip, master_port) -> None:
+        """the rendezvous store by itself (reference ``:1145-1154``): ``store_set`` / ``store_get`` work before any group exists"""
+        if self.tcp_store is None:
+            self.tcp_store = dist.TCPStore(master_ip, int(master_port), self.bootstrap_info.world_size,
+                                           is_master=(self.bootstrap_info.global_rank == 0), use_libuv=True)
+
     def benchmark_comms(self, benchTime, commsParams) -> None:
         if getattr(commsParams, "init_only", False):
             sleep(10)

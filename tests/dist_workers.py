@@ -462,6 +462,16 @@ def plugin_table_collectives(rank, world, port):
         bf.wait(ca)
         assert ca.waitObj == []
         bf.sync_barrier(ca)
+        # get_new_pg (trace replay's group creation, pytorch_dist_backend.py:1132-1138) and the store hand-off used by
+        # --disable-parallel-read
+        ca.group = bf.get_new_pg(list(range(world)), "gloo")
+        ca.asyncOp, ca.ipTensor = False, torch.full((3,), float(rank + 1))
+        ca.opTensor = ca.ipTensor
+        bf.all_reduce(ca)
+        assert ca.ipTensor.tolist() == [float(sum(range(1, world + 1)))] * 3
+        if rank == 0:
+            bf.store_set("k", "v1")
+        assert bf.store_get("k") == b"v1"
     finally:
         bf.shutdown()
 
