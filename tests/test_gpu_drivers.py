@@ -342,7 +342,8 @@ def test_compute_python_json_config_runner(tmp_path):
     assert [r["config"]["input"]["args"] for r in ev][:4] == [[128, 5], [128, 20], [256, 5], [256, 20]]
     assert all(len(r["metric"]["backward"]["gpu.time"]) == 4 and min(r["metric"]["backward"]["gpu.time"]) > 0 for r in ev)
     assert all(len(r["metric"]["forward"]["gpu.time"]) == 1 and len(r["metric"]["backward"]["gpu.time"]) == 1 for r in co)
-    assert len((tmp_path / "res.json").read_text().splitlines()) == 16
+    lines = (tmp_path / "res.json").read_text().splitlines()      # header line (run options + system information) + one line per run
+    assert len(lines) == 17 and "run_options" in json.loads(lines[0]) and all("id" in json.loads(ln) for ln in lines[1:])
     assert len(fl) == 16 and "backward" not in fl[0]["metric"] and len(fl[0]["metric"]["forward"]["gpu.time"]) == 2
 
 
