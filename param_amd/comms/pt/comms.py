@@ -891,7 +891,7 @@ def main(argv=None):
             args = bench.readArgs(parser)
         finally:
             sys.argv = old
-    logging.basicConfig(level=getattr(logging, args.log.upper(), logging.ERROR))
+    comms_utils.init_logging(args.log)
     env = comms_utils.read_comms_env_vars()
     if env["global_rank"] == 0 or (args.enable_local_report and env["local_rank"] == 0):       # comms.py:1559-1575
         print("\t PARAM COMM environment: %s " % (str(env)))

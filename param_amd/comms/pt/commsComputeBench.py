@@ -218,7 +218,7 @@ def main(argv=None):
         args = bench.readArgs(parser)
     finally:
         sys.argv = old
-    logging.basicConfig(level=getattr(logging, args.log.upper(), logging.ERROR))
+    comms_utils.init_logging(args.log)
     bench.checkArgs(args)
     env = comms_utils.read_comms_env_vars()
     if env["world_size"] < 1:

@@ -632,7 +632,7 @@ def main(argv=None):
     bench = commsTraceReplayBench()
     parser = argparse.ArgumentParser(description="PARAM-Comms trace replay (MI355X / RCCL over xGMI build)")
     args = bench.readArgs(parser, argv)
-    logging.basicConfig(level=getattr(logging, args.log.upper(), logging.ERROR))
+    comms_utils.init_logging(args.log)
     bench.checkArgs(args)
     bench.setTraceFile(args)
     env = comms_utils.read_comms_env_vars()

@@ -125,6 +125,18 @@ def clearQuantCommCtx(collectiveArgs) -> None:
     collectiveArgs.reduce_qcomm = 32
 
 
+def init_logging(level_name: str) -> None:
+    """root logger as the reference's drivers set it up (``:1895-1906``): the level named by ``--log``, every line prefixed with
+    time, logger, level and this process's rank from the launcher's environment; an unknown level name is an error"""
+    level = getattr(logging, str(level_name).upper(), None)
+    if not isinstance(level, int):
+        raise ValueError(f"Invalid log level: {level_name}")
+    rank = read_comms_env_vars()["global_rank"]
+    # no force=True: a host application (or a test runner) that configured logging first keeps its handlers; the level applies
+    logging.basicConfig(level=level, format="[%(asctime)s][%(name)s][%(levelname)s][Rank{:3}] - %(message)s".format(rank))
+    logging.getLogger().setLevel(level)
+
+
 def get_rank_details(backendFuncs):
     """(local rank, global rank, world size, default group, device, hardware device) of this process, from the backend
     (reference ``:255-273``)"""

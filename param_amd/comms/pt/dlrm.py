@@ -546,7 +546,7 @@ class commsDLRMBench:
 def main(argv=None):
     bench = commsDLRMBench()
     args = bench.readArgs(argparse.ArgumentParser(description="DLRM sparse-feature comms benchmark (MI355X build)"), argv)
-    logging.basicConfig(level=getattr(logging, args.log.upper(), logging.ERROR))
+    comms_utils.init_logging(args.log)
     return bench.run(args)
 
 
