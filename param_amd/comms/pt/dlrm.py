@@ -413,6 +413,20 @@ class commsDLRMBench:
             return [torch.rand(dims[i + 1], dims[i], device=dev) for i in range(len(dims) - 1)]
         num_int = self.top_mlp_input_size(args, len(ln_emb))
         top, bot = layers(f"{num_int}-{args.arch_mlp_top}"), layers(args.arch_mlp_bot)
+        if rank == 0:          # the configuration lines of the reference's set-up (dlrm.py:545-612, 1421-1428)
+            dims_sum = [n * D for n in n_emb_per_rank]
+            print("\t mpi-params: %s" % (env,))
+            print("\t rank: %s args.model: %s model: %s " % (rank, args.model, args.model))
+            print("\tdims_sum_per_rank: %s " % (dims_sum,))
+            print("\t ipConfig['num_sparse_fea']: %s " % (len(ln_emb),))
+            print("\t ipConfig['n_emb_per_rank']: %s " % (list(n_emb_per_rank),))
+            print("\t ipConfig['dims_sum_per_rank']: %s " % (dims_sum,))
+            print("\t ipConfig['local_emb_dims']: %s " % ([D] * len(my_rows),))
+            print("\t ln_top: %s \n\t ln_bot: %s \n\t n_emb: %s " % (
+                np.array([num_int] + [int(x) for x in args.arch_mlp_top.split("-")]),
+                np.array([int(x) for x in args.arch_mlp_bot.split("-")]), len(ln_emb)))
+        print("\n\t ****** Rank: G: %d L: %d host: %s starting new epoch, model: %s ***** \n"
+              % (rank, bf.get_local_rank(), os.uname()[1], args.model))
         gen = torch.Generator(device=dev)
         gen.manual_seed(args.numpy_rand_seed + rank)
         timers = ca.timers

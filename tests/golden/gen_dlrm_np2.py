@@ -68,7 +68,11 @@ if __name__ == "__main__":
         elif ln.strip().startswith("-----"):
             seps += 1
     assert header is not None and len(tables) == 2 and len(tables[0]) == 22, (header, [len(t) for t in tables])
-    _json.dump({"flags": FLAGS, "header": header, "tables": tables, "separator_lines": seps,
+    keep = ("\t mpi-params", "\t rank: 0 args.model", "\tdims_sum_per_rank", "\t ipConfig[", "\t ln_top", "\t ln_bot", "\t n_emb")
+    config_lines = [ln for ln in texts[0].splitlines() if ln.startswith(keep)]
+    epoch = [ln.replace(os.uname()[1], "<host>") for ln in texts[0].splitlines() if "starting new epoch" in ln]
+    _json.dump({"flags": FLAGS, "config_lines": config_lines, "epoch_line": epoch[0],
+                "header": header, "tables": tables, "separator_lines": seps,
                 "rank1_prints_table": any("intermed_calc_length" in ln for ln in texts[1].splitlines())},
                open(os.path.join(out, "report_rank0.json"), "w"), indent=1)
     print("report rows:", [(r["region"], r["memory"]) for r in tables[0]])
