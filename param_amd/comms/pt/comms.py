@@ -896,7 +896,8 @@ def main(argv=None):
     if env["global_rank"] == 0 or (args.enable_local_report and env["local_rank"] == 0):       # comms.py:1559-1575
         print("\t PARAM COMM environment: %s " % (str(env)))
         print("\t backend: %s nw-stack: %s args.data_types: %s args.b: %s args.e: %s args.f: %s args.z: %s args.master_ip: %s "
-              % (args.backend, args.nw_stack, args.data_types, args.b, args.e, args.f, args.z, args.master_ip))
+              % (args.backend, args.nw_stack, [d for d in args.data_types.split(",") if d], args.b, args.e, args.f, args.z,
+                 args.master_ip))
     bench.checkArgs(args)
     if env["world_size"] < 1:
         env = {"world_size": 1, "local_size": 1, "global_rank": 0, "local_rank": 0}

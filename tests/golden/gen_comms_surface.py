@@ -64,7 +64,7 @@ def digest(text, pt2pt=False):
     for ln in text.splitlines():
         if ln.startswith("[Rank") and "allSizes" in ln:
             fixed.append(ln)
-        elif ln.startswith("\t collective="):
+        elif ln.startswith(("\t collective=", "\t PARAM COMM environment", "\t backend: ")):
             fixed.append(ln)
         elif ln.startswith("\tCOMMS-RES") and not ln.startswith("\tCOMMS-RES-"):
             fixed.append(ln)
