@@ -277,3 +277,27 @@ def test_param_profile_ranges_and_timer():
     names = {e.name for e in prof.events()}
     assert {"# PARAM unit range", "# untimed", "# PARAM replay 3 pre-comm barrier # blockA", "# PARAM replay 3:blockA",
             "# PARAM replay 3 post-comm barrier # blockA"} <= names
+
+
+def test_replay_report_text_equals_reference(capsys):
+    """reportBenchTime: for the same statistics (message sizes per collective, replay latencies, batch latencies) the text equals
+    what the REFERENCE's commsTraceReplayBench.reportBenchTime prints, in dry-run and in replay mode
+    (tests/golden/replay_report.json, gen_replay_report.py ran the reference's method on a bare instance)"""
+    import json
+    import os
+
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "replay_report.json")))
+    st = gold["stats"]
+    for dry, key in ((True, "dry_run"), (False, "replay")):
+        b = commsTraceReplayBench()
+        b.comms_trace = [None] * st["n_msgs"]
+        b.trace_file, b.is_dry_run = st["trace_file"], dry
+        b.collInMsgBytes = {k: list(v) for k, v in st["collInMsgBytes"].items()}
+        b.collOutMsgBytes = {k: list(v) for k, v in st["collOutMsgBytes"].items()}
+        b.collLat = {k: list(v) for k, v in st["collLat"].items()}
+        b.compLat = {}
+        b.totalTraceLatency, b.totalCommsLatency, b.totalCompsLatency = st["totalTraceLatency"], st["totalCommsLatency"], 0.0
+        b.batchLat, b.colls_per_batch = list(st["batchLat"]), st["colls_per_batch"]
+        capsys.readouterr()
+        b.reportBenchTime()
+        assert capsys.readouterr().out == gold[key], key
