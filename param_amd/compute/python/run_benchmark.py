@@ -252,6 +252,14 @@ def run_op(name: str, op_cfg: dict, device: str, warmup: int, iters: int, backwa
                 # reference appends every further build id of a config to the previous one -- not reproduced)
                 stats = {"op_name": name, "id": f"{ci}|{build_id}|{input_id}", "metric": metrics,
                          "config": {"build": {"args": bargs, "kwargs": bkw}, "input": {"args": [batch_size, pooling_factor]}}}
+                for pass_name, metric in metrics.items():          # the reference's log lines per pass and metric (build_executor.py:514-532)
+                    logger.info(f"pass: {pass_name}")
+                    for metric_name, records in metric.items():
+                        total = sum(records) if records else 0
+                        avg = total / len(records) if records else 0
+                        unit = "ms" if metric_name.endswith(".time") else "MB"
+                        logger.info(f"metric: {metric_name}, average: {avg:.3f} {unit}, total: {total:.3f} {unit}")
+                        logger.info("[" + ", ".join(f"{x:.3f}" for x in records) + "]")
                 out_stream.write(json.dumps(stats) + "\n")
                 out_stream.flush()
                 results.append(stats)
