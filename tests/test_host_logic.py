@@ -491,3 +491,46 @@ def test_comms_compute_bench_report_equals_reference_text(golden_dir, monkeypatc
     rows = [ln for ln in out.splitlines() if ln.startswith("\tCOMMS-RES-all_to_allv-float32-x")]
     assert len(rows) == 2 and [int(ln.split()[1]) for ln in rows] == [1024, 4096] and len(rows[0].split()) == 12
     assert out.count("COMMS-COMPUTE-RES-all_to_allv-emb_lookup") == 2
+
+
+def test_run_benchmark_main_with_stub_operator(tmp_path, monkeypatch, golden_dir):
+    """run_benchmark.main end to end on the host with the operator and the executor stubbed out (the product operator has no CPU
+    path): id stream of a ranged config, ``-r / -s`` window applied to it, result file = header line + one JSON line per run,
+    ``--append`` keeps the earlier lines, the per-metric log lines"""
+    from param_amd.compute.python import op_map, run_benchmark as R
+
+    calls = []
+
+    class FakeOp:
+        device = None
+
+        def cleanup(self):
+            pass
+
+        def build(self, *a, **k):
+            calls.append(a[:3])
+
+    class FakeExec:
+        def __init__(self, *a, **k):
+            pass
+
+        def run(self, data):
+            return {"forward": {"gpu.time": [0.5, 0.25], "gpu.memory": [1.0, 1.0]}, "backward": {"gpu.time": [], "gpu.memory": []}}
+
+    monkeypatch.setitem(op_map, "FakeTBE", FakeOp())
+    monkeypatch.setattr(R, "OpExecutor", FakeExec)
+    fx = json.load(open(os.path.join(golden_dir, "ref_plugin_rows.json")))["compute_python"]
+    cfg = {"FakeTBE": dict(list(fx["config"].values())[0])}
+    path = tmp_path / "cfg.json"
+    path.write_text(json.dumps(cfg))
+    want = [f"0|{r['build_id']}|{r['input_id']}" for r in fx["stream"]]       # the reference's (build id, input id) stream
+    res = R.main(["-c", str(path), "-d", "cpu", "-o", str(tmp_path / "out")])
+    assert [r["id"] for r in res] == want and len(calls) == len(want)
+    lines = (tmp_path / "out.json").read_text().splitlines()
+    assert len(lines) == len(want) + 1 and "run_options" in json.loads(lines[0]) and "sys_info" in json.loads(lines[0])
+    assert [json.loads(ln)["id"] for ln in lines[1:]] == want and json.loads(lines[1])["op_name"] == "FakeTBE"
+    # resume at the third run, stop in front of the sixth; --append leaves the earlier file content in place
+    res = R.main(["-c", str(path), "-d", "cpu", "-o", str(tmp_path / "out"), "-a", "-r", f"FakeTBE|{want[2]}", "-s", f"FakeTBE|{want[5]}"])
+    assert [r["id"] for r in res] == want[2:5]
+    lines2 = (tmp_path / "out.json").read_text().splitlines()
+    assert lines2[:len(lines)] == lines and len(lines2) == len(lines) + 1 + 3
