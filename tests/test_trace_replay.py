@@ -301,3 +301,41 @@ def test_replay_report_text_equals_reference(capsys):
         capsys.readouterr()
         b.reportBenchTime()
         assert capsys.readouterr().out == gold[key], key
+
+
+def test_example_trace_replays_on_the_host_with_stub_lookup(tmp_path, monkeypatch):
+    """examples/trace_replay/0.json (the trace the GPU test replays: a2a's, all_reduces, emb_lookup forward / backward as compute
+    entries) through commsTraceReplay.main on one gloo rank with the lookup kernel stubbed out -- the driver's bookkeeping around
+    the compute entries (profiler ranges, reuse cache, per-kernel latency table) without the device"""
+    import contextlib
+    import io
+    import json
+    import os
+
+    from param_amd.comms.pt import comms_utils, commsTraceReplay
+    from param_amd.comms.pt.mi355_backend import MI355XBackend
+    from tests.dist_workers import free_port
+
+    def fake_init(ca, cur, bf):
+        ca.direction, ca.emb_dim, ca.batch_size = cur.direction, cur.emb_dim, cur.batch_size
+        ca.num_emb_ops, ca.num_emb_tables_batched, ca.embRequests, ca.emb, ca.LookupOut, ca.grad_output = 1, -1, [None], [None], None, None
+
+    monkeypatch.setattr(comms_utils, "init_emb_lookup", fake_init)
+    monkeypatch.setattr(MI355XBackend, "emb_lookup", lambda self, ca: None)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    tdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "trace_replay")
+    for blocking in ("1", "0"):
+        out = tmp_path / f"z{blocking}"
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            b = commsTraceReplay.main(["--trace-path", tdir, "--device", "cpu", "--backend", "gloo", "--master-ip", "127.0.0.1",
+                                       "--master-port", str(free_port()), "--num-replays", "3", "--do-warm-up", "--reuse-tensors",
+                                       "--z", blocking, "--output-path", str(out)])
+        assert len(b.compLat["emb_lookup"]) == 6 and min(b.compLat["emb_lookup"]) > 0
+        assert len(b.collLat["all_to_allv"]) == 9 and len(b.collLat["all_reduce"]) == 3
+        assert len(b.embLookupReuse) == 2
+        rec = json.load(open(out / "replayedCommsPerf.rank0.json"))
+        fwd = [r for r in rec if r.get("compute") == "emb_lookup" and r["direction"] == "forward"]
+        assert len(fwd) == 3 and fwd[0]["num_emb_tables"] == 8 and fwd[0]["latency_us"] > 0
+        assert "Replayed 6 emb_lookup (compute)" in buf.getvalue()
