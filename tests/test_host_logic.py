@@ -491,6 +491,18 @@ def test_comms_compute_bench_report_equals_reference_text(golden_dir, monkeypatc
     rows = [ln for ln in out.splitlines() if ln.startswith("\tCOMMS-RES-all_to_allv-float32-x")]
     assert len(rows) == 2 and [int(ln.split()[1]) for ln in rows] == [1024, 4096] and len(rows[0].split()) == 12
     assert out.count("COMMS-COMPUTE-RES-all_to_allv-emb_lookup") == 2
+    # the two other invocations of the GPU test: compute only (no collective: zero bytes, the short header), and --bitwidth 8
+    res = C.main(["--master-ip", "127.0.0.1", "--master-port", str(free_port()), "--b", "1K", "--e", "1K", "--n", "2", "--w", "1",
+                  "--collective", "all_to_allv", "--device", "cpu", "--backend", "gloo", "--mode", "compute", "--direction", "backward",
+                  "--num-compute", "2", "--ntables", "4", "--num-emb-tables-batched", "2", "--batch-size", "8"])
+    out = capsys.readouterr().out
+    assert res[0]["memSize"] == 0 and res[0]["report"]["algBW"] == 0 and C.format_cc_header("compute", 32) in out
+    assert len([ln for ln in out.splitlines() if ln.startswith("\tCOMMS-RES-all_to_allv-float32")][0].split()) == 10
+    res = C.main(["--master-ip", "127.0.0.1", "--master-port", str(free_port()), "--b", "4K", "--e", "4K", "--n", "3", "--w", "1",
+                  "--collective", "all_to_allv", "--device", "cpu", "--backend", "rccl_xgmi", "--ntables", "4", "--batch-size", "8",
+                  "--bitwidth", "8", "--quant-a2a-embedding-dim", "128", "--z", "1"])
+    out = capsys.readouterr().out
+    assert res[0]["bitwidth"] == 8 and res[0]["quant_us"] > 0 and res[0]["dequant_us"] > 0 and C.format_cc_header("comms-compute", 8) in out
 
 
 def test_run_benchmark_main_with_stub_operator(tmp_path, monkeypatch, golden_dir):
