@@ -218,3 +218,39 @@ def test_oracle_rowwise_adagrad_pinned_to_fbgemm_fixture(coracle, golden_dir):
                                             None, lr=float(lr), eps=float(eps), weight_decay=float(wd), weight_decay_mode=mode)
             assert np.allclose(W, z[f"{tag}.W.{t}"], rtol=2e-5, atol=1e-6), (tag, t)
             assert np.allclose(mom, z[f"{tag}.mom.{t}"], rtol=2e-5, atol=1e-7), (tag, t)
+
+
+def test_c_oracle_against_live_torch_on_random_requests(coracle):
+    """Beside the committed goldens: 40 random requests (ragged bags incl. empty first / middle / last ones, repeated indices,
+    per-sample weights, int32 and int64 indices, D from 4 to 160) through torch's CPU EmbeddingBag(sum) -- the engine the
+    reference calls -- live: forward bit for bit, dense gradient (autograd of the same op, ``sparse=False``) within 1e-5 of the
+    summed magnitudes (it is exact except for the order of additions into rows looked up many times)"""
+    import torch
+
+    rng = np.random.default_rng(20260928)
+    for case in range(40):
+        rows, D, B = int(rng.integers(1, 400)), int(rng.choice([4, 8, 32, 56, 128, 160])), int(rng.integers(1, 40))
+        lens = rng.integers(0, 9, size=B)
+        if case % 4 == 0:
+            lens[0] = 0
+        if case % 5 == 0:
+            lens[-1] = 0
+        off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+        n = int(lens.sum())
+        idx = rng.integers(0, rows, size=n).astype(np.int64 if case % 2 else np.int32)
+        psw = rng.standard_normal(n).astype(np.float32) if case % 3 == 0 else None
+        W = rng.standard_normal((rows, D)).astype(np.float32)
+        grad = rng.standard_normal((B, D)).astype(np.float32)
+        Wt = torch.tensor(W, requires_grad=True)
+        out_t = torch.nn.functional.embedding_bag(torch.from_numpy(idx), Wt, torch.from_numpy(off).to(torch.from_numpy(idx).dtype),
+                                                  mode="sum", per_sample_weights=None if psw is None else torch.from_numpy(psw))
+        out = coracle.fwd(W, idx, off, psw)
+        assert np.array_equal(out, out_t.detach().numpy()), case
+        out_t.backward(torch.from_numpy(grad))
+        dW = coracle.bwd_f32(np.zeros_like(W), idx, off, grad, psw)
+        mag = np.zeros(W.shape, dtype=np.float64)
+        start, end = O.bag_bounds(off, B, n)
+        for b in range(B):
+            for j in range(start[b], end[b]):
+                mag[idx[j]] += np.abs(grad[b].astype(np.float64)) * (1.0 if psw is None else abs(float(psw[j])))
+        assert (np.abs(dW.astype(np.float64) - Wt.grad.numpy().astype(np.float64)) <= 1e-5 * mag + 1e-30).all(), case
