@@ -181,7 +181,7 @@ def dlrm_sparse_path(rank, world, port):
         bf.shutdown()
 
 
-def dlrm_driver(rank, world, port, outdir, extra_json="[]", num_batches="4"):
+def dlrm_driver(rank, world, port, outdir, extra_json="[]", num_batches="4", flags_json=""):
     import contextlib
     import io
     import json
@@ -203,11 +203,15 @@ def dlrm_driver(rank, world, port, outdir, extra_json="[]", num_batches="4"):
 
     bench = D_.commsDLRMBench()
     import argparse
-    args = bench.readArgs(argparse.ArgumentParser(), [
-        "--master-ip", "127.0.0.1", "--master-port", str(port), "--backend", "gloo", "--device", "cpu",
-        "--mini-batch-size", "8", "--num-batches", num_batches, "--warmup-batches", "1", "--arch-mlp-bot", "16-8",
-        "--arch-mlp-top", "8-1", "--arch-sparse-feature-size", "8", "--arch-embedding-size", "100-200-300-400",
-        "--num-indices-per-lookup", "5", "--print-comms", "--data-generation", "random"] + __import__("json").loads(extra_json))
+    if flags_json:          # the flag list of another fixture (tests/golden/dlrm_np4/flags.json), as the reference was given it
+        args = bench.readArgs(argparse.ArgumentParser(), ["--master-ip", "127.0.0.1", "--master-port", str(port)]
+                              + __import__("json").loads(flags_json) + ["--data-generation", "random"])
+    else:
+        args = bench.readArgs(argparse.ArgumentParser(), [
+            "--master-ip", "127.0.0.1", "--master-port", str(port), "--backend", "gloo", "--device", "cpu",
+            "--mini-batch-size", "8", "--num-batches", num_batches, "--warmup-batches", "1", "--arch-mlp-bot", "16-8",
+            "--arch-mlp-top", "8-1", "--arch-sparse-feature-size", "8", "--arch-embedding-size", "100-200-300-400",
+            "--num-indices-per-lookup", "5", "--print-comms", "--data-generation", "random"] + __import__("json").loads(extra_json))
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         rep = bench.run(args, lookup_factory=factory)
