@@ -322,7 +322,9 @@ class commsDLRMBench:
         parser.add_argument("--num-batches", type=int, default=10)
         parser.add_argument("--warmup-batches", type=int, default=2)
         parser.add_argument("--num-indices-per-lookup", type=int, default=10)
-        parser.add_argument("--num-indices-per-lookup-fixed", action="store_true", default=False)
+        # the reference declares this one ``type=bool`` (dlrm.py:705): it takes a value and any non-empty string means True;
+        # here the value is optional, so both ``--num-indices-per-lookup-fixed`` and ``--num-indices-per-lookup-fixed True`` parse
+        parser.add_argument("--num-indices-per-lookup-fixed", nargs="?", const=True, default=False, type=bool)
         parser.add_argument("--numpy-rand-seed", type=int, default=123)
         parser.add_argument("--embed-data-type", type=str, default="float32", choices=["float32", "bfloat16", "float16"])
         parser.add_argument("--learning-rate", type=float, default=0.01)
