@@ -39,6 +39,10 @@ CASES = [
     {"name": "multi_comms", "world": 4,
      "argv": ["--multi-comms", "2", "--b", "64", "--e", "1024", "--f", "4", "--z", "1", "--c", "1", "--root", "1",
               "--collective", "all_reduce,all_to_allv,all_gather,broadcast"]},
+    {"name": "eight_ranks", "world": 8,
+     "argv": ["--b", "64", "--e", "4096", "--f", "8", "--z", "1", "--c", "1", "--collective", "all_to_allv,all_gather_base,reduce_scatter_base,all_reduce"]},
+    {"name": "zero_byte_splits", "world": 4,
+     "argv": ["--b", "96", "--e", "384", "--f", "2", "--z", "1", "--include-0B", "--collective", "all_to_all_single"]},
     # incast / multicast: the reference hangs on gloo here (both, 4 ranks, probed with a 60 s limit) -- no golden for them
 ]
 
