@@ -356,7 +356,7 @@ class commsCollBench:
             ca.ipTensor_split, ca.opTensor_split = [], []
         else:
             ca.ipTensor, ca.opTensor = ip, op
-            if commsParams.include_0B and world > 1:
+            if commsParams.include_0B and world > 1 and commsParams.collective == "all_to_all_single":     # the reference's scope (:1180)
                 mates = (self.groupRanks or {}).get(getattr(ca, "pgId", 0), [])
                 me = mates.index(ca.global_rank) if ca.global_rank in mates else ca.global_rank      # rank inside the group
                 ins = {i: [0] * world for i in range(world)}
