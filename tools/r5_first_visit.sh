@@ -31,4 +31,6 @@ step dlrm        python -m param_amd.comms.pt.dlrm --master-ip 127.0.0.1 --maste
 step replay      python -m param_amd.comms.pt.commsTraceReplay --trace-path examples/trace_replay --device rocm --master-ip 127.0.0.1 \
                  --master-port 29708 --num-replays 4 --do-warm-up --z 1 --use-one-trace --disable-parallel-read --enable-profiler \
                  --profiler-num-replays 2 --output-path $out/replay
+PARAM_AMD_R5_CLI=1 timeout 900 python -m pytest tests/test_gpu_cli_surface.py -q -m gpu > "$out/pytest_cli_surface.log" 2>&1
+echo "== gated GPU tests of the command-line surface (green -> drop the gate in tests/test_gpu_cli_surface.py)"; tail -5 "$out/pytest_cli_surface.log"
 ls "$out" | head -60
