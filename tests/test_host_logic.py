@@ -546,3 +546,21 @@ def test_run_benchmark_main_with_stub_operator(tmp_path, monkeypatch, golden_dir
     assert [r["id"] for r in res] == want[2:5]
     lines2 = (tmp_path / "out.json").read_text().splitlines()
     assert lines2[:len(lines)] == lines and len(lines2) == len(lines) + 1 + 3
+
+
+def test_comms_cli_refuses_what_one_rank_cannot_run(monkeypatch, capsys):
+    """a single rank (the GPU visits' world): --pt2pt needs a peer, --multi-comms must divide the ranks, --root must exist --
+    a configuration error ends the run through gracefulExit with the process group shut down, not with a hang or a traceback"""
+    import torch.distributed as dist
+
+    from param_amd.comms.pt import comms
+    from tests.dist_workers import free_port
+
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    for extra in (["--pt2pt", "one2one"], ["--multi-comms", "2"], ["--root", "1", "--collective", "broadcast"],
+                  ["--collective", "all_to_allv", "--i", "4,4"]):
+        with pytest.raises(SystemExit):
+            comms.main(["--master-ip", "127.0.0.1", "--master-port", str(free_port()), "--device", "cpu", "--backend", "gloo"] + extra)
+        assert not dist.is_initialized()
+    capsys.readouterr()
