@@ -233,6 +233,10 @@ class commsCollBench:
 
     def checkArgs(self, args):
         """argument checks that need no backend (reference checkBasicArgs + checkArgsdataType, comms.py:277-374)"""
+        if getattr(args, "nw_stack", "pytorch-dist") != "pytorch-dist":           # comms_utils.py:1884-1888; the one stack of this build
+            logger.error(f"Specified backend: {args.nw_stack} is not one of the supported backends: ['pytorch-dist']. "
+                         "Make sure the input is using the correct case.")
+            comms_utils.gracefulExit()
         args.b = comms_utils.parsesize(args.b)
         args.e = comms_utils.parsesize(args.e)
         if getattr(args, "pt2pt", None) is not None:                  # _checkPt2Pt (comms.py:208-216)

@@ -360,6 +360,9 @@ def test_comms_cli_argument_checks():
     bench, a = _parse_comms(["--i", "4,4", "--collective", "all_reduce"])
     with pytest.raises(SystemExit):
         bench.checkArgs(a)
+    bench, a = _parse_comms(["--nw-stack", "pytorch-xla-tpu"])
+    with pytest.raises(SystemExit):
+        bench.checkArgs(a)
     bench, a = _parse_comms(["--collective", "all_to_all,nonsense"])
     with pytest.raises(SystemExit):
         bench.checkArgs(a)
