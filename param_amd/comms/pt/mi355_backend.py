@@ -691,9 +691,7 @@ class MI355XBackend(backendFunctions):
         rank, world = self.bootstrap_info.global_rank, self.bootstrap_info.world_size
         backend = self._pg_backend(backend)
         if not dist.is_initialized():
-            if self.tcp_store is None:
-                self.tcp_store = dist.TCPStore(master_ip, int(master_port), world, is_master=(rank == 0),
-                                               use_libuv=True)
+            self.initialize_tcpstore(master_ip, master_port)
             init_method = self._cp("init_method", None)          # --init-method URL replaces the store (reference :1182-1183)
             dist.init_process_group(backend, rank=rank, world_size=world, store=self.tcp_store if init_method is None else None,
                                     init_method=init_method,
@@ -723,8 +721,12 @@ class MI355XBackend(backendFunctions):
     def initialize_tcpstore(self, master_ip, master_port) -> None:
         """the rendezvous store by itself (reference ``:1145-1154``): ``store_set`` / ``store_get`` work before any group exists"""
         if self.tcp_store is None:
+            # under torch.distributed.run the launcher's agent already serves a store on MASTER_PORT
+            # (TORCHELASTIC_USE_AGENT_STORE=True): a driver started without --master-port of its own (its default IS MASTER_PORT)
+            # joins that store as a client instead of failing to bind the port -- rank 0 included
+            agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True" and str(master_port) == os.environ.get("MASTER_PORT")
             self.tcp_store = dist.TCPStore(master_ip, int(master_port), self.bootstrap_info.world_size,
-                                           is_master=(self.bootstrap_info.global_rank == 0), use_libuv=True)
+                                           is_master=(self.bootstrap_info.global_rank == 0 and not agent), use_libuv=True)
 
     def benchmark_comms(self, benchTime, commsParams) -> None:
         if getattr(commsParams, "init_only", False):
