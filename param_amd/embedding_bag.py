@@ -481,6 +481,13 @@ class BatchedEmbeddingBagMI355(nn.Module):
             self.reset_parameters(init, seed)
 
     # -- tables ------------------------------------------------------------------------------
+    @property
+    def embedding_specs(self):
+        """``(rows, dim, location, compute device)`` per table -- the attribute of fbgemm's TBE module that callers of the
+        reference's operator read back (train/compute/python/test/test_split_table_batched_embeddings_ops.py:29-30)"""
+        dev = self.weights.device
+        return [(int(r), int(d), "device" if dev.type == "cuda" else "host", dev.type) for r, d in zip(self.rows, self.dims)]
+
     def table(self, t: int) -> torch.Tensor:
         s = self._starts[t]
         return self.weights.data[s:s + self._sizes[t]].view(self.rows[t], self.dims[t])

@@ -567,3 +567,12 @@ def test_comms_cli_refuses_what_one_rank_cannot_run(monkeypatch, capsys):
             comms.main(["--master-ip", "127.0.0.1", "--master-port", str(free_port()), "--device", "cpu", "--backend", "gloo"] + extra)
         assert not dist.is_initialized()
     capsys.readouterr()
+
+
+def test_batched_module_reports_embedding_specs():
+    """``embedding_specs``: (rows, dim, location, compute device) per table, the attribute of fbgemm's TBE module the reference's
+    operator test reads back (test_split_table_batched_embeddings_ops.py:29-60); scalar rows / dims are broadcast as there"""
+    import param_amd
+
+    m = param_amd.BatchedEmbeddingBagMI355([1000, 2000], [64, 128], device="cpu", init=None)
+    assert [(s[0], s[1]) for s in m.embedding_specs] == [(1000, 64), (2000, 128)] and m.embedding_specs[0][2:] == ("host", "cpu")
