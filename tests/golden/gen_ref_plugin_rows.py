@@ -39,6 +39,11 @@ SWEEPS = [
      "collective": "all_to_allv,all_to_all_single,all_reduce"},
     {"name": "nonblocking_rest_of_table", "z": "0",
      "collective": "all_to_allv,all_gather,all_gather_base,reduce_scatter,reduce_scatter_base,broadcast,reduce,gather,scatter"},
+    # --multi-comms: the reference's driver leaves the group table on the backend object and calls initialize_groups(backend=...)
+    # (comms.py:1455-1456); --pt2pt: send / recv / P2POp / batch_isend_irecv of the plug-in under the reference's four measurements
+    {"name": "multi_comms_groups", "z": "1", "collective": "all_reduce,all_to_allv", "extra": ["--multi-comms", "2"]},
+    {"name": "pt2pt_one2one", "z": "0", "collective": "all_reduce", "extra": ["--pt2pt", "one2one", "--window", "4"], "pt2pt": True,
+     "c": "0"},        # the reference's --c 1 dereferences an unset rank list under --pt2pt (comms_utils.py:1036)
 ]
 
 
@@ -64,6 +69,11 @@ def rows_of(text):
     return rows
 
 
+def pt2pt_rows_of(text):
+    return [{"name": ln.split()[0], "size": int(ln.split()[1]), "columns": len(ln.split())} for ln in text.splitlines()
+            if ln.startswith("\tCOMMS-RES-")]
+
+
 def main():
     work = tempfile.mkdtemp()
     os.makedirs(os.path.join(work, "pb"))
@@ -74,16 +84,16 @@ def main():
 
     # 1. comms.py sweeps: plug-in vs the reference's own backend
     for sw in SWEEPS:
-        common = ["--b", "64", "--e", "1024", "--f", "4", "--n", "3", "--w", "1", "--z", sw["z"], "--c", "1",
-                  "--collective", sw["collective"], "--device", "cpu"]
+        common = ["--b", "64", "--e", "1024", "--f", "4", "--n", "3", "--w", "1", "--z", sw["z"], "--c", sw.get("c", "1"),
+                  "--collective", sw["collective"], "--device", "cpu"] + sw.get("extra", [])
         plug = run2(work, COMMS_LAUNCH, common + ["--backend", "rccl_xgmi"], port, pb, pre=(f"{REF}/train/comms/pt/comms.py",))
         own = run2(work, f"{REF}/train/comms/pt/comms.py", common + ["--backend", "gloo"], port + 1, pb)
         port += 2
         assert "Hello from Rank 1" in plug, "sayHello() under the reference driver"
-        r_plug, r_own = rows_of(plug), rows_of(own)
+        r_plug, r_own = (rows_of(plug), rows_of(own)) if not sw.get("pt2pt") else (pt2pt_rows_of(plug), pt2pt_rows_of(own))
         assert r_plug and r_plug == r_own, (r_plug, r_own)
         result["comms"].append({"name": sw["name"], "args": common + ["--backend", "rccl_xgmi"], "rows": r_plug,
-                                "header": [ln for ln in plug.splitlines() if "COMMS-RES" in ln and "total-size" in ln][0]})
+                                "header": [ln for ln in plug.splitlines() if "COMMS-RES" in ln and ("total-size" in ln or "pingLatency" in ln)][0]})
         print(sw["name"], len(r_plug), "rows == reference backend's")
 
     # 2. dlrm.py with the plug-in's collectives: --print-comms records == the reference's own (dlrm_np2 fixture)
