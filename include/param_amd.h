@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PM_ABI_VERSION 5
+#define PM_ABI_VERSION 6
 
 typedef void* pm_stream_t;
 
@@ -312,6 +312,18 @@ int pm_set_tuning(int32_t unroll, int32_t bags_per_block, int32_t xcd_affine, in
  * reads (uniform indices: 0.69 -> 0.72-0.74 of the HBM peak).
  */
 int pm_set_forward_tuning(int32_t stage_out);
+
+/*
+ * Persistent forward (ABI v6; csrc/embbag_fwd_persist.hip): for requests the staged-burst kernel serves (fixed pooling,
+ * fp32 output) the launch is `wgs_per_cu` workgroups per compute unit that loop over the request's tiles in the dispatch
+ * order's (table, tile) sequence; each workgroup = `pool_waves` (4 or 7) pooling waves that issue row loads and LDS
+ * accesses only + ONE helper wave that stages the coming tiles' offsets / indices into a ring of `slots` LDS slots and
+ * writes finished tiles' pooled rows to memory -- no workgroup-wide barrier, no store in a pooling wave's memory queue.
+ * A tile is (bags pooled concurrently) x `bags_per_group` bags.  mode: 1 = requests of at least 8 tiles per resident
+ * workgroup (the default at -1), 0 = never (embbag_fwd_kernel's launch of one workgroup per tile), 2 = every eligible request
+ * whatever its size (tests).  0 for the other arguments = default.  Results are bit-identical in every setting.
+ */
+int pm_set_forward_persist(int32_t mode, int32_t slots, int32_t bags_per_group, int32_t pool_waves, int32_t wgs_per_cu);
 
 /*
  * Tuning knobs of the sorted backward (process-wide; -1 = default, which the environment can change:

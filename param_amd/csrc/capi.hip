@@ -20,6 +20,16 @@ std::atomic<int> g_bags_per_block{0};
 std::atomic<int> g_xcd_affine{-1};
 std::atomic<int> g_nt_loads{-1};
 std::atomic<int> g_stage_out{-1};
+// persistent forward (embbag_fwd_persist.hip; pm_set_forward_persist): mode -1 / 1 = for requests large enough to keep every
+// workgroup busy for several tiles, 0 = never, 2 = whenever the request is eligible (tests); the rest 0 = default
+std::atomic<int> g_ps_mode{-1};
+std::atomic<int> g_ps_slots{0};
+std::atomic<int> g_ps_bags_per_group{0};
+std::atomic<int> g_ps_pool_waves{0};
+std::atomic<int> g_ps_wgs_per_cu{0};
+constexpr int kPsDefaultSlots = 3;
+constexpr int kPsDefaultBagsPerGroup = 1;
+constexpr int kPsDefaultPoolWaves = 4;
 
 // destination-row cache policy of the sorted backward when pm_set_tuning leaves nt_loads at its default: plain loads,
 // agent-scope (sc1) stores.  The store writes through and drops the row's lines from the XCD's L2, so a row occupies L2 only
@@ -143,6 +153,7 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
     p.stage_bags = 0;
     p.flat_bags = 0;
     p.flat_target = 0;
+    p.ps_slots = 0;
     if (forward) {
         int want = g_stage_out.load();
         if (want < 0) {
@@ -225,6 +236,52 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
     return PM_OK;
 }
 
+// Persistent forward: decide and size.  Eligible = what the staged-burst kernel serves (fixed-pooling request, fp32 output,
+// bag-count tiles); the geometry of `p` is rewritten for embbag_fwd_persist_kernel (tile = bags pooled concurrently x bags per
+// lane group, one index slot sized for twice the tile's average lookups).  Returns false to keep the classic launch.
+bool configure_persist(const pm_embbag_batch* op, pm::KParams& p, int& pool_waves, int& wgs_per_cu) {
+    const int mode = g_ps_mode.load();
+    if (mode == 0) return false;
+    if (!(p.stage_out > 0 && !p.ordered && p.flat_bags == 0 && p.out_bits == 0)) return false;
+    const int vec = (op->weight_dtype == PM_F32) ? 4 : 8;
+    const int G = pm::group_lanes(op->max_dim, vec);
+    pool_waves = g_ps_pool_waves.load() == 7 ? 7 : (g_ps_pool_waves.load() == 4 ? 4 : kPsDefaultPoolWaves);
+    const int NG = pool_waves * (pm::kWave / G);
+    int bpg = g_ps_bags_per_group.load();
+    if (bpg <= 0) bpg = kPsDefaultBagsPerGroup;
+    while (bpg > 1 && NG * bpg + 1 > pm::kWave) --bpg;           // the helper wave stages a tile's offsets one per lane
+    const int tb = NG * bpg;
+    if (tb + 1 > pm::kWave) return false;
+    int slots = g_ps_slots.load();
+    if (slots <= 0) slots = kPsDefaultSlots;
+    if (slots < 2) slots = 2;
+    if (slots > 8) slots = 8;
+    const int64_t total_bags = static_cast<int64_t>(op->num_tables) * op->batch;
+    const int64_t avg_l = total_bags > 0 ? (op->num_indices + total_bags - 1) / total_bags : 0;
+    int64_t cap = (2 * static_cast<int64_t>(tb) * avg_l + 63) / 64 * 64;
+    if (cap < 64) cap = 64;
+    if (cap > 4096) cap = 4096;
+    const bool weighted = op->per_sample_weights != nullptr;
+    size_t lds = pm::fwd_persist_lds_bytes(tb, static_cast<int>(cap), weighted, p.stage_out, slots);
+    while (lds > 64 * 1024 && slots > 2) lds = pm::fwd_persist_lds_bytes(tb, static_cast<int>(cap), weighted, p.stage_out, --slots);
+    if (lds > 64 * 1024) return false;
+    const int64_t tiles = (op->bag_count + tb - 1) / tb;
+    if (tiles * op->num_tables > 0x7fffffffLL) return false;
+    int by_lds = static_cast<int>((160 * 1024) / lds);
+    int by_waves = 32 / (pool_waves + 1);
+    wgs_per_cu = g_ps_wgs_per_cu.load();
+    if (wgs_per_cu <= 0) wgs_per_cu = by_lds < by_waves ? by_lds : by_waves;
+    if (wgs_per_cu < 1) wgs_per_cu = 1;
+    // worth it only when a workgroup loops over several tiles (start-up is one two-round-trip prologue per workgroup, as before)
+    if (mode != 2 && tiles * op->num_tables < 8LL * 256 * wgs_per_cu) return false;
+    p.bags_per_block = tb;
+    p.tiles_per_table = static_cast<int32_t>(tiles);
+    p.idx_cap = static_cast<int32_t>(cap);
+    p.stage_bags = tb;
+    p.ps_slots = slots;
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -251,6 +308,20 @@ int pm_set_tuning(int32_t unroll, int32_t bags_per_block, int32_t xcd_affine, in
 int pm_set_forward_tuning(int32_t stage_out) {
     if (stage_out < -1 || stage_out > 1) return fail(PM_ERR_INVALID, "stage_out must be -1, 0 or 1");
     g_stage_out.store(stage_out);
+    return PM_OK;
+}
+
+int pm_set_forward_persist(int32_t mode, int32_t slots, int32_t bags_per_group, int32_t pool_waves, int32_t wgs_per_cu) {
+    if (mode < -1 || mode > 2) return fail(PM_ERR_INVALID, "mode must be -1 (default), 0 (off), 1 (large requests) or 2 (every eligible request)");
+    if (slots < 0 || slots == 1 || slots > 8) return fail(PM_ERR_INVALID, "slots must be 0 (default) or 2 .. 8");
+    if (bags_per_group < 0 || bags_per_group > 8) return fail(PM_ERR_INVALID, "bags_per_group must be 0 (default) or 1 .. 8");
+    if (pool_waves != 0 && pool_waves != 4 && pool_waves != 7) return fail(PM_ERR_INVALID, "pool_waves must be 0 (default), 4 or 7");
+    if (wgs_per_cu < 0 || wgs_per_cu > 8) return fail(PM_ERR_INVALID, "wgs_per_cu must be 0 (default) or 1 .. 8");
+    g_ps_mode.store(mode);
+    g_ps_slots.store(slots);
+    g_ps_bags_per_group.store(bags_per_group);
+    g_ps_pool_waves.store(pool_waves);
+    g_ps_wgs_per_cu.store(wgs_per_cu);
     return PM_OK;
 }
 
@@ -370,7 +441,13 @@ int pm_embbag_fwd(const pm_embbag_batch* op, float* out, pm_stream_t stream) {
     p.io = out;
     int unroll = g_unroll.load();
     if (unroll == 0) unroll = kDefaultUnroll;
-    hipError_t h = pm::launch_embbag_fwd(p, op->weight_dtype, op->max_dim, unroll, static_cast<hipStream_t>(stream));
+    int pool_waves = 0, wgs_per_cu = 0;
+    hipError_t h;
+    if (configure_persist(op, p, pool_waves, wgs_per_cu))
+        h = pm::launch_embbag_fwd_persist(p, op->weight_dtype, op->max_dim, unroll == 3 || unroll == 6 ? 2 : unroll, pool_waves, wgs_per_cu,
+                                          static_cast<hipStream_t>(stream));
+    else
+        h = pm::launch_embbag_fwd(p, op->weight_dtype, op->max_dim, unroll, static_cast<hipStream_t>(stream));
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_fwd launch");
     return PM_OK;
 }

@@ -58,6 +58,8 @@ struct KParams {
     int32_t flat_bags;           // forward: > 0 = the flat-walk kernel (short-bag requests): bags per tile derived per table on the
                                  // device, at most this many (= bags_per_block, which sizes the LDS offsets array)
     int32_t flat_target;         // ... lookups per tile aimed at
+    int32_t ps_slots;            // forward: > 0 = the persistent kernel (embbag_fwd_persist.hip) with this many ring slots; bags_per_block is
+                                 // then its tile (a multiple of the bags pooled concurrently), idx_cap the index entries per slot
     float alpha;                 // bwd scale
 };
 
@@ -157,6 +159,10 @@ __host__ __device__ inline size_t tile_lds_bytes(int bags_per_block, int idx_cap
 // ---- host-side launchers implemented in the kernel files ----------------------------------
 hipError_t launch_embbag_fwd(const KParams& p, int weight_dtype, int max_dim, int unroll,
                              hipStream_t stream);
+// persistent forward (embbag_fwd_persist.hip): pool_waves 4 or 7 pooling waves + one helper wave per workgroup
+size_t fwd_persist_lds_bytes(int tile_bags, int idx_cap, bool weighted, int row_floats, int slots);
+hipError_t launch_embbag_fwd_persist(const KParams& p, int weight_dtype, int max_dim, int unroll, int pool_waves, int wgs_per_cu,
+                                     hipStream_t stream);
 hipError_t launch_embbag_fwd_split(const KParams& p, int weight_dtype, int max_dim, hipStream_t stream);
 hipError_t launch_embbag_bwd(const KParams& p, int dst_dtype, int max_dim, hipStream_t stream);
 hipError_t launch_embbag_check(const KParams& p, int32_t* d_err, int vec, int max_dim, int64_t fixed_pooling,

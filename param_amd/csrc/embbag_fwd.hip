@@ -25,74 +25,13 @@
 #include <type_traits>
 
 #include "common.h"
+#include "fwd_elem.h"
 #include "rowquant.inc"
 
 namespace pm {
 namespace {
 
-struct bf16_t { uint16_t v; };
-struct f16_t { uint16_t v; };
-
-#ifndef PM_FWD_STORE
-#define PM_FWD_STORE 0    // how the staged burst is written: 0 nt (streaming), 1 plain, 2 sc1, 3 sc0 sc1, 4 nt sc1, 5 sc0, 6 nt sc0, 7 nt sc0 sc1 (experiment builds)
-#endif
-__device__ __forceinline__ void burst_store(pm::f32x4* q, pm::f32x4 v) {
-#if PM_FWD_STORE == 0
-    __builtin_nontemporal_store(v, q);
-#elif PM_FWD_STORE == 1
-    *q = v;
-#elif PM_FWD_STORE == 2
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(q), "v"(v) : "memory");
-#elif PM_FWD_STORE == 3
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(q), "v"(v) : "memory");
-#elif PM_FWD_STORE == 4
-    asm volatile("global_store_dwordx4 %0, %1, off nt sc1\n\ts_nop 1" : : "v"(q), "v"(v) : "memory");
-#elif PM_FWD_STORE == 5
-    asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 1" : : "v"(q), "v"(v) : "memory");
-#elif PM_FWD_STORE == 6
-    asm volatile("global_store_dwordx4 %0, %1, off nt sc0\n\ts_nop 1" : : "v"(q), "v"(v) : "memory");
-#else
-    asm volatile("global_store_dwordx4 %0, %1, off nt sc0 sc1\n\ts_nop 1" : : "v"(q), "v"(v) : "memory");
-#endif
-}
-#ifndef PM_FWD_EXP
-#define PM_FWD_EXP 0      // experiment builds: 1 = the staged burst is not written (what the output costs), 2 = written onto 32 KB per table (cache-resident)
-#endif
-template <typename WT> struct Elem;
-template <> struct Elem<float> {
-    static constexpr int kVec = 4;
-    __device__ static __forceinline__ void widen(const u32x4& raw, float (&f)[4]) {
-        f[0] = __uint_as_float(raw.x); f[1] = __uint_as_float(raw.y);
-        f[2] = __uint_as_float(raw.z); f[3] = __uint_as_float(raw.w);
-    }
-};
-template <> struct Elem<bf16_t> {
-    static constexpr int kVec = 8;
-    __device__ static __forceinline__ void widen(const u32x4& raw, float (&f)[8]) {
-        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f[2 * i] = __uint_as_float(w[i] << 16);
-            f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
-        }
-    }
-};
-template <> struct Elem<f16_t> {
-    static constexpr int kVec = 8;
-    __device__ static __forceinline__ void widen(const u32x4& raw, float (&f)[8]) {
-        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f[2 * i] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(w[i] & 0xffffu)));
-            f[2 * i + 1] = static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(w[i] >> 16)));
-        }
-    }
-};
-
-__device__ __forceinline__ u32x4 load16(const char* p, bool nt) {
-    const PM_GLOBAL u32x4* q = as_global<u32x4>(p);   // global_load_dwordx4, not flat_load (common.h)
-    return nt ? __builtin_nontemporal_load(q) : *q;
-}
+using namespace fwd;
 
 // Quantised output burst (p.out_bits = 16 / 8 / 4 / 2): the tile's pooled rows leave LDS as row-wise quantised rows
 // (rowquant.hip's formats) -- what the quantised all-to-all sends -- so the fp32 pooled output never reaches HBM.  The
@@ -153,14 +92,6 @@ __device__ __forceinline__ void quantized_burst(const KParams& p, const float* s
         case 4: fused_rows_burst<4>(s_out, nb, D, qout, row0, rows_per_bag); break;
         default: fused_rows_burst<2>(s_out, nb, D, qout, row0, rows_per_bag); break;
     }
-}
-
-// byte offset of row r: staged indices are int32 (rows[t] < 2^31, the caller's contract) and a row is < 2^31 bytes, so the
-// product is ONE 32 x 32 -> 64-bit multiply (v_mad_u64_u32); as int64 x int64 it is a multiply-add, two multiplies and an add
-template <bool ST>
-__device__ __forceinline__ int64_t row_offset(int64_t r, int64_t row_bytes) {
-    if (ST) return static_cast<int64_t>(static_cast<uint64_t>(static_cast<uint32_t>(r)) * static_cast<uint32_t>(row_bytes));
-    return r * row_bytes;
 }
 
 template <typename WT, int G, int UNROLL, bool WEIGHTED, bool ORDERED, bool STAGE>
@@ -327,13 +258,7 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
             const int q = D / 4;                       // 16-byte pieces per row
             auto piece = [&](int bg, int c4) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(s_out + static_cast<size_t>(bg) * D + c4 * 4);
-#if PM_FWD_EXP & 1
-                asm volatile("" : : "v"(v));
-#elif PM_FWD_EXP & 2
-                burst_store(reinterpret_cast<f32x4*>(out_t + ((bag0 + bg) & 63) * p.out_stride + c4 * 4), v);      // every tile onto the table's first 64 rows
-#else
-                burst_store(reinterpret_cast<f32x4*>(out_t + (bag0 + bg) * p.out_stride + c4 * 4), v);
-#endif
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out_t + (bag0 + bg) * p.out_stride + c4 * 4));
             };
             if ((q & (q - 1)) == 0) {                  // piece i is (i >> lg, i & (q - 1)): no integer division per 16 bytes
                 const int lg = 31 - __builtin_clz(static_cast<unsigned>(q));
