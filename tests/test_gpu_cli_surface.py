@@ -1,6 +1,6 @@
-"""GPU tests of the command-line surface added at the end of round 4 -- written without a GPU (the round's budget was spent), so
-they are GATED: they run only with PARAM_AMD_R5_CLI=1 (tools/r5_first_visit.sh sets it) and are skipped in the default ``-m gpu``
-run until a visit has shown them green; then the gate goes.  Each mirrors a CPU test that already passes on gloo ranks."""
+"""GPU tests of the command-line surface added at the end of round 4 (written without a GPU, gated until round 5's first visit
+showed them green on a 1-rank RCCL group: gpurun visit r5_v1, 4 passed; the gate is gone).  Each mirrors a CPU test that passes on
+gloo ranks."""
 import contextlib
 import io
 import json
@@ -8,8 +8,7 @@ import os
 
 import pytest
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("PARAM_AMD_R5_CLI") != "1", reason="not yet run on a GPU: set PARAM_AMD_R5_CLI=1")]
+pytestmark = pytest.mark.gpu
 
 
 def _port():

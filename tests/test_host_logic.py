@@ -576,3 +576,41 @@ def test_batched_module_reports_embedding_specs():
 
     m = param_amd.BatchedEmbeddingBagMI355([1000, 2000], [64, 128], device="cpu", init=None)
     assert [(s[0], s[1]) for s in m.embedding_specs] == [(1000, 64), (2000, 128)] and m.embedding_specs[0][2:] == ("host", "cpu")
+
+
+# ----------------------------------------------------------------------------- bench.py launch contract (round 5)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_gpus_n_without_launcher_launches_itself(tmp_path):
+    """`python bench.py --gpus 4 ...` with WORLD_SIZE unset must not measure one GPU and call it four (round 4 did): it re-executes
+    itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 ...` with its own
+    arguments.  The launcher is replaced by a stub that records the command line."""
+    import subprocess
+    import sys
+
+    stub = tmp_path / "stub.sh"
+    rec = tmp_path / "cmd.txt"
+    stub.write_text(f"#!/bin/bash\nprintf '%s\\n' \"$@\" > {rec}\nexit 7\n")
+    stub.chmod(0o755)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["PARAM_AMD_BENCH_LAUNCHER"] = str(stub)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1", "--tables", "26"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 7, r.stderr[-500:]                      # the launcher's exit code is the bench's
+    cmd = rec.read_text().split("\n")
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:i + 9] == ["--gpus", "4", "--steps", "3", "--warmup", "1", "--tables", "26"]
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """a launcher that started 2 ranks for --gpus 4 (or 1 rank for --gpus 2) is an error before anything is measured"""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in r.stderr
