@@ -183,6 +183,17 @@ int pm_embbag_bwd_sorted(const pm_embbag_batch* op, const float* grad, void* con
                          int32_t dst_dtype, float alpha, int64_t max_rows, const void* workspace,
                          int64_t workspace_bytes, pm_stream_t stream);
 /*
+ * ABI v6.  Sort + apply of one request in ONE call (what a backward step that does not hide the sort under other work
+ * wants): pm_embbag_sort_indices followed by pm_embbag_bwd_sorted / pm_embbag_bwd_sorted_adagrad_ex on `stream`, same
+ * arguments, same results bit for bit.  Because the library itself sequences the two halves, it may DEFER part of the sort
+ * into the apply -- the hybrid backward (pm_set_hybrid_tuning): the sort half then only classifies the tables and builds
+ * their "looked up twice" maps, and the apply half reads the request's indices and offsets again.  A sort issued on its own
+ * (pm_embbag_sort_indices*) never defers: it consumes the request completely, so the caller may reuse the index buffer
+ * once the sort has run, as the sort-aside contract above says.
+ */
+int pm_embbag_bwd_fused(const pm_embbag_batch* op, const float* grad, void* const* dst_tables, int32_t dst_dtype,
+                        float alpha, int64_t max_rows, void* workspace, int64_t workspace_bytes, pm_stream_t stream);
+/*
  * ABI v4, host-only, for tests and tools: where the last pm_embbag_sort_indices* on this workspace left its pairs.
  * *keys / *vals: device pointers into the workspace (keys of *key_bytes bytes: table << *tshift | row; values: bag within
  * the table, or the lookup position for weighted requests); *d_count: device uint32 holding the number of pairs (batch
@@ -253,6 +264,10 @@ int pm_embbag_bwd_sorted_adagrad_ex(const pm_embbag_batch* op, const float* grad
                                     int32_t table_dtype, float* const* momentum, const pm_rowwise_adagrad* opt,
                                     int64_t max_rows, const void* workspace, int64_t workspace_bytes,
                                     pm_stream_t stream);
+/* ABI v6: pm_embbag_sort_indices + pm_embbag_bwd_sorted_adagrad_ex in one call (see pm_embbag_bwd_fused: may take the hybrid path). */
+int pm_embbag_bwd_fused_adagrad(const pm_embbag_batch* op, const float* grad, void* const* tables, int32_t table_dtype,
+                                float* const* momentum, const pm_rowwise_adagrad* opt, int64_t max_rows, void* workspace,
+                                int64_t workspace_bytes, pm_stream_t stream);
 
 /*
  * DLRM input redistribution on the device: regroup what the lengths / indices all-to-alls deliver
@@ -319,9 +334,10 @@ int pm_set_forward_tuning(int32_t stage_out);
  * order's (table, tile) sequence; each workgroup = `pool_waves` (4 or 7) pooling waves that issue row loads and LDS
  * accesses only + ONE helper wave that stages the coming tiles' offsets / indices into a ring of `slots` LDS slots and
  * writes finished tiles' pooled rows to memory -- no workgroup-wide barrier, no store in a pooling wave's memory queue.
- * A tile is (bags pooled concurrently) x `bags_per_group` bags.  mode: 1 = requests of at least 8 tiles per resident
- * workgroup (the default at -1), 0 = never (embbag_fwd_kernel's launch of one workgroup per tile), 2 = every eligible request
- * whatever its size (tests).  0 for the other arguments = default.  Results are bit-identical in every setting.
+ * A tile is (bags pooled concurrently) x `bags_per_group` bags.  mode: 0 = never (the default at -1: embbag_fwd_kernel's
+ * launch of one workgroup per tile -- measured equal under uniform indices and 4-9 % faster under Zipf),
+ * 1 = requests of at least 8 tiles per resident workgroup, 2 = every eligible request whatever its size (tests).  0 for the
+ * other arguments = default.  Results are bit-identical in every setting.
  */
 int pm_set_forward_persist(int32_t mode, int32_t slots, int32_t bags_per_group, int32_t pool_waves, int32_t wgs_per_cu);
 
@@ -379,10 +395,13 @@ int pm_set_sort_tuning(int32_t mode);
  *   lookback_spin_cap  polls before a look-back walk of the key sort stops waiting for a predecessor and counts that tile's digits
  *            itself; 0 = default (2^12).  Tests: 1 = the fallback runs wherever a predecessor is a moment late; 0xFFFFFFFF = it
  *            runs for every predecessor of every tile (nothing published is believed).
- * While the hybrid kernels are launched for a sort, pm_embbag_sort_indices* runs only the classification and the bitmaps; the
- * rest of the sort (of the flagged lookups, and of every lookup of the tables that did not qualify) runs inside the apply
- * call, behind the bag-major kernel, which lists the flagged lookups as a by-product.  pm_embbag_sorted_pairs is then
- * meaningful only after an apply (tests that inspect the sorted pairs of a bare sort switch the hybrid path off).
+ * The path is offered by the FUSED entry points only (pm_embbag_bwd_fused*, ABI v6): its sort half runs the classification and
+ * the bitmaps, the rest of the sort (of the flagged lookups, and of every lookup of the tables that did not qualify) runs in the
+ * apply half, behind the bag-major kernel, which lists the flagged lookups as a by-product -- and reads the request's indices
+ * again.  pm_embbag_sort_indices* on their own always sort completely (round 4 deferred there too: a caller that refilled its
+ * index buffer between a side-stream sort and the apply would have had stale dup maps applied to new indices).
+ * pm_embbag_sorted_pairs after a fused call shows the pairs that went through the sort; between a deferred sort and its apply
+ * (which only the library can be) it returns PM_ERR_INVALID.
  */
 int pm_set_hybrid_tuning(int32_t enable, int64_t lookback_spin_cap);
 

@@ -41,6 +41,8 @@ EXPORTED_SYMBOLS = (
     "pm_embbag_bwd_sorted",
     "pm_embbag_bwd_sorted_adagrad",
     "pm_embbag_bwd_sorted_adagrad_ex",
+    "pm_embbag_bwd_fused",
+    "pm_embbag_bwd_fused_adagrad",
     "pm_dlrm_regroup",
     "pm_embbag_check",
     "pm_fill_random",
@@ -171,6 +173,11 @@ def load() -> ctypes.CDLL:
         L.pm_embbag_bwd_sorted_adagrad_ex.restype = ctypes.c_int
         L.pm_embbag_bwd_sorted_adagrad_ex.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, vp,
                                                       ctypes.POINTER(pm_rowwise_adagrad), i64, vp, i64, vp]
+        L.pm_embbag_bwd_fused.restype = ctypes.c_int
+        L.pm_embbag_bwd_fused.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, ctypes.c_float, i64, vp, i64, vp]
+        L.pm_embbag_bwd_fused_adagrad.restype = ctypes.c_int
+        L.pm_embbag_bwd_fused_adagrad.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, vp,
+                                                  ctypes.POINTER(pm_rowwise_adagrad), i64, vp, i64, vp]
         L.pm_dlrm_regroup.restype = ctypes.c_int
         L.pm_dlrm_regroup.argtypes = [vp, vp, i32, i32, i64, vp, vp, vp, vp]
         L.pm_embbag_check.restype = ctypes.c_int
@@ -220,7 +227,7 @@ def set_forward_tuning(stage_out: int = -1) -> None:
 
 def set_forward_persist(mode: int = -1, slots: int = 0, bags_per_group: int = 0, pool_waves: int = 0, wgs_per_cu: int = 0) -> None:
     """``pm_set_forward_persist``: the persistent forward (pooling waves + one helper wave per workgroup, looping over tiles):
-    mode 1 large requests (default) / 0 never / 2 every eligible request; 0 elsewhere = default.  Same bits in every setting."""
+    mode 0 never (default) / 1 large requests / 2 every eligible request; 0 elsewhere = default.  Same bits in every setting."""
     check(load().pm_set_forward_persist(mode, slots, bags_per_group, pool_waves, wgs_per_cu))
 
 

@@ -20,15 +20,19 @@ std::atomic<int> g_bags_per_block{0};
 std::atomic<int> g_xcd_affine{-1};
 std::atomic<int> g_nt_loads{-1};
 std::atomic<int> g_stage_out{-1};
-// persistent forward (embbag_fwd_persist.hip; pm_set_forward_persist): mode -1 / 1 = for requests large enough to keep every
-// workgroup busy for several tiles, 0 = never, 2 = whenever the request is eligible (tests); the rest 0 = default
+// persistent forward (embbag_fwd_persist.hip; pm_set_forward_persist): mode 1 = for requests large enough to keep every
+// workgroup busy for several tiles, 0 (and -1, the default) = never, 2 = whenever the request is eligible (tests); the rest 0 = default.
+// OFF by default: measured on two boxes (profiles/r05_fwd_persist_*.jsonl), bit-identical and, at its best geometry (16-bag tiles, 4
+// workgroups per CU), within 1 % of embbag_fwd_kernel under uniform indices (746-752 vs 745-746 us) and 4-9 % behind it under Zipf
+// (371-388 vs 355 us): the launch is bound by the memory system (uniform: the fabric's random-row rate; Zipf: 6.3 TB/s through the
+// fabric at a 48 % L2 hit rate), not by the workgroup's barrier / burst / relaunch sequence the persistent form removes.
 std::atomic<int> g_ps_mode{-1};
 std::atomic<int> g_ps_slots{0};
 std::atomic<int> g_ps_bags_per_group{0};
 std::atomic<int> g_ps_pool_waves{0};
 std::atomic<int> g_ps_wgs_per_cu{0};
 constexpr int kPsDefaultSlots = 3;
-constexpr int kPsDefaultBagsPerGroup = 1;
+constexpr int kPsDefaultBagsPerGroup = 2;
 constexpr int kPsDefaultPoolWaves = 4;
 
 // destination-row cache policy of the sorted backward when pm_set_tuning leaves nt_loads at its default: plain loads,
@@ -44,6 +48,33 @@ int fail(int code, const std::string& msg) {
 
 int hip_fail(hipError_t rc, const char* what) {
     return fail(PM_ERR_HIP, std::string(what) + ": " + hipGetErrorString(rc));
+}
+
+// The forward's environment switches (kernel sweeps; every one has a pm_set_* or a default that the product uses): read ONCE
+// per process, on the first forward -- not on the launch path (getenv is not thread-safe against setenv, and a value that
+// changes between two calls of one request's sequence is a hazard, not a feature).
+struct FwdEnv {
+    int stage;        // PARAM_AMD_FWD_STAGE=0: no LDS-staged output burst
+    int flat;         // PARAM_AMD_FWD_FLAT=0: no flat-walk kernel; 2: also for pooling factors up to 4
+    int flat_maxl;    // PARAM_AMD_FLAT_MAXL
+    int flat_target;  // PARAM_AMD_FLAT_TARGET (lookups per flat-walk tile)
+    int flat_bags;    // PARAM_AMD_FLAT_BAGS (bags per flat-walk tile at most)
+    int tile_major;   // PARAM_AMD_FWD_TILE_MAJOR=1
+};
+const FwdEnv& fwd_env() {
+    static const FwdEnv e = [] {
+        auto num = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
+        FwdEnv r;
+        const char* st = getenv("PARAM_AMD_FWD_STAGE");
+        r.stage = (st && st[0] == '0') ? 0 : 1;
+        r.flat = num("PARAM_AMD_FWD_FLAT", 1);
+        r.flat_maxl = num("PARAM_AMD_FLAT_MAXL", 0);
+        r.flat_target = num("PARAM_AMD_FLAT_TARGET", 256);
+        r.flat_bags = num("PARAM_AMD_FLAT_BAGS", 32);
+        r.tile_major = num("PARAM_AMD_FWD_TILE_MAJOR", -1);
+        return r;
+    }();
+    return e;
 }
 
 bool dtype_is_weight(int d) { return d == PM_F32 || d == PM_BF16 || d == PM_F16; }
@@ -155,11 +186,9 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
     p.flat_target = 0;
     p.ps_slots = 0;
     if (forward) {
+        const FwdEnv& env = fwd_env();
         int want = g_stage_out.load();
-        if (want < 0) {
-            const char* e = getenv("PARAM_AMD_FWD_STAGE");
-            want = (e && e[0] == '0') ? 0 : 1;
-        }
+        if (want < 0) want = env.stage;
         const bool even = total_bags > 0 && op->num_indices % total_bags == 0;
         if (want && even && !p.ordered && g_bags_per_block.load() <= 0) {
             while (bpb > NG && static_cast<int64_t>(bpb) * op->max_dim * 4 > 16384) bpb /= 2;
@@ -192,18 +221,18 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
         // r3_criteo_flat (Zipf G lookups/s / uniform fraction; run-to-run +-1.5 %): 8-bag tiles 15.7-15.9 / 0.69-0.71; flat walk
         // target 512 cap 64: 16.4-16.5 / 0.705-0.716; **256 / 32: 16.6 / 0.719**; 128: 16.1 / 0.695; 1024 / 128: 14.1 / 0.64.
         // PARAM_AMD_FWD_FLAT=0 turns it off (PARAM_AMD_FLAT_TARGET / _BAGS: sweeps).
-        const int flat_env = [] { const char* e = getenv("PARAM_AMD_FWD_FLAT"); return e ? atoi(e) : 1; }();       // read per call: sweeps set it between requests
+        const int flat_env = env.flat;
         const bool flat_on = flat_env != 0;
         // ... and so do fixed-pooling requests of one or two lookups per bag (one-hot tables): bag by bag a lane group has one or
         // two row loads in flight.  48 x 10 M x 128 fp32, batch 65536 (tools/r3_shortbags.sh; Zipf G lookups/s / uniform fraction):
         // pooling 1: 4.00 / 0.529 -> 5.05 / 0.624; pooling 2: 7.78 / 0.687 -> 8.75 / 0.686; pooling 4: 13.5 / 0.723 -> 13.4 / 0.679
         // (not taken; PARAM_AMD_FWD_FLAT=2 extends the rule to 4 for that measurement).
-        const int flat_maxl = [] { const char* e = getenv("PARAM_AMD_FLAT_MAXL"); return e ? atoi(e) : 0; }();   // experiments
+        const int flat_maxl = env.flat_maxl;
         if (flat_on && even && avg_l <= (flat_maxl > 0 ? flat_maxl : flat_env == 2 ? 4 : 2) && !p.ordered && g_bags_per_block.load() <= 0 &&
             p.stage_out > 0) {
             const int64_t tiles_ng = (op->bag_count + NG - 1) / NG;
             if (tiles_ng * op->num_tables <= 0x7fffffffLL) {
-                const int tgt2 = [] { const char* e = getenv("PARAM_AMD_FLAT_TARGET"); return e ? atoi(e) : 256; }();
+                const int tgt2 = env.flat_target;
                 p.flat_bags = 32;
                 p.flat_target = tgt2;
                 p.tiles_per_table = static_cast<int32_t>(tiles_ng);
@@ -213,8 +242,8 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
             }
         }
         if (flat_on && !even && !p.ordered && g_bags_per_block.load() <= 0 && bpb == NG && p.stage_out > 0) {
-            const int cap_env = [] { const char* e = getenv("PARAM_AMD_FLAT_BAGS"); return e ? atoi(e) : 32; }();
-            const int tgt_env = [] { const char* e = getenv("PARAM_AMD_FLAT_TARGET"); return e ? atoi(e) : 256; }();
+            const int cap_env = env.flat_bags;
+            const int tgt_env = env.flat_target;
             p.flat_bags = cap_env < NG ? NG : (cap_env > 1024 ? 1024 : cap_env / NG * NG);
             p.flat_target = tgt_env < 1 ? 1 : tgt_env;
             p.bags_per_block = p.flat_bags;   // sizes the LDS offsets array; stage_bags (the burst buffer) stays at NG rows
@@ -229,7 +258,7 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
         //  * tile-major block order (t = b % T, so every table advances at the same rate and the heavy table's long workgroups
         //    start throughout the launch): 165 against 120 us under Zipf, 220 against 186 us uniform -- a table's tiles then run
         //    on all eight XCDs at once and on every CU next to other tables' rows.  Kept behind PARAM_AMD_FWD_TILE_MAJOR=1.
-        const int tm_env = [] { const char* e = getenv("PARAM_AMD_FWD_TILE_MAJOR"); return e ? atoi(e) : -1; }();
+        const int tm_env = env.tile_major;
         const bool uneven = total_bags > 0 && op->num_indices % total_bags != 0;
         if (p.xcd_affine != 1 && op->num_tables > 1 && tm_env > 0 && uneven) p.xcd_affine = 2;
     }
@@ -241,7 +270,7 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
 // lane group, one index slot sized for twice the tile's average lookups).  Returns false to keep the classic launch.
 bool configure_persist(const pm_embbag_batch* op, pm::KParams& p, int& pool_waves, int& wgs_per_cu) {
     const int mode = g_ps_mode.load();
-    if (mode == 0) return false;
+    if (mode <= 0) return false;
     if (!(p.stage_out > 0 && !p.ordered && p.flat_bags == 0 && p.out_bits == 0)) return false;
     const int vec = (op->weight_dtype == PM_F32) ? 4 : 8;
     const int G = pm::group_lanes(op->max_dim, vec);
@@ -527,8 +556,8 @@ int pm_embbag_sort_indices(const pm_embbag_batch* op, int64_t max_rows, void* wo
     return pm_embbag_sort_indices_ex(op, max_rows, 1, workspace, workspace_bytes, stream);
 }
 
-int pm_embbag_sort_indices_ex(const pm_embbag_batch* op, int64_t max_rows, int32_t phases, void* workspace,
-                              int64_t workspace_bytes, pm_stream_t stream) {
+static int sort_request(const pm_embbag_batch* op, int64_t max_rows, int32_t phases, void* workspace, int64_t workspace_bytes,
+                        pm_stream_t stream, bool defer_ok) {
     if (phases != 1 && phases != 2) return fail(PM_ERR_INVALID, "phases must be 1 or 2");
     pm::KParams p;
     int rc = make_params(op, op ? op->weight_dtype : -1, p);
@@ -540,9 +569,31 @@ int pm_embbag_sort_indices_ex(const pm_embbag_batch* op, int64_t max_rows, int32
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_sort_indices");
     if (!workspace || workspace_bytes < static_cast<int64_t>(need))
         return fail(PM_ERR_INVALID, "workspace too small: need " + std::to_string(need) + " bytes");
-    h = pm::sort_indices(p, max_rows, op->max_dim, op->fixed_pooling, phases, workspace, static_cast<hipStream_t>(stream));
+    h = pm::sort_indices(p, max_rows, op->max_dim, op->fixed_pooling, phases, workspace, static_cast<hipStream_t>(stream), defer_ok);
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_sort_indices");
     return PM_OK;
+}
+
+int pm_embbag_sort_indices_ex(const pm_embbag_batch* op, int64_t max_rows, int32_t phases, void* workspace,
+                              int64_t workspace_bytes, pm_stream_t stream) {
+    return sort_request(op, max_rows, phases, workspace, workspace_bytes, stream, false);
+}
+
+int pm_embbag_bwd_fused(const pm_embbag_batch* op, const float* grad, void* const* dst_tables, int32_t dst_dtype, float alpha,
+                        int64_t max_rows, void* workspace, int64_t workspace_bytes, pm_stream_t stream) {
+    if (op && (op->num_indices == 0 || op->bag_count == 0)) return PM_OK;
+    int rc = sort_request(op, max_rows, 1, workspace, workspace_bytes, stream, true);
+    if (rc != PM_OK) return rc;
+    return pm_embbag_bwd_sorted(op, grad, dst_tables, dst_dtype, alpha, max_rows, workspace, workspace_bytes, stream);
+}
+
+int pm_embbag_bwd_fused_adagrad(const pm_embbag_batch* op, const float* grad, void* const* tables, int32_t table_dtype,
+                                float* const* momentum, const pm_rowwise_adagrad* opt, int64_t max_rows, void* workspace,
+                                int64_t workspace_bytes, pm_stream_t stream) {
+    if (op && (op->num_indices == 0 || op->bag_count == 0)) return PM_OK;
+    int rc = sort_request(op, max_rows, 1, workspace, workspace_bytes, stream, true);
+    if (rc != PM_OK) return rc;
+    return pm_embbag_bwd_sorted_adagrad_ex(op, grad, tables, table_dtype, momentum, opt, max_rows, workspace, workspace_bytes, stream);
 }
 
 int pm_embbag_sort_plan(const pm_embbag_batch* op, int64_t max_rows, int32_t phases, char* out, int32_t out_bytes) {
@@ -565,8 +616,11 @@ int pm_embbag_sorted_pairs(const pm_embbag_batch* op, int64_t max_rows, const vo
     if ((rc = sorted_args_ok(op, max_rows)) != PM_OK) return rc;
     if (!workspace || !keys || !vals || !d_count || !key_bytes || !tshift) return fail(PM_ERR_INVALID, "NULL argument");
     int kb = 0, ts = 0;
-    if (pm::sorted_pairs_info(p, max_rows, op->max_dim, workspace, keys, vals, d_count, &kb, &ts) != 0)
-        return fail(PM_ERR_INVALID, "no sort has been recorded for this workspace");
+    const int pi = pm::sorted_pairs_info(p, max_rows, op->max_dim, workspace, keys, vals, d_count, &kb, &ts);
+    if (pi == 2)
+        return fail(PM_ERR_INVALID, "the last sort on this workspace was deferred into its apply (pm_embbag_bwd_fused*, hybrid backward) and no "
+                                    "apply has been issued yet: there are no sorted pairs to look at");
+    if (pi != 0) return fail(PM_ERR_INVALID, "no sort has been recorded for this workspace");
     *key_bytes = kb;
     *tshift = ts;
     return PM_OK;

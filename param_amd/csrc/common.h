@@ -172,8 +172,11 @@ hipError_t launch_fill_random(void* dst, int64_t count, int dtype, int dist, flo
 
 // sort-based deterministic backward (embbag_bwd_sorted.hip)
 hipError_t sorted_workspace_bytes(const KParams& p, int64_t max_rows, int max_dim, size_t& bytes);
+// defer_ok: the caller issues the apply of this very request right behind the sort (the fused entry points): only then may the
+// sort stop after its first part (segments, verdicts, dup maps) and leave the rest to the apply call (hybrid backward), which
+// reads the request's indices again.  A sort issued on its own always consumes the request completely.
 hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, int64_t fixed_pooling, int phases, void* workspace,
-                        hipStream_t stream);
+                        hipStream_t stream, bool defer_ok = false);
 int bwd_sorted_plan_check(const KParams& p, int64_t max_rows, const void* workspace, bool adagrad);
 int sorted_pairs_info(const KParams& p, int64_t max_rows, int max_dim, const void* workspace, const void** keys, const uint32_t** vals,
                       const uint32_t** d_count, int* key_bytes, int* tshift);
@@ -214,6 +217,10 @@ constexpr int kBloomWords = (1 << 16) / kBloomK;   // 32-bit words per slice (4 
 constexpr int kBloomTableWords = kBloomK * kBloomWords;   // 65 536 words = 256 KB per table
 constexpr uint32_t kHybMaxCount = 1u << 18;     // lookups per table beyond which a 2^21-bit map flags too many unique rows
 constexpr uint32_t kHybMinCount = 8192;         // ... and below which a table is not worth three extra kernels
+constexpr int kUniqueBags = 128;                // bags per tile of the bag-major apply: ONE value for the sort-time guard, the apply's launch and
+                                                // the compaction of its per-tile lists (no knob: the three must agree)
+constexpr int kCompactMaxTiles = 4096;          // bag-major tiles per table the compaction scans (sort-time guard: bags <= 128 x 4096)
+bool seg_sort_hybrid_available();               // the mark kernel's 128 KB of dynamic LDS can be had on this device (probed once)
 struct HybTable {            // one per table (device): written by the sort's first kernel and by the compaction
     uint32_t mode;           // 0: every lookup through the sort; 1: hybrid.  Final verdict, written by hyb_mark_kernel's first workgroup
     uint32_t pooling;        // the table's pooling factor (hybrid tables have one)

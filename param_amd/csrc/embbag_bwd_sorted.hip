@@ -115,7 +115,9 @@ struct SortWs {
 // 1024: 1.496 / 0.815, 394 / 481.  Smaller tiles balance the tail of a launch better; larger ones cut a long run (a Zipf head,
 // a 3-row table) into fewer pieces for the fix-up kernel.  PARAM_AMD_BWD_TILE overrides (256 / 512 / 1024).
 inline int apply_tile(int64_t n) {
-    const int env = [] { const char* e = getenv("PARAM_AMD_BWD_TILE"); return e ? atoi(e) : 0; }();     // per call (it also sizes the workspace: max_chunks)
+    // read ONCE per process: the value also sizes the workspace (max_chunks), so the workspace query, the sort and the apply of a
+    // request must see the same one
+    static const int env = [] { const char* e = getenv("PARAM_AMD_BWD_TILE"); return e ? atoi(e) : 0; }();
     if (env == 256 || env == 512 || env == 1024) return env;
     return n < (static_cast<int64_t>(3) << 18) ? 256 : 512;
 }
@@ -253,6 +255,7 @@ struct SortPlan {
     int mode;            // seg_sort mode (0 / 3 LSD passes, 1 / 2 partition + bucket-local sort)
     int hyb;             // hybrid backward: 0 not launched for this sort, else the `allow` value its kernels ran with (part B of the
                          // sort then runs inside the apply call, after the bag-major kernel)
+    bool applied;        // an apply has been issued for this sort (a deferred sort's pairs exist only then)
     // what the sort was issued for: the apply must follow with the same request on the same workspace
     const void* indices;
     const void* offsets;
@@ -277,6 +280,7 @@ SortPlan make_plan(const KParams& p, int64_t max_rows, int64_t fixed_pooling, in
     g.v2 = sort_impl_knob() == 0 && p.T <= kSegSortMaxTables;
     g.mode = sort_mode_knob();
     g.hyb = 0;
+    g.applied = false;
     if (g.v2) {
         // one plan for every request: the device establishes segments, per-table pooling and (for slices) the pair count
         g.H = 1;
@@ -412,7 +416,7 @@ hipError_t sorted_workspace_bytes(const KParams& p, int64_t max_rows, int max_di
 }
 
 hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, int64_t fixed_pooling, int phases, void* workspace,
-                        hipStream_t stream) {
+                        hipStream_t stream, bool defer_ok) {
     SortPlan g = make_plan(p, max_rows, fixed_pooling, phases);
     SortWs ws;
     hipError_t rc = ws_layout(workspace, p.N, p.T, ws_key_bytes(p, max_rows), ws_kbits_sort(p, max_rows), g.weighted, max_dim, ws);
@@ -431,7 +435,12 @@ hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, int64_t
         const int en = hyb_enable_knob();
         const int64_t tb = static_cast<int64_t>(p.T) * p.B;
         const bool even_req = tb > 0 && p.N % tb == 0;
-        if (g.v2 && en > 0 && !g.weighted && p.N >= static_cast<int64_t>(kHybMinCount) && p.tiles_per_table <= 2048 && (even_req || en >= 2))
+        // ... and only to a sort whose apply follows in the same library call (defer_ok: pm_embbag_bwd_fused*): the hybrid apply reads
+        // the request's indices and offsets AGAIN (bag-major kernel, compaction), so a sort issued on its own -- possibly on a side
+        // stream, with the caller free to refill the index buffer before the apply -- consumes the request completely, as before round 4.
+        const int64_t uniq_tiles = (p.bag_count + kUniqueBags - 1) / kUniqueBags;     // the bag-major apply's tiles per table
+        if (defer_ok && g.v2 && en > 0 && !g.weighted && p.N >= static_cast<int64_t>(kHybMinCount) && uniq_tiles >= 1 &&
+            uniq_tiles <= kCompactMaxTiles && (even_req || en >= 2) && seg_sort_hybrid_available())
             g.hyb = en >= 2 ? 2 : 1;
         std::lock_guard<std::mutex> lock(g_plan_mutex);
         // bound the record table: the OLDEST record goes (a clear() would also drop plans of workspaces that are sorted
@@ -499,6 +508,7 @@ int sorted_pairs_info(const KParams& p, int64_t max_rows, int max_dim, const voi
         if (it == g_plans.end()) return 1;
         g = it->second;
     }
+    if (g.hyb && !g.applied) return 2;      // a deferred sort: the pairs exist once the apply has run
     SortWs ws;
     if (ws_layout(const_cast<void*>(workspace), p.N, p.T, ws_key_bytes(p, max_rows), ws_kbits_sort(p, max_rows), g.weighted, max_dim, ws) !=
         hipSuccess)
@@ -519,6 +529,7 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
         auto it = g_plans.find(workspace);
         if (it == g_plans.end()) return hipErrorInvalidValue;
         g = it->second;
+        it->second.applied = true;
     }
     SortWs ws;
     hipError_t rc = ws_layout(const_cast<void*>(workspace), p.N, p.T, ws_key_bytes(p, max_rows), ws_kbits_sort(p, max_rows), g.weighted,
@@ -561,10 +572,7 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
     sp.xcd = g.xcd ? (g.v2 ? 2 : 1) : 0;
     sp.d_n = g.v2 ? seg_sort_count(ws.temp, static_cast<size_t>(p.N), p.T) : nullptr;
     sp.tile = g.v2 ? apply_tile(p.N) : kSortTile;      // round 2's plans (segments per table, phases) are laid out for 1024
-    {
-        static const int wgs = env_int("PARAM_AMD_UNIQUE_WGS_PER_CU", 0);      // experiments: the bag-major kernel as a looping grid
-        sp.unique_wgs_per_cu = wgs;
-    }
+    sp.unique_wgs_per_cu = 0;      // (the bag-major kernel as a looping grid: measured slower, HISTORY r4; one workgroup per tile)
     if (sp.n == 0) return hipSuccess;
     // (Hybrid sorts leave a few per cent of the lookups to this apply.  Measured on what is left of the uniform benchmark request
     // (225 K pairs): 66 us with 256-position tiles, 60 us with 512 -- the same ~5 G pairs/s as at full size, not a latency chain;
@@ -595,15 +603,14 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
     // per pair): 32 bags 1.622 / --, 64: 1.597 / 1.287, 128: 1.555 / 1.184 (on the box where 64 read 1.617), 256 (8192-entry index
     // tile): 1.676 / 1.232.  A hybrid table's tile of 128 bags is at most 128 x 32 lookups (kHybMaxCount / bags): the 4096-entry
     // LDS index tile; longer tiles take the unstaged path.  Row loads in flight per lane group: 4 (2: same / -1 %, 8: -2.5 / -4 %).
+    // The tile is kUniqueBags for every request and element type: the sort's guard (sort_indices), this launch and the compaction
+    // of its per-tile lists derive their geometry from that one constant and the request's bag count -- nothing a knob or the
+    // environment can make disagree between the two calls.
     KParams q = p;
-    {
-        const int ub = env_int("PARAM_AMD_UNIQUE_BAGS", 128);      // experiments: bags per tile of the bag-major kernel
-        if (q.bags_per_block < ub || (getenv("PARAM_AMD_UNIQUE_BAGS") && q.bags_per_block != ub)) {
-            q.bags_per_block = ub;
-            q.tiles_per_table = static_cast<int32_t>((q.bag_count + ub - 1) / ub);
-            q.idx_cap = ub > 128 ? 8192 : 4096;
-        }
-    }
+    q.bags_per_block = kUniqueBags;
+    q.tiles_per_table = static_cast<int32_t>((q.bag_count + kUniqueBags - 1) / kUniqueBags);
+    q.idx_cap = 4096;
+    if (q.tiles_per_table < 1 || q.tiles_per_table > kCompactMaxTiles) return hipErrorInvalidValue;   // (before any table is touched; the sort refused such requests)
     switch (dst_dtype) {
         case PM_F32: rc = bwd_unique_launch_f32(sp, q, ua, max_dim, stream); break;
         case PM_BF16: rc = bwd_unique_launch_bf16(sp, q, ua, max_dim, stream); break;

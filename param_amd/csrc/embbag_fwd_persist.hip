@@ -297,10 +297,8 @@ template <typename WT, int G>
 hipError_t launch_u(const KParams& p, int unroll, int pool_waves, int wgs_per_cu, hipStream_t stream) {
 #define PM_PS(U_) (pool_waves == 7 ? launch_n<WT, G, U_, 7>(p, wgs_per_cu, stream) : launch_n<WT, G, U_, 4>(p, wgs_per_cu, stream))
     switch (unroll) {
-        case 1: return PM_PS(1);
-        case 2: return PM_PS(2);
-        case 4: return PM_PS(4);
-        default: return PM_PS(8);
+        case 1: case 2: return PM_PS(2);
+        default: return PM_PS(4);
     }
 #undef PM_PS
 }

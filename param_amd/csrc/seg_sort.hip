@@ -56,9 +56,6 @@ constexpr uint32_t kWaveCap = 1024;     // bucket-local sort by one wave: 16 pai
 constexpr uint32_t kLocalCap = kTile;   // ... by one workgroup; larger buckets go to the second level
 constexpr int kL2Grid = 512;            // persistent grid of the second-level passes
 constexpr int kBuildBags = 1024;        // bags per workgroup of the key-building kernel
-#ifndef PM_LB_EXP
-#define PM_LB_EXP 0    // experiment builds (tools/r4_sort_probe.py: the sort alone, results not applied): 1 no ranking, 2 no walk, 4 no stores, 8 no loads
-#endif
 constexpr int kMaxLbPasses = 5;         // passes the look-back form of mode 0 takes at most
 
 struct SegHeader {
@@ -582,11 +579,7 @@ __device__ __forceinline__ void tile_count_digits(const K (&key)[ITEMS], uint32_
             const bool valid = off < chunk && wave * chunk + off < cnt;
             const uint32_t d = static_cast<uint32_t>(key[r] >> shift) & mask;
             uint32_t below, total;
-#if PM_LB_EXP & 1
-            below = 0; total = 1;
-#else
             match_digit<RB>(d, valid, below, total);
-#endif
             const uint32_t base = valid ? wcnt[d] : 0u;
             rank[r] = base + below;
             // the lowest lane of each match set advances the digit's counter; a wave executes its LDS operations in program
@@ -1023,12 +1016,7 @@ __global__ void __launch_bounds__(kT) seg_lookback_pass_kernel(const TileDesc* t
     const bool from_idx = src.first && td.pooling > 0;    // keys formed from the index array, bag = position / pooling
     K key[kTileItems];
     uint32_t val[kTileItems];
-#if PM_LB_EXP & 8
-#pragma unroll
-    for (int r = 0; r < kTileItems; ++r) { key[r] = static_cast<K>((threadIdx.x * 2654435761u + r * 40503u + g) & 0xffffffu); val[r] = r; }
-#else
     load_tile_pairs<K>(td, src, base, from_idx, key, val);
-#endif
     uint32_t rank[kTileItems];
     tile_count_digits<K, kTileItems, RB>(key, rank, cnt, chunk, shift, mask, s_wcnt);
     tile_digit_starts<RB>(s_wcnt, s_dstart, s_tmp, s_gbase);                  // s_gbase: the tile's count of every digit, for now
@@ -1042,11 +1030,7 @@ __global__ void __launch_bounds__(kT) seg_lookback_pass_kernel(const TileDesc* t
     if (wave < LW) {
         u32x4 ex = {0u, 0u, 0u, 0u};
         u32x4 open = {~0u, ~0u, ~0u, ~0u};                                    // digits still walking: all-ones
-#if PM_LB_EXP & 2
-        bool walking = false;
-#else
         bool walking = j > 0;
-#endif
         uint32_t k = j;                                                       // next predecessor: table tile k - 1
         while (walking) {
             // kLbBatch predecessors per trip, their rows requested together (short of predecessors, the table's first tile is
@@ -1109,18 +1093,9 @@ __global__ void __launch_bounds__(kT) seg_lookback_pass_kernel(const TileDesc* t
         if (q < cnt) {
             const K kk = s_key[q];
             const uint32_t dg = static_cast<uint32_t>(kk >> shift) & mask;
-#if PM_LB_EXP
-            uint64_t o = static_cast<uint64_t>(s_gbase[dg]) + (q - s_dstart[dg]);
-            if (o >= hdr->n_total) o = q;           // experiment builds only: wrong ranks / prefixes must not leave the arrays
-#else
             const uint64_t o = static_cast<uint64_t>(s_gbase[dg]) + (q - s_dstart[dg]);
-#endif
-#if !(PM_LB_EXP & 4)
             kout[o] = kk;
             vout[o] = s_val[q];
-#else
-            asm volatile("" : : "v"(o), "v"(kk));
-#endif
         }
     }
 }
@@ -1481,6 +1456,14 @@ void launch_level1_pass(const Scratch& s, unsigned tm, int T, const PassSrc<K>& 
 }
 }  // namespace
 
+// The mark kernel needs 128 KB of dynamic LDS: asked for once per process; where it cannot be had (another ARCH, a smaller
+// carve-out) the hybrid path is simply not offered -- the sort then runs complete, as for any other request.
+bool seg_sort_hybrid_available() {
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(hyb_mark_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               2 * kBloomWords * 4) == hipSuccess;
+    return ok;
+}
+
 // part A: the tables' segments, pooling factors and verdicts; the dup bitmaps of the hybrid tables
 template <typename K>
 hipError_t seg_sort_part_a(const SegSortRequest& rq, void* scratch, hipStream_t stream) {
@@ -1493,9 +1476,7 @@ hipError_t seg_sort_part_a(const SegSortRequest& rq, void* scratch, hipStream_t 
     hipLaunchKernelGGL(seg_prep_tables_kernel, dim3(rq.T), dim3(1024), 0, stream, rq.indices, rq.offsets, rq.idx64, rq.rows, rq.T, rq.B, rq.N,
                        rq.bag_begin, rq.bag_count, rq.weighted ? 1 : 0, s.desc, rq.zero4, hyb, s.hyb_tab);
     if (hyb.allow) {
-        static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(hyb_mark_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       2 * kBloomWords * 4) == hipSuccess;
-        if (!lds_ok) return hipErrorInvalidValue;
+        if (!seg_sort_hybrid_available()) return hipErrorInvalidValue;      // (sort_indices asks first and does not offer the path then)
         const int th = rq.T < kHybMaxTables ? rq.T : kHybMaxTables;
         const unsigned grid = static_cast<unsigned>(kXcds * kBloomK * ((th + kXcds - 1) / kXcds));
         hipLaunchKernelGGL(hyb_mark_kernel, dim3(grid), dim3(kMarkThreads), 2 * kBloomWords * 4, stream, s.desc, s.hyb_tab, rq.indices, rq.idx64, th,

@@ -237,7 +237,10 @@ def _workspace(ts: _TableSet, op) -> torch.Tensor:
 def _sort_indices(ts: _TableSet, indices, offsets, B, psw=None, bag_begin=0, bag_count=None, phases: int = 2,
                   pooling: Optional[int] = None) -> None:
     """Step 1+2 of the deterministic backward (keys + stable radix sort): needs only the request,
-    so it can be issued early / on another stream; ``_bwd(..., presorted=True)`` consumes it.  ``phases=2`` (scatter-add /
+    so it can be issued early / on another stream; ``_bwd(..., presorted=True)`` consumes it.  A sort issued on its own is
+    always COMPLETE (the request's index buffer may be reused once it has run); the hybrid backward, which defers part of the
+    sort into the apply and reads the indices again there, is taken by the fused calls only (``_bwd`` / ``_adagrad`` without
+    ``presorted``).  ``phases=2`` (scatter-add /
     SGD apply) lets the apply run in two bag phases where the request allows; the fused row-wise Adagrad needs ``phases=1``."""
     op = ts.request(indices, offsets, B, psw, bag_begin, bag_count)
     op.fixed_pooling = ts.fixed_pooling(indices, offsets, B, pooling) if _lib.needs_pooling_hint() else 0
@@ -306,8 +309,14 @@ def _bwd(ts: _TableSet, grad, indices, offsets, B, dst_ptrs_dev, dst_dtype, alph
     if method != "sorted":
         raise ValueError('method must be "sorted" or "atomic"')
     ws = _workspace(ts, op)
-    if not presorted:
-        op.fixed_pooling = ts.fixed_pooling(indices, offsets, B, pooling) if _lib.needs_pooling_hint() else 0
+    if not presorted and not _lib.needs_pooling_hint():
+        # sort + apply sequenced by the library itself: the one form in which it may defer part of the sort into the apply
+        # (hybrid backward: rows looked up once skip the sort)
+        _lib.check(L.pm_embbag_bwd_fused(ctypes.byref(op), grad.data_ptr(), dst_ptrs_dev.data_ptr(), _WDTYPE[dst_dtype],
+                                         float(alpha), max(ts.rows), ws.data_ptr(), ws.numel(), _stream_ptr()))
+        return
+    if not presorted:      # the alternative key sorts (sort_impl 1 / 2) read a pooling hint and may lay out two bag phases
+        op.fixed_pooling = ts.fixed_pooling(indices, offsets, B, pooling)
         _lib.check(L.pm_embbag_sort_indices_ex(ctypes.byref(op), max(ts.rows), 2, ws.data_ptr(), ws.numel(), _stream_ptr()))
     _lib.check(L.pm_embbag_bwd_sorted(ctypes.byref(op), grad.data_ptr(), dst_ptrs_dev.data_ptr(), _WDTYPE[dst_dtype],
                                       float(alpha), max(ts.rows), ws.data_ptr(), ws.numel(), _stream_ptr()))
@@ -342,11 +351,16 @@ def _adagrad(ts: _TableSet, grad, indices, offsets, B, mom_ptrs_dev, lr: float, 
     op = ts.request(indices, offsets, B, psw, 0, None)
     L = _lib.load()
     ws = _workspace(ts, op)
-    if not presorted:
-        op.fixed_pooling = ts.fixed_pooling(indices, offsets, B, pooling) if _lib.needs_pooling_hint() else 0
-        _lib.check(L.pm_embbag_sort_indices_ex(ctypes.byref(op), max(ts.rows), 1, ws.data_ptr(), ws.numel(), _stream_ptr()))
     opt = _lib.pm_rowwise_adagrad(float(lr), float(eps), float(weight_decay), _WD_MODES[weight_decay_mode],
                                   1 if stochastic_rounding else 0, 0, int(seed) & (2**64 - 1))
+    if not presorted and not _lib.needs_pooling_hint():
+        _lib.check(L.pm_embbag_bwd_fused_adagrad(ctypes.byref(op), grad.data_ptr(), ts.d_ptrs.data_ptr(), _WDTYPE[ts.dtype],
+                                                 mom_ptrs_dev.data_ptr(), ctypes.byref(opt), max(ts.rows),
+                                                 ws.data_ptr(), ws.numel(), _stream_ptr()))
+        return
+    if not presorted:
+        op.fixed_pooling = ts.fixed_pooling(indices, offsets, B, pooling)
+        _lib.check(L.pm_embbag_sort_indices_ex(ctypes.byref(op), max(ts.rows), 1, ws.data_ptr(), ws.numel(), _stream_ptr()))
     _lib.check(L.pm_embbag_bwd_sorted_adagrad_ex(ctypes.byref(op), grad.data_ptr(), ts.d_ptrs.data_ptr(), _WDTYPE[ts.dtype],
                                                  mom_ptrs_dev.data_ptr(), ctypes.byref(opt), max(ts.rows),
                                                  ws.data_ptr(), ws.numel(), _stream_ptr()))

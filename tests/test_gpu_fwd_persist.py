@@ -112,8 +112,8 @@ def test_persistent_forward_ragged_but_divisible(coracle, cfg, idt):
 
 
 def test_persistent_forward_many_iterations_mixed_dims_and_default_mode(coracle):
-    """a request large enough for the DEFAULT mode (>= 8 tiles per resident workgroup): 16 tables of mixed widths, each
-    workgroup loops ~10 times; checked against the classic kernel bit for bit (the oracle on a slice of the batch), and
+    """a request large enough for mode 1 (>= 8 tiles per resident workgroup): 16 tables of mixed widths, each
+    workgroup loops ~10 times (mode 1 = large requests only); checked against the classic kernel bit for bit (the oracle on a slice of the batch), and
     repeated launches on two streams give the same bits (no state survives a launch)"""
     import param_amd
     from param_amd import BatchedEmbeddingBagMI355
@@ -128,7 +128,7 @@ def test_persistent_forward_many_iterations_mixed_dims_and_default_mode(coracle)
     di, do = _t(idx), _t(off)
     param_amd.set_forward_persist(0)
     cla = m.lookup(di, do).cpu().numpy()
-    param_amd.set_forward_persist()                      # default: this request qualifies
+    param_amd.set_forward_persist(1)                     # mode 1: this request qualifies (>= 8 tiles per resident workgroup)
     per = m.lookup(di, do).cpu().numpy()
     assert np.array_equal(per, cla)
     s = torch.cuda.Stream()

@@ -378,3 +378,49 @@ def test_random_mid_size_requests_hybrid_vs_sorted_and_oracle(seed, coracle):
         cold = np.bincount(idx_h[s:e], minlength=rows[0]) <= 256
         assert np.array_equal(w0_after[cold], exp[cold]), seed
     param_amd.set_hybrid_tuning()
+
+
+def test_sort_aside_consumes_the_request_and_only_fused_calls_defer(coracle):
+    """Round 5: the hybrid backward defers part of the sort into the apply, which reads the request's indices AGAIN.
+    That is safe only when the library sequences sort and apply itself (pm_embbag_bwd_fused*).  A sort issued on its own must
+    consume the request completely -- the caller may refill the index buffer before the apply:
+      * sort aside, overwrite the indices with another request's, apply presorted -> the tables of the ORIGINAL request, bit for bit;
+      * pm_embbag_sorted_pairs after the bare sort (hybrid at its default) shows every pair, in numpy's stable order;
+      * the fused call on the same request goes hybrid (status) and gives the same tables."""
+    import param_amd
+    from param_amd.embedding_bag import _sort_indices, sorted_pairs
+
+    param_amd.set_hybrid_tuning()                       # default: on
+    rows, D, B, L = [300_000] * 8, 128, 1024, 16
+    idx, off = _request(rows, B, L, 0.0, 5)
+    other, _ = _request(rows, B, L, 0.0, 6)
+    grad = torch.randn(B, len(rows) * D, device=DEV)
+    ref = _model(rows, D, seed=4)
+    tabs = [ref.table(t).cpu().numpy() for t in range(len(rows))]
+    exp = _oracle_tables(coracle, tabs, idx, off, B, grad, D, -0.5)
+
+    fused = _model(rows, D, seed=4)
+    fused.scatter_add_(grad, idx, off, alpha=-0.5, batch=B)
+    st = fused.sort_status(idx, off, batch=B)
+    assert st["hybrid_launched"] == 1 and st["hybrid_tables"] == len(rows), st
+    for t in range(len(rows)):
+        assert np.array_equal(fused.table(t).cpu().numpy(), exp[t]), t
+
+    aside = _model(rows, D, seed=4)
+    ts = aside._tables()
+    work = idx.clone()
+    _sort_indices(ts, work, off, B)
+    k, v, tsh = sorted_pairs(ts, work, off, B)          # a bare sort is complete: no PM_ERR_INVALID, all pairs there
+    n1 = B * L
+    kh, ih = k.cpu().numpy(), idx.cpu().numpy()
+    for t in range(len(rows)):
+        seg = ih[t * n1:(t + 1) * n1]
+        order = np.argsort(seg, kind="stable")
+        assert np.array_equal(kh[t * n1:(t + 1) * n1], (t << tsh) | seg[order]), t
+    st = aside.sort_status(work, off, batch=B)
+    assert st["hybrid_launched"] == 0 and st["pairs_sorted"] == idx.numel(), st
+    work.copy_(other)                                   # the caller reuses its index buffer ...
+    torch.cuda.synchronize()
+    aside.scatter_add_(grad, work, off, alpha=-0.5, batch=B, presorted=True)      # ... and the apply still applies what was sorted
+    for t in range(len(rows)):
+        assert np.array_equal(aside.table(t).cpu().numpy(), exp[t]), t

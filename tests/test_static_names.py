@@ -91,3 +91,23 @@ def test_the_guard_sees_a_misspelt_name(tmp_path):
     p = tmp_path / "m.py"
     p.write_text("import os\n\ndef f(a):\n    if a:\n        return oss.getcwd()\n    return [x for x in range(a)] + [lambda q: q + b]\n")
     assert unbound_names(str(p)) == [(5, "oss"), (6, "b")]
+
+
+def test_no_experiment_branches_in_the_product_kernels():
+    """round 4's ablation switches (PM_FWD_EXP, PM_FWD_STORE, PM_MAIN_EXP, PM_UNIQ_EXP, PM_LB_EXP: `#if` branches inside the hot kernels
+    that dropped loads / stores / ranking for timing experiments) are gone from the product sources, and nothing on a launch path
+    reads the environment per call (capi.hip reads its switches once per process)"""
+    import glob
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for path in glob.glob(os.path.join(root, "param_amd", "csrc", "*")):
+        if not path.endswith((".hip", ".inc", ".h")):
+            continue
+        text = open(path).read()
+        assert not re.search(r"PM_[A-Z0-9_]*EXP\b", text), path
+        assert "PM_FWD_STORE" not in text, path
+    capi = open(os.path.join(root, "param_amd", "csrc", "capi.hip")).read()
+    body = capi[capi.index("int make_params("):]
+    assert "getenv" not in body, "capi.hip: getenv on a launch path"
