@@ -39,6 +39,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "pm_experiments.h"
 
 namespace pm {
 namespace {
@@ -1016,9 +1017,14 @@ __global__ void __launch_bounds__(kT) seg_lookback_pass_kernel(const TileDesc* t
     const bool from_idx = src.first && td.pooling > 0;    // keys formed from the index array, bag = position / pooling
     K key[kTileItems];
     uint32_t val[kTileItems];
+    const unsigned trace_id = static_cast<unsigned>(pass) * 4096u + blockIdx.x;      // (experiment builds: PM_STAMP; nothing otherwise)
+    (void)trace_id;
+    PM_STAMP(trace_id, 0);
     load_tile_pairs<K>(td, src, base, from_idx, key, val);
+    PM_STAMP_DRAINED(trace_id, 1);
     uint32_t rank[kTileItems];
     tile_count_digits<K, kTileItems, RB>(key, rank, cnt, chunk, shift, mask, s_wcnt);
+    PM_STAMP(trace_id, 2);
     tile_digit_starts<RB>(s_wcnt, s_dstart, s_tmp, s_gbase);                  // s_gbase: the tile's count of every digit, for now
     u32x4 mine = {0u, 0u, 0u, 0u};
     if (wave < LW) {
@@ -1026,7 +1032,9 @@ __global__ void __launch_bounds__(kT) seg_lookback_pass_kernel(const TileDesc* t
         // pass 0's aggregates were published by seg_hist_all; a table's first tile publishes its inclusive prefix at once
         if (pass != 0) store_status(st + static_cast<uint64_t>(g) * RAD + dq, mine | (j == 0 ? kStInclusive : kStAggregate));
     }
+    PM_STAMP_DRAINED(trace_id, 3);
     tile_place<K, kTileItems, RB>(key, val, rank, cnt, chunk, shift, mask, s_key, s_val, s_wcnt, s_dstart, false);
+    PM_STAMP(trace_id, 4);
     if (wave < LW) {
         u32x4 ex = {0u, 0u, 0u, 0u};
         u32x4 open = {~0u, ~0u, ~0u, ~0u};                                    // digits still walking: all-ones
@@ -1085,8 +1093,10 @@ __global__ void __launch_bounds__(kT) seg_lookback_pass_kernel(const TileDesc* t
         }
         if (j > 0) store_status(st + static_cast<uint64_t>(g) * RAD + dq, ((ex + mine) & kStValue) | kStInclusive);
         *reinterpret_cast<u32x4*>(s_gbase + dq) = tb + ex;                    // where this tile's run of each digit starts
+        PM_STAMP_DRAINED(trace_id, 5);
     }
     __syncthreads();
+    PM_STAMP(trace_id, 6);
 #pragma unroll 4
     for (int q0 = 0; q0 < kTileItems; ++q0) {
         const uint32_t q = q0 * kT + threadIdx.x;
@@ -1098,6 +1108,7 @@ __global__ void __launch_bounds__(kT) seg_lookback_pass_kernel(const TileDesc* t
             vout[o] = s_val[q];
         }
     }
+    PM_STAMP_DRAINED(trace_id, 7);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1579,3 +1590,22 @@ PM_SEG_INST(uint64_t)
 #undef PM_SEG_INST
 
 }  // namespace pm
+
+#ifdef PM_EXPERIMENTS
+namespace pm {
+namespace exp {
+__device__ unsigned long long g_trace[kTraceWgs * kTraceSlots];
+}
+}  // namespace pm
+extern "C" int pm_experiment_trace(unsigned long long* out, int words, int clear) {      // experiment builds only (pm_experiments.h)
+    const size_t bytes = sizeof(unsigned long long) * static_cast<size_t>(words);
+    if (bytes > sizeof(unsigned long long) * pm::exp::kTraceWgs * pm::exp::kTraceSlots) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(pm::exp::g_trace), bytes) != hipSuccess) return -3;
+    if (clear) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(pm::exp::g_trace)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned long long) * pm::exp::kTraceWgs * pm::exp::kTraceSlots) != hipSuccess) return -4;
+    }
+    return 0;
+}
+#endif
