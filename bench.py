@@ -369,8 +369,20 @@ def cpu_baseline(spec: dict, budget_s: float = 20.0):
     }
 
 
+def profile_traffic(workload: str, phase: str):
+    """L2 -> fabric bytes per step of a COMMITTED rocprofv3 --pmc profile (profiles/pmc_traffic.json["phases"], produced by
+    tools/r5_pmc.sh: never collected inside a bench run), as {"traffic_over_algorithmic": r, "from": ...}, or {} when there is none"""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        ph = rec["phases"][f"{workload}.{phase}"]
+        return {"traffic_over_algorithmic": ph["traffic_over_algorithmic"], "traffic_bytes_per_step": ph["fabric_bytes_per_step"],
+                "traffic_from_profile": f"profiles/pmc_traffic.json[phases][{workload}.{phase}] <- {rec.get('phases_source', '')[:40]}"}
+    except Exception:
+        return {}
+
+
 # ---- compact extra blocks of the default N == 1 run -------------------------------------------------------------------
-def extra_block(dev, rows, pools, D, dtype_name, B, alpha, n_sub, barrier, layout):
+def extra_block(dev, rows, pools, D, dtype_name, B, alpha, n_sub, barrier, layout, pmc_key=None):
     """One more workload measured in the same run, compactly: BASELINE configs[2]'s bf16 half with ALL 64 tables resident (the
     configuration the metric is quoted on: 64 x 10 M x 128 fits one GPU in bf16) and configs[4]'s Criteo tables.  Forward under Zipf
     and uniform indices (the latter is the roofline fraction), the deterministic backward (sort + apply), the fwd + bwd step."""
@@ -391,12 +403,16 @@ def extra_block(dev, rows, pools, D, dtype_name, B, alpha, n_sub, barrier, layou
     _, fu = time_steps_med(lambda: model.lookup(ui, uo, out=out, batch=B), 2 * n_sub, 25, barrier)
     _, fz = time_steps_med(lambda: model.lookup(zi, zo, out=out, batch=B), 2 * n_sub, 5, barrier)
     rec["fwd"] = {"zipf_lookups_per_s": n / fz, "zipf_avg_launch_s": fz, "uniform_avg_launch_s": fu, "uniform_frac": fwd_bytes / fu / 1e9 / HBM_PEAK_GBPS}
+    if pmc_key:
+        rec["fwd"]["uniform_profile"] = profile_traffic(pmc_key, "fwd_uniform")
+        rec["fwd"]["zipf_profile"] = profile_traffic(pmc_key, "fwd_zipf")
     bwd = {}
     for tag, (i, o) in (("uniform", (ui, uo)), ("zipf", (zi, zo))):
         _, bs = time_steps_med(lambda: model.scatter_add_(grad, i, o, alpha=-1e-6, batch=B), n_sub, 10, barrier)
         st = model.sort_status(i, o, batch=B)
         bwd[tag] = {"avg_s_sort_plus_apply": bs, ("frac" if tag == "uniform" else "alg_frac"): bwd_bytes / bs / 1e9 / HBM_PEAK_GBPS,
-                    "hybrid_tables": st["hybrid_tables"], "pairs_sorted": st["pairs_sorted"]}
+                    "hybrid_tables": st["hybrid_tables"], "pairs_sorted": st["pairs_sorted"],
+                    **(profile_traffic(pmc_key, "bwd_" + tag) if pmc_key else {})}
 
         def fwd_bwd():
             model.lookup(i, o, out=out, batch=B)
@@ -872,6 +888,8 @@ def main():
                  "bytes_per_lookup": bwd_bytes / lookups_step_rank,
                  "timing": f"{SECONDARY_TIMING} of {n_sub} steps, 10 warm-ups; one fused call per step (pm_embbag_bwd_fused)",
                  "sort": st,
+                 **(profile_traffic("fp32", "bwd_uniform" if uniform else "bwd_zipf")
+                    if (a.dtype == "fp32" and a.workload == "uniform-tables" and T_loc == 48 and R == 10_000_000 and D == 128) else {}),
                  "sort_aside": {"avg_s_whole_key_sort": ks, "avg_s_sorted_apply_of_all_pairs": ba,
                                 ("sorted_apply_frac" if uniform else "sorted_apply_alg_frac"): bwd_bytes / ba / 1e9 / HBM_PEAK_GBPS,
                                 "note": "pm_embbag_sort_indices on its own (complete, never hybrid) + pm_embbag_bwd_sorted: the form "
@@ -956,7 +974,8 @@ def main():
                 if free_now < need:
                     result[key] = {"skipped": f"needs {need / 1e9:.0f} GB of free HBM, {free_now / 1e9:.0f} available after the fp32 block"}
                     continue
-                result[key] = extra_block(dev, rows_x, pools_x, 128, dt_x, B_local, a.alpha, n_sub, barrier, lay_x)
+                result[key] = extra_block(dev, rows_x, pools_x, 128, dt_x, B_local, a.alpha, n_sub, barrier, lay_x,
+                                          pmc_key="bf16" if key == "bf16_T64" else "criteo")
             except Exception as exc:
                 result[key] = {"error": str(exc)[:300]}
             gc.collect()
