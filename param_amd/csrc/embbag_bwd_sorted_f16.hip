@@ -1,6 +1,7 @@
 // param_amd/csrc/embbag_bwd_sorted_f16.hip -- the sorted backward's apply kernels for f16 destination tables (one translation
 // unit per destination dtype: see bwd_sorted_apply.h).
 #include "bwd_sorted_apply.h"
+#include "pm_experiments.h"
 
 namespace pm {
 namespace {

@@ -1,6 +1,7 @@
 // param_amd/csrc/embbag_bwd_sorted_f32.hip -- the sorted backward's apply kernels for f32 destination tables (one translation
 // unit per destination dtype: see bwd_sorted_apply.h).
 #include "bwd_sorted_apply.h"
+#include "pm_experiments.h"
 
 namespace pm {
 namespace {
@@ -16,3 +17,5 @@ hipError_t bwd_unique_launch_f32(const SortedParams& sp, const KParams& kp, cons
 }
 
 }  // namespace pm
+
+PM_DEFINE_TRACE_READER(pm_experiment_trace_apply_f32)      // experiment builds only (pm_experiments.h); nothing in the product

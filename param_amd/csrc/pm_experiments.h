@@ -16,7 +16,9 @@ namespace pm {
 namespace exp {
 constexpr int kTraceSlots = 8;
 constexpr int kTraceWgs = 1 << 15;
-extern __device__ unsigned long long g_trace[kTraceWgs * kTraceSlots];
+namespace {      // one buffer per translation unit (the library is not built with relocatable device code)
+__device__ unsigned long long g_trace[kTraceWgs * kTraceSlots];
+}
 __device__ __forceinline__ void stamp(unsigned wg, int slot, bool drain) {
     if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (threadIdx.x == 0 && wg < static_cast<unsigned>(kTraceWgs)) g_trace[wg * kTraceSlots + slot] = __builtin_amdgcn_s_memrealtime();
@@ -25,7 +27,22 @@ __device__ __forceinline__ void stamp(unsigned wg, int slot, bool drain) {
 }  // namespace pm
 #define PM_STAMP(wg, slot) pm::exp::stamp((wg), (slot), false)
 #define PM_STAMP_DRAINED(wg, slot) pm::exp::stamp((wg), (slot), true)
+// the translation unit's reader: copies `words` 64-bit words of its trace buffer to `out` (device synchronised first), optionally clears it
+#define PM_DEFINE_TRACE_READER(fn)                                                                                                      \
+    extern "C" int fn(unsigned long long* out, int words, int clear) {                                                                  \
+        const size_t all = sizeof(unsigned long long) * pm::exp::kTraceWgs * pm::exp::kTraceSlots;                                      \
+        const size_t bytes = sizeof(unsigned long long) * static_cast<size_t>(words);                                                   \
+        if (bytes > all) return -1;                                                                                                     \
+        if (hipDeviceSynchronize() != hipSuccess) return -2;                                                                            \
+        if (out && bytes && hipMemcpyFromSymbol(out, HIP_SYMBOL(pm::exp::g_trace), bytes) != hipSuccess) return -3;                     \
+        if (clear) {                                                                                                                    \
+            void* p = nullptr;                                                                                                          \
+            if (hipGetSymbolAddress(&p, HIP_SYMBOL(pm::exp::g_trace)) != hipSuccess || hipMemset(p, 0, all) != hipSuccess) return -4;   \
+        }                                                                                                                               \
+        return 0;                                                                                                                       \
+    }
 #else
 #define PM_STAMP(wg, slot) ((void)0)
 #define PM_STAMP_DRAINED(wg, slot) ((void)0)
+#define PM_DEFINE_TRACE_READER(fn)
 #endif

@@ -1591,21 +1591,4 @@ PM_SEG_INST(uint64_t)
 
 }  // namespace pm
 
-#ifdef PM_EXPERIMENTS
-namespace pm {
-namespace exp {
-__device__ unsigned long long g_trace[kTraceWgs * kTraceSlots];
-}
-}  // namespace pm
-extern "C" int pm_experiment_trace(unsigned long long* out, int words, int clear) {      // experiment builds only (pm_experiments.h)
-    const size_t bytes = sizeof(unsigned long long) * static_cast<size_t>(words);
-    if (bytes > sizeof(unsigned long long) * pm::exp::kTraceWgs * pm::exp::kTraceSlots) return -1;
-    if (hipDeviceSynchronize() != hipSuccess) return -2;
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(pm::exp::g_trace), bytes) != hipSuccess) return -3;
-    if (clear) {
-        void* p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(pm::exp::g_trace)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned long long) * pm::exp::kTraceWgs * pm::exp::kTraceSlots) != hipSuccess) return -4;
-    }
-    return 0;
-}
-#endif
+PM_DEFINE_TRACE_READER(pm_experiment_trace)      // experiment builds only (pm_experiments.h); nothing in the product
