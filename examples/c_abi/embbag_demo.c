@@ -94,28 +94,42 @@ int main(void) {
     if (ws_bytes < 0) { fprintf(stderr, "workspace: %s\n", pm_last_error()); return 6; }
     void* ws_d;
     HIP_OK(hipMalloc(&ws_d, (size_t)ws_bytes));
-    PM_CALL(pm_embbag_sort_indices(&op, R0, ws_d, ws_bytes, NULL));
-    PM_CALL(pm_embbag_bwd_sorted(&op, grad_d, tabs_dd, PM_F32, -0.5f, R0, ws_d, ws_bytes, NULL));
-    HIP_OK(hipDeviceSynchronize());
+    /* step 1: the sort-aside form (the sort is complete on its own); step 2: the fused call of ABI v6 (sort + apply in one call: the
+       form in which the library may take the hybrid path).  Both checked bit for bit against sequential host loops. */
+    float* ref_h[8];
     for (int t = 0; t < T; ++t) {
         const size_t bytes = (size_t)rows_h[t] * dims_h[t] * sizeof(float);
-        float* ref = (float*)malloc(bytes);
-        memcpy(ref, tab_h[t], bytes);
-        for (int b = 0; b < B; ++b)
-            for (int64_t j = off_h[t * B + b]; j < off_h[t * B + b + 1]; ++j)
-                for (int d = 0; d < dims_h[t]; ++d) {
-                    const float step = -0.5f * grad_h[(size_t)b * out_stride + col0_h[t] + d];
-                    ref[idx_h[j] * dims_h[t] + d] = ref[idx_h[j] * dims_h[t] + d] + step;
-                }
-        float* got = (float*)malloc(bytes);
-        HIP_OK(hipMemcpy(got, tab_d[t], bytes, hipMemcpyDeviceToHost));
-        if (memcmp(got, ref, bytes) != 0) { fprintf(stderr, "backward mismatch in table %d\n", t); return 7; }
-        free(ref); free(got);
+        ref_h[t] = (float*)malloc(bytes);
+        memcpy(ref_h[t], tab_h[t], bytes);
+    }
+    for (int step = 0; step < 2; ++step) {
+        const float alpha = step == 0 ? -0.5f : -0.25f;
+        if (step == 0) {
+            PM_CALL(pm_embbag_sort_indices(&op, R0, ws_d, ws_bytes, NULL));
+            PM_CALL(pm_embbag_bwd_sorted(&op, grad_d, tabs_dd, PM_F32, alpha, R0, ws_d, ws_bytes, NULL));
+        } else {
+            PM_CALL(pm_embbag_bwd_fused(&op, grad_d, tabs_dd, PM_F32, alpha, R0, ws_d, ws_bytes, NULL));
+        }
+        HIP_OK(hipDeviceSynchronize());
+        for (int t = 0; t < T; ++t) {
+            const size_t bytes = (size_t)rows_h[t] * dims_h[t] * sizeof(float);
+            float* ref = ref_h[t];
+            for (int b = 0; b < B; ++b)
+                for (int64_t j = off_h[t * B + b]; j < off_h[t * B + b + 1]; ++j)
+                    for (int d = 0; d < dims_h[t]; ++d) {
+                        const float stepv = alpha * grad_h[(size_t)b * out_stride + col0_h[t] + d];
+                        ref[idx_h[j] * dims_h[t] + d] = ref[idx_h[j] * dims_h[t] + d] + stepv;
+                    }
+            float* got = (float*)malloc(bytes);
+            HIP_OK(hipMemcpy(got, tab_d[t], bytes, hipMemcpyDeviceToHost));
+            if (memcmp(got, ref, bytes) != 0) { fprintf(stderr, "backward mismatch in table %d (step %d)\n", t, step); return 7; }
+            free(got);
+        }
     }
 
     /* error behaviour: a bad argument returns a negative code and a message, nothing is launched */
     op.max_dim = 7;
     if (pm_embbag_fwd(&op, out_d, NULL) != PM_ERR_UNSUPPORTED || strlen(pm_last_error()) == 0) { fprintf(stderr, "error path\n"); return 8; }
-    printf("embbag_demo: forward bit-exact, sorted backward bit-exact (%lld lookups, %d tables)\n", (long long)n, T);
+    printf("embbag_demo: forward bit-exact, sorted and fused backward bit-exact (%lld lookups, %d tables)\n", (long long)n, T);
     return 0;
 }

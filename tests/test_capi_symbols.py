@@ -114,12 +114,12 @@ def test_c_abi_demo_compiles_as_plain_c(tmp_path):
 
 @pytest.mark.gpu
 def test_c_abi_demo_runs_on_gpu(tmp_path):
-    """the same program on the device: forward and sorted backward bit-exact against its own sequential host loops"""
+    """the same program on the device: forward, sorted (sort-aside) and fused (ABI v6) backward bit-exact against its own sequential host loops"""
     import subprocess
 
     r = subprocess.run([_build_c_demo(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "forward bit-exact, sorted backward bit-exact" in r.stdout
+    assert "forward bit-exact, sorted and fused backward bit-exact" in r.stdout
 
 
 def _plan(L, T, B, Lp, max_rows, phases=1, fixed=True, slice_=None, weighted=False):
