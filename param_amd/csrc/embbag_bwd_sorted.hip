@@ -145,14 +145,18 @@ hipError_t rocprim_temp_bytes(int64_t n, int kbits_sort, size_t& bytes) {
 //              only the row bits are sorted (one pass fewer; the apply kernel then runs 5 % slower and cannot be XCD-affine)
 //   xcd        1 (default): XCD-affine tile mapping of the apply kernel where the layout allows  PARAM_AMD_BWD_XCD=0
 std::atomic<int> g_sort_impl{-1}, g_sort_order{-1}, g_bwd_xcd{-1}, g_max_phases{-1};
+// (called from knob(): each knob's environment default is looked up the first time the knob is read and stored in the knob)
 int env_is(const char* name, const char* value) {
     const char* e = getenv(name);
     return (e && std::string(e) == value) ? 1 : 0;
 }
-int knob(std::atomic<int>& k, int env_default) {
+// a knob left at -1 takes its default from the environment, looked up ONCE, when the knob is first read (and again only after a
+// pm_set_* call has put it back to -1): never on a launch path
+template <typename F>
+int knob(std::atomic<int>& k, F env_default) {
     int v = k.load();
     if (v < 0) {
-        v = env_default;
+        v = env_default();
         k.store(v);
     }
     return v;
@@ -160,7 +164,7 @@ int knob(std::atomic<int>& k, int env_default) {
 // sort_impl: 0 (default) the segmented sort of round 3 (seg_sort.hip: per-table segments established on the device);
 //            1 rocPRIM radix_sort_pairs (PARAM_AMD_SORT=rocprim); 2 round 2's own LSD sort with host-side plans
 //            (PARAM_AMD_SORT=legacy) -- both kept as measured alternatives and as independent checks of the new path
-int sort_impl_knob() { return knob(g_sort_impl, env_is("PARAM_AMD_SORT", "rocprim") ? 1 : env_is("PARAM_AMD_SORT", "legacy") ? 2 : 0); }
+int sort_impl_knob() { return knob(g_sort_impl, [] { return env_is("PARAM_AMD_SORT", "rocprim") ? 1 : env_is("PARAM_AMD_SORT", "legacy") ? 2 : 0; }); }
 bool use_rocprim_sort() { return sort_impl_knob() == 1; }
 // how the segmented sort orders a table's pairs (pm_set_sort_tuning, PARAM_AMD_SORT_MODE): 0 LSD passes over all row bits
 // (ascending rows; one kernel per pass, tiles learn their prefixes from their predecessors in flight), 1 one partition pass on
@@ -175,7 +179,11 @@ int sort_mode_knob() {
     }
     return v;
 }
-bool table_major_order() { return knob(g_sort_order, env_is("PARAM_AMD_SORT_ORDER", "row") ? 0 : 1) == 1; }
+bool fused_keys_allowed() {      // sort_impl 2 only; once per process
+    static const bool ok = !env_is("PARAM_AMD_SORT_FUSED_KEYS", "0");
+    return ok;
+}
+bool table_major_order() { return knob(g_sort_order, [] { return env_is("PARAM_AMD_SORT_ORDER", "row") ? 0 : 1; }) == 1; }
 // hybrid backward (pm_set_hybrid_tuning; common.h "Hybrid backward"):
 //   enable   0 off; 1 (default) on: every table is classified on the device at every sort, from the request alone; 2 every
 //            structurally eligible table takes the hybrid path whatever its indices look like (tests)   PARAM_AMD_BWD_HYBRID=0..2
@@ -189,13 +197,13 @@ int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return (e && e[0] >= '0' && e[0] <= '9') ? atoi(e) : dflt;
 }
-int hyb_enable_knob() { return knob(g_hyb_enable, env_int("PARAM_AMD_BWD_HYBRID", 1)); }
-bool want_xcd() { return knob(g_bwd_xcd, env_is("PARAM_AMD_BWD_XCD", "0") ? 0 : 1) == 1; }
+int hyb_enable_knob() { return knob(g_hyb_enable, [] { return env_int("PARAM_AMD_BWD_HYBRID", 1); }); }
+bool want_xcd() { return knob(g_bwd_xcd, [] { return env_is("PARAM_AMD_BWD_XCD", "0") ? 0 : 1; }) == 1; }
 //   max_phases 1 (default): one apply launch; 2: a phases = 2 sort lays a fixed-pooling request out for the two-phase
 //              apply (measured at benchmark size: uniform indices 1.60 -> 1.58 ms, Zipf 0.97 -> 1.12 ms: rows looked up in
 //              both bag halves are read and written twice, and halving the gradient working set does not make it stay in
 //              L2 -- 1 KB of row traffic streams through for every 512 B gradient row)              PARAM_AMD_BWD_PHASES=2
-int max_phases() { return knob(g_max_phases, env_is("PARAM_AMD_BWD_PHASES", "2") ? 2 : 1); }
+int max_phases() { return knob(g_max_phases, [] { return env_is("PARAM_AMD_BWD_PHASES", "2") ? 2 : 1; }); }
 
 hipError_t ws_layout(void* base, int64_t n, int T, int key_bytes, int kbits_sort, bool weighted, int max_dim, SortWs& ws) {
     size_t tb = 0;
@@ -316,7 +324,7 @@ SortPlan make_plan(const KParams& p, int64_t max_rows, int64_t fixed_pooling, in
     else if (g.segmented) g.sort_end_bit = g.rbits;              // per (table, phase) segment: rows only
     else g.sort_end_bit = table_major_order() ? g.kbits : g.rbits;
     g.in_b = g.rocprim || (rs_num_passes(0, g.sort_end_bit) % 2 == 1);
-    g.fused_keys = g.segmented && g.H == 1 && !g.weighted && !g.sliced && g.sort_end_bit > 0 && !env_is("PARAM_AMD_SORT_FUSED_KEYS", "0");
+    g.fused_keys = g.segmented && g.H == 1 && !g.weighted && !g.sliced && g.sort_end_bit > 0 && fused_keys_allowed();
     return g;
 }
 

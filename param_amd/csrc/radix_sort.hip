@@ -298,17 +298,8 @@ hipError_t rs_sort_pairs(K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_
         sh[p] = s;
         s += wd[p];
     }
-    // experiment (PARAM_AMD_EXP_DIGIT_ROT=1): the lowest digit is sorted LAST, i.e. it becomes the most significant one --
-    // equal keys still end up adjacent and in input order, but neighbours in the output are no longer neighbours in key
-    // space (measures what the ascending-row order is worth to the apply kernel's address translation)
-    const char* rot_env = getenv("PARAM_AMD_EXP_DIGIT_ROT");   // read per call: a probe flips it between sorts
-    const bool rot = rot_env && rot_env[0] == '1';
-    if (rot && passes > 1) {
-        const int s0 = sh[0], w0 = wd[0];
-        for (int p = 0; p + 1 < passes; ++p) { sh[p] = sh[p + 1]; wd[p] = wd[p + 1]; }
-        sh[passes - 1] = s0;
-        wd[passes - 1] = w0;
-    }
+    // (round 3 measured what the ascending-row order is worth to the apply's address translation with the lowest digit sorted
+    // LAST -- equal keys adjacent, neighbours in the output no longer neighbours in key space: HISTORY; the switch is gone)
     for (int p = 0; p < passes; ++p) {
         const int shift = sh[p], w = wd[p];
         const uint32_t mask = (1u << w) - 1u;
