@@ -179,10 +179,9 @@ int sort_mode_knob() {
     }
     return v;
 }
-bool fused_keys_allowed() {      // sort_impl 2 only; once per process
-    static const bool ok = !env_is("PARAM_AMD_SORT_FUSED_KEYS", "0");
-    return ok;
-}
+// round 2's sort (sort_impl 2, a measured alternative and cross-check) only: the default segmented sort returns from make_plan before
+// this is looked at, so no default launch path reads the environment; tests flip it between two plans of one process
+bool fused_keys_allowed() { return !env_is("PARAM_AMD_SORT_FUSED_KEYS", "0"); }
 bool table_major_order() { return knob(g_sort_order, [] { return env_is("PARAM_AMD_SORT_ORDER", "row") ? 0 : 1; }) == 1; }
 // hybrid backward (pm_set_hybrid_tuning; common.h "Hybrid backward"):
 //   enable   0 off; 1 (default) on: every table is classified on the device at every sort, from the request alone; 2 every
