@@ -79,6 +79,19 @@ def test_argument_validation_without_gpu():
                                              None) == _lib.PM_ERR_INVALID
     assert b"weight_decay_mode" in L.pm_last_error()
     assert L.pm_dlrm_regroup(8, 8, 65, 64, 4, 8, 8, 8, None) == _lib.PM_ERR_UNSUPPORTED   # world * tables > 4096
+    # ABI v6: the fused backward validates like its two halves (nothing is launched before the arguments are accepted) ...
+    assert L.pm_embbag_bwd_fused(None, 8, 8, _lib.PM_F32, 1.0, 1000, 8, 1 << 40, None) == _lib.PM_ERR_INVALID
+    assert L.pm_embbag_bwd_fused(ctypes.byref(op), 8, 8, _lib.PM_F32, 1.0, 1000, None, 0, None) == _lib.PM_ERR_INVALID
+    assert b"workspace" in L.pm_last_error()
+    assert L.pm_embbag_bwd_fused_adagrad(ctypes.byref(op), 8, 8, _lib.PM_F32, 8, ctypes.byref(opt), 1000, None, 0, None) == _lib.PM_ERR_INVALID
+    op.num_indices = 0                                                               # ... and an empty request succeeds without a device
+    assert L.pm_embbag_bwd_fused(ctypes.byref(op), None, None, _lib.PM_F32, 1.0, 1000, None, 0, None) == _lib.PM_OK
+    op.num_indices = 100
+    # ... and the persistent-forward knob takes only what the kernel was built for
+    assert L.pm_set_forward_persist(3, 0, 0, 0, 0) == _lib.PM_ERR_INVALID
+    assert L.pm_set_forward_persist(1, 1, 0, 0, 0) == _lib.PM_ERR_INVALID and L.pm_set_forward_persist(1, 9, 0, 0, 0) == _lib.PM_ERR_INVALID
+    assert L.pm_set_forward_persist(1, 0, 0, 5, 0) == _lib.PM_ERR_INVALID and b"pool_waves" in L.pm_last_error()
+    assert L.pm_set_forward_persist(2, 4, 2, 7, 3) == _lib.PM_OK and L.pm_set_forward_persist(-1, 0, 0, 0, 0) == _lib.PM_OK
 
 
 def test_graft_entry_build_runs():
