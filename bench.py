@@ -84,6 +84,10 @@ def parse():
                    help="N == 1 output layout of the timed step: tbd = [T, B, D] (one [B, D] block per table: what the reference's "
                         "pytorch_emb.py / dlrm.py apply_emb produce, dlrm.py:380-387), bd = [B, sum D] (fbgemm TBE's, the "
                         "all-to-all send layout); the other one is timed too and reported as `other_layout`")
+    p.add_argument("--send-layout", choices=["bd", "blocked"], default="bd",
+                   help="N>1: layout of the lookup's send buffer: bd = [W * B_local, T_loc * D] (default: measured fastest at the N = 8 rank "
+                        "shape, profiles/r05_blocked_layout_probe.jsonl) or blocked = [W][T_loc][B_local][D] (ABI v6: every peer's chunk made of "
+                        "contiguous [B_local, D] runs per table; needs one embedding dim and a power-of-two batch)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--dist-debug", action="store_true", help="run the N>1 (exchange + RCCL) code path even at world size 1")
     p.add_argument("--no-uniform", action="store_true", help="skip the uniform-index (roofline-defining) measurement")
@@ -548,8 +552,12 @@ def main():
     B_glob = B_local * world  # table-wise sharding: every rank serves the global batch for its tables
     table_bytes = R * D * esize
 
-    model = param_amd.BatchedEmbeddingBagMI355(rows_list, D, dtype=dtype, device=dev, init="normal", layout=a.layout if not multi else "bd",
-                                               seed=1000 + rank, fused_update=False)
+    blocked = multi and a.send_layout == "blocked"
+    if blocked and (a.a2a_bitwidth < 32 or a.grad_bitwidth < 32 or B_local & (B_local - 1)):
+        raise SystemExit("--send-layout blocked: fp32 payloads and a power-of-two --batch")
+    model = param_amd.BatchedEmbeddingBagMI355(rows_list, D, dtype=dtype, device=dev, init="normal",
+                                               layout=a.layout if not multi else ("blocked" if blocked else "bd"),
+                                               block_bags=B_local if blocked else None, seed=1000 + rank, fused_update=False)
 
     def make_request(alpha, seed):
         return tbe_request(rows_list, B_glob, pool_list, alpha=alpha, device=dev, seed=seed + 17 * rank)
@@ -588,11 +596,13 @@ def main():
         def lookup_only(i=idx, o=off):
             step(i, o)
     else:
+        blk_shape = (world, T_loc, B_local, D)
+
         def hip_lookup(i, o, out_t):
-            model.lookup(i, o, out=out_t, batch=B_glob)
+            model.lookup(i, o, out=out_t.view(blk_shape) if blocked else out_t, batch=B_glob)
 
         def hip_backward(g, i, o):
-            model.scatter_add_(g, i, o, alpha=-1e-6, batch=B_glob)   # key sort + deterministic apply
+            model.scatter_add_(g.view(blk_shape) if blocked else g, i, o, alpha=-1e-6, batch=B_glob)   # key sort + deterministic apply
 
         rq = None
         if a.a2a_bitwidth < 32 or a.grad_bitwidth < 32:
@@ -601,7 +611,8 @@ def main():
             fbits = a.a2a_bitwidth if a.a2a_bitwidth < 32 else 0
             rq = RowQuant(D, fbits, a.grad_bitwidth if a.grad_bitwidth < 32 else 0,
                           lookup_quantized=(lambda i, o, q: model.lookup_quantized(i, o, fbits, out=q, batch=B_glob)) if fbits else None)
-        ex = ShardedEmbeddingExchange(hip_lookup, hip_backward, world, rank, B_local, widths, dev, quant=rq)
+        ex = ShardedEmbeddingExchange(hip_lookup, hip_backward, world, rank, B_local, widths, dev, quant=rq,
+                                      layout="blocked" if blocked else "bd", dim=D)
         fwd_pending = [None, None]
         kstep = [0]
 
@@ -672,7 +683,7 @@ def main():
             "tables_total": a.tables if world > 1 else T_loc, "tables_per_gpu": split if world > 1 else T_loc,
             "rows": R if a.workload != "criteo" else "criteo_v2 (3 .. 40M rows, 204.2 M total)", "dim": D,
             "batch_per_rank": B_local, "global_batch": B_glob, "pooling": L if a.workload != "criteo" else "criteo_v2 multi-hot",
-            "alpha": a.alpha, "index_dtype": "int64", "output_layout": "[B, sum D]" if (multi or a.layout == "bd") else "[T, B, D]",
+            "alpha": a.alpha, "index_dtype": "int64", "output_layout": ("[W][T_loc][B_local][D] (blocked)" if blocked else "[B, sum D]") if (multi or a.layout == "bd") else "[T, B, D]",
             "parallelism": "1gpu" if world == 1 else f"table-wise x{world} + all-to-all",
             "lookups_per_step": lookups_step_all,
         },

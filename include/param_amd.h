@@ -90,6 +90,19 @@ typedef struct pm_embbag_batch {
                                      0: bags may be ragged.  A hint that changes speed only: the sorted backward then knows
                                      where each table's lookups start without reading device memory (per-table sort segments,
                                      XCD-affine and two-phase apply).  pm_embbag_check verifies it; the kernels do not. */
+    /* ABI v6: the BLOCKED send layout of a table-wise sharded exchange, [W][T][B_local][D] -- every peer's chunk of the pooled
+       output is one contiguous run whose tiles are 16 KB runs (the [B, sum D] layout writes 512-byte pieces 24 KB apart).
+       FORWARD: nothing new in the kernels -- the same indices / offsets arrays describe T * W request tables of batch B_local
+       (request table t * W + w = the lookups of weight table t for the bags of block w: the arrays are table-major), with
+       tables[t * W + w] = table t's pointer and out_offsets[t * W + w] = w * T * B_local * D + t * B_local * D, out_stride = D;
+       `table_group` = W tells the launch that W consecutive request tables read ONE weight table, so that they are placed on
+       one XCD (speed only).  BACKWARD (pm_embbag_bwd, pm_embbag_bwd_sorted*, pm_embbag_bwd_fused*): the request keeps its T
+       weight tables and batch B = W * B_local (a row's lookups must meet in ONE run); the gradient of bag b of table t is read at
+       out_offsets[t] + b * out_stride + (b >> grad_block_shift) * grad_block_extra (B_local = 2^grad_block_shift; out_offsets[t] =
+       t * B_local * D, out_stride = D, grad_block_extra = (T - 1) * B_local * D).  0 / 0 / 0: no blocking. */
+    int32_t table_group;
+    int32_t grad_block_shift;
+    int64_t grad_block_extra;
 } pm_embbag_batch;
 
 /* ABI / build identification. */

@@ -104,6 +104,9 @@ class pm_embbag_batch(ctypes.Structure):
         ("offsets", ctypes.c_void_p),
         ("per_sample_weights", ctypes.c_void_p),
         ("fixed_pooling", ctypes.c_int64),
+        ("table_group", ctypes.c_int32),
+        ("grad_block_shift", ctypes.c_int32),
+        ("grad_block_extra", ctypes.c_int64),
     ]
 
 

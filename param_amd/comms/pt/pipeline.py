@@ -134,11 +134,19 @@ class ShardedEmbeddingExchange:
 
     def __init__(self, lookup: Callable, backward: Callable, world: int, rank: int, local_batch: int,
                  widths: Sequence[int], device, group=None, make_grad: Callable = None, slots: int = 3,
-                 quant: "RowQuant | None" = None):
+                 quant: "RowQuant | None" = None, layout: str = "bd", dim: int = 0):
         self.lookup, self.backward, self.make_grad = lookup, backward, make_grad
         self.world, self.rank, self.local_batch, self.pg = world, rank, local_batch, group
         self.widths = [int(w) for w in widths]
         assert len(self.widths) == world
+        # layout of a peer's chunk inside the send / receive buffers: "bd" = [B_local, widths[r]] (the default: measured fastest at the
+        # N = 8 rank shape, profiles/r05_blocked_layout_probe.jsonl) or "blocked" = [tables of r, B_local, dim] (include/param_amd.h,
+        # ABI v6; one common `dim`, B_local a power of two).  Chunk sizes, splits and every collective are the same either way: the
+        # injected lookup / backward write and read the buffers in the layout they were built for.
+        assert layout in ("bd", "blocked")
+        if layout == "blocked" and (dim <= 0 or any(w % dim for w in self.widths) or quant is not None):
+            raise ValueError("blocked layout: one common embedding dim dividing every rank's width, fp32 payloads")
+        self.layout, self.dim = layout, int(dim)
         wme, n = self.widths[rank], world * local_batch
         self.fwd_recv_splits = [local_batch * w for w in self.widths]
         self.fwd_send_splits = [local_batch * wme] * world
@@ -211,9 +219,13 @@ class ShardedEmbeddingExchange:
         self.backward(self.grad[slot], *self._req[slot])
 
     def recv_block(self, slot: int, src: int) -> torch.Tensor:
-        """[B_local, widths[src]] view of what rank ``src`` sent me in the forward exchange"""
+        """[B_local, widths[src]] view of what rank ``src`` sent me in the forward exchange ([tables of src, B_local, dim] for the
+        blocked layout)"""
         o = sum(self.fwd_recv_splits[:src])
-        return self.recv[slot][o:o + self.fwd_recv_splits[src]].view(self.local_batch, self.widths[src])
+        flat = self.recv[slot][o:o + self.fwd_recv_splits[src]]
+        if self.layout == "blocked":
+            return flat.view(self.widths[src] // self.dim, self.local_batch, self.dim)
+        return flat.view(self.local_batch, self.widths[src])
 
     def selfcheck(self, slot: int, peer_block: Callable, exact: bool = True, rtol: float = 1e-5, local_only: bool = False) -> dict:
         """Verify the payload of the forward exchange held in ``slot`` (already waited for) -- the reference's ``--c 1``
@@ -230,7 +242,8 @@ class ShardedEmbeddingExchange:
             if exp is None:
                 continue
             checked += 1
-            got = self.recv_block(slot, src)[:, :exp.shape[1]]
+            blk = self.recv_block(slot, src)
+            got = (blk[0] if self.layout == "blocked" else blk)[:, :exp.shape[1]]      # table 0 of the source's chunk
             if exact:
                 same = bool(torch.equal(got, exp))
             else:

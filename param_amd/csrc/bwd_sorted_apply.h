@@ -36,6 +36,8 @@ struct SortedParams {
     const float* grad;
     const float* psw;
     int64_t out_stride;
+    int32_t gblk_shift;      // blocked gradient layout (common.h: grad_bag_offset); extra == 0: none
+    int64_t gblk_extra;
     int64_t n;               // number of sorted pairs
     int32_t rbits;           // key = (t << rbits) | row ; keys with bit (tbits+rbits) set are padding
     int32_t kbits;           // tbits + rbits

@@ -165,6 +165,9 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
         const int64_t tb = static_cast<int64_t>(op->num_tables) * op->batch;
         const bool even_req = tb > 0 && op->num_indices % tb == 0;
         p.xcd_affine = xa == 0 ? 0 : (op->num_tables % pm::kXcds == 0 ? 1 : ((op->num_tables > 1 && even_req) ? 3 : 0));
+        // blocked requests (table_group = W consecutive request tables read ONE weight table): contiguous eighths of the
+        // table-major tile order keep a weight table's blocks on one XCD; t % 8 would spread them over all eight
+        if (xa != 0 && op->table_group > 1 && op->num_tables > 1 && even_req) p.xcd_affine = 3;
     }
     const int nt = g_nt_loads.load();
     p.nt_loads = nt > 0 ? nt : 0;   // forward: any non-zero = non-temporal row loads; sorted backward: 1 nt, 2 system scope
@@ -173,6 +176,10 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
     // ... and only where the order can matter: with one bag per lane group (short-bag tiles) nothing is pulled
     p.ordered = (total_bags > 0 && op->num_indices % total_bags != 0 && bpb > NG) ? 1 : 0;
     p.alpha = 1.0f;
+    if (op->grad_block_shift < 0 || op->grad_block_shift > 31 || op->grad_block_extra < 0 || op->table_group < 0)
+        return fail(PM_ERR_INVALID, "grad_block_shift must be in [0, 31], grad_block_extra and table_group >= 0");
+    p.gblk_shift = op->grad_block_shift > 0 ? op->grad_block_shift : 31;
+    p.gblk_extra = op->grad_block_shift > 0 ? op->grad_block_extra : 0;
     // LDS-staged output (forward): the tile's pooled rows leave in one burst at the end of the tile (embbag_fwd.hip).
     // Measured at benchmark size: uniform indices 0.69 -> 0.72-0.74 of the HBM peak in both output layouts, Zipf within
     // +-2 % -- provided the workgroup's LDS stays small (at 6 workgroups per CU the latency-bound Zipf launch lost 12 %):

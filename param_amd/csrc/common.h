@@ -58,10 +58,21 @@ struct KParams {
     int32_t flat_bags;           // forward: > 0 = the flat-walk kernel (short-bag requests): bags per tile derived per table on the
                                  // device, at most this many (= bags_per_block, which sizes the LDS offsets array)
     int32_t flat_target;         // ... lookups per tile aimed at
+    int32_t gblk_shift;          // backward kernels: blocked gradient layout (ABI v6, pm_embbag_batch::grad_block_shift): bag b of table t at
+    int64_t gblk_extra;          //   io + out_offsets[t] + b * out_stride + (b >> gblk_shift) * gblk_extra ; no blocking: extra = 0
     int32_t ps_slots;            // forward: > 0 = the persistent kernel (embbag_fwd_persist.hip) with this many ring slots; bags_per_block is
                                  // then its tile (a multiple of the bags pooled concurrently), idx_cap the index entries per slot
     float alpha;                 // bwd scale
 };
+
+// element offset of bag `bag`'s gradient row inside its table's slice (blocked layouts add a per-block term; extra == 0 otherwise)
+// (`extra` is a kernel argument: the test is a scalar branch, and the un-blocked layouts -- every benchmark line -- skip the second
+// 64-bit multiply; computed unconditionally it cost the Zipf sorted apply 1.1 %, same-box A/B)
+__device__ __forceinline__ int64_t grad_bag_offset(int64_t bag, int64_t out_stride, int shift, int64_t extra) {
+    int64_t o = bag * out_stride;
+    if (__builtin_expect(extra != 0, 0)) o += (bag >> shift) * extra;
+    return o;
+}
 
 __device__ __forceinline__ int64_t load_index(const void* p, int64_t i, int idx64) {
     return idx64 ? as_global<int64_t>(p)[i] : static_cast<int64_t>(as_global<int32_t>(p)[i]);

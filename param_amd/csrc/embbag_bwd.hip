@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(kBlock) embbag_bwd_kernel(const KParams p) {
         const int64_t s = s_off[bg];
         const int64_t e = s_off[bg + 1];
         if (s == e) continue;
-        const float* grow = grad_t + (bag0 + bg) * p.out_stride;
+        const float* grow = grad_t + grad_bag_offset(bag0 + bg, p.out_stride, p.gblk_shift, p.gblk_extra);
 
         for (int c = lig * VEC; c < D; c += G * VEC) {
             float g[VEC];

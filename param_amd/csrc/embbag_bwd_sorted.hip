@@ -558,6 +558,8 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
     sp.grad = p.io;
     sp.psw = p.psw;
     sp.out_stride = p.out_stride;
+    sp.gblk_shift = p.gblk_shift;
+    sp.gblk_extra = p.gblk_extra;
     sp.n = p.N;
     sp.rbits = g.rbits;
     sp.kbits = g.kbits;

@@ -62,8 +62,8 @@ def fill_random_(t: torch.Tensor, dist: str = "normal", a: float = 0.0, b: float
 class _TableSet:
     """Device-side description of T tables (pointer / rows / dims / output-offset arrays)."""
 
-    def __init__(self, tables: Sequence[torch.Tensor], layout: str = "bd"):
-        assert layout in ("bd", "tbd")
+    def __init__(self, tables: Sequence[torch.Tensor], layout: str = "bd", block_bags: Optional[int] = None):
+        assert layout in ("bd", "tbd", "blocked")
         t0 = tables[0]
         for t in tables:
             _require_device(t, "embedding table")
@@ -82,8 +82,16 @@ class _TableSet:
         for d in self.dims:
             if d % vec:
                 raise ValueError(f"embedding dim {d} must be a multiple of {vec} for dtype {t0.dtype}")
-        if layout == "tbd" and len(set(self.dims)) != 1:
-            raise ValueError('layout "tbd" needs one common embedding dim')
+        if layout in ("tbd", "blocked") and len(set(self.dims)) != 1:
+            raise ValueError(f'layout "{layout}" needs one common embedding dim')
+        # "blocked" = [W][T][block_bags][D], W = B / block_bags: the send layout of a table-wise sharded exchange whose peers each
+        # get ONE contiguous chunk made of [block_bags, D] runs per table (include/param_amd.h, pm_embbag_batch, ABI v6)
+        self.block_bags = None
+        if layout == "blocked":
+            if block_bags is None or block_bags < 1 or block_bags & (block_bags - 1):
+                raise ValueError('layout "blocked" needs block_bags = a power of two (the per-rank batch)')
+            self.block_bags = int(block_bags)
+        self._blk_cache: dict = {}
         self.T = len(tables)
         self.max_dim = max(self.dims)
         self.total_dim = sum(self.dims)
@@ -105,11 +113,33 @@ class _TableSet:
         if self.layout == "bd":
             return self.d_col0, self.total_dim, (B, self.total_dim)
         D = self.dims[0]
+        if self.layout == "blocked":
+            # (the BACKWARD's description: T weight tables, batch B, gradient of bag b at t * Bl * D + b * D + (b >> log2 Bl) * (T - 1) * Bl * D)
+            Bl = self.block_bags
+            if B % Bl:
+                raise ValueError(f"blocked layout: batch {B} is not a multiple of block_bags {Bl}")
+            key = ("bwd", B)
+            if key not in self._blk_cache:
+                self._blk_cache[key] = torch.arange(self.T, dtype=torch.int64, device=self.device) * (Bl * D)
+            return self._blk_cache[key], D, (B // Bl, self.T, Bl, D)
         if B not in self._tbd_cache:
             self._tbd_cache[B] = torch.arange(self.T, dtype=torch.int64, device=self.device) * (B * D)
         return self._tbd_cache[B], D, (self.T, B, D)
 
-    def request(self, indices, offsets, B, psw, bag_begin, bag_count, d_ptrs=None) -> _lib.pm_embbag_batch:
+    def blocked_forward_arrays(self, B: int):
+        """request tables of the blocked FORWARD: W = B / block_bags consecutive request tables per weight table (the
+        table-major indices / offsets arrays already are that request) -> (tables, rows, dims, out_offsets) device arrays, W"""
+        Bl, D, T = self.block_bags, self.dims[0], self.T
+        W = B // Bl
+        key = ("fwd", W)
+        if key not in self._blk_cache:
+            rep_ = lambda t: t.repeat_interleave(W)                                                        # noqa: E731
+            w = torch.arange(W, dtype=torch.int64, device=self.device).repeat(T)
+            tt = torch.arange(T, dtype=torch.int64, device=self.device).repeat_interleave(W)
+            self._blk_cache[key] = (rep_(self.d_ptrs), rep_(self.d_rows), rep_(self.d_dims), w * (T * Bl * D) + tt * (Bl * D))
+        return self._blk_cache[key], W
+
+    def request(self, indices, offsets, B, psw, bag_begin, bag_count, d_ptrs=None, forward: bool = False) -> _lib.pm_embbag_batch:
         # benchmark loops call with the SAME tensors every step (pytorch_emb.py:56-66): the validated descriptor of the
         # last request is reused when pointers, sizes and dtypes are unchanged (saves ~4 us of host time per call, which
         # is what a 512-bag lookup costs on the device)
@@ -117,10 +147,10 @@ class _TableSet:
         key = (indices.data_ptr(), indices.numel(), indices.dtype, indices.is_contiguous(), indices.device,
                offsets.data_ptr(), offsets.numel(), offsets.dtype, offsets.is_contiguous(), offsets.device, B,
                None if psw is None else (psw.data_ptr(), psw.numel(), psw.dtype, psw.is_contiguous(), psw.device),
-               bag_begin, bag_count, None if d_ptrs is None else d_ptrs.data_ptr())
+               bag_begin, bag_count, None if d_ptrs is None else d_ptrs.data_ptr(), forward and self.layout == "blocked")
         if key == self._req_key:
             return self._req_op
-        op = self._build_request(indices, offsets, B, psw, bag_begin, bag_count, d_ptrs)
+        op = self._build_request(indices, offsets, B, psw, bag_begin, bag_count, d_ptrs, forward)
         self._req_key, self._req_op = key, op
         return op
 
@@ -144,7 +174,7 @@ class _TableSet:
             self._pool_key, self._pool_val = key, (L if bool(torch.equal(offsets[:tb], ramp)) else 0)
         return self._pool_val
 
-    def _build_request(self, indices, offsets, B, psw, bag_begin, bag_count, d_ptrs=None) -> _lib.pm_embbag_batch:
+    def _build_request(self, indices, offsets, B, psw, bag_begin, bag_count, d_ptrs=None, forward: bool = False) -> _lib.pm_embbag_batch:
         _require_device(indices, "indices")
         _require_device(offsets, "offsets")
         if indices.dtype != offsets.dtype or indices.dtype not in _IDTYPE:
@@ -177,13 +207,30 @@ class _TableSet:
         op.offsets = offsets.data_ptr()
         op.per_sample_weights = None if psw is None else psw.data_ptr()
         op.fixed_pooling = 0          # filled in by the sorted backward (fixed_pooling()); the forward does not use it
+        if self.layout == "blocked":
+            Bl, D = self.block_bags, self.dims[0]
+            if forward:
+                # the same arrays read as T * W request tables of batch Bl (include/param_amd.h, pm_embbag_batch, ABI v6)
+                if bag_begin != 0 or (bag_count is not None and bag_count != B) or d_ptrs is not None:
+                    raise ValueError("blocked layout: the forward takes whole-batch requests only")
+                (tabs, rows_v, dims_v, offs_v), W = self.blocked_forward_arrays(B)
+                op.num_tables = self.T * W
+                op.batch = Bl
+                op.bag_begin, op.bag_count = 0, Bl
+                op.tables, op.rows, op.dims, op.out_offsets = tabs.data_ptr(), rows_v.data_ptr(), dims_v.data_ptr(), offs_v.data_ptr()
+                op.table_group = W
+            else:
+                op.grad_block_shift = Bl.bit_length() - 1
+                op.grad_block_extra = (self.T - 1) * Bl * D
+                if Bl == 1 and self.T > 1:
+                    raise ValueError("blocked layout: block_bags must be at least 2")
         return op
 
 
 def _fwd(ts: _TableSet, indices, offsets, B, psw=None, out=None, bag_begin=0, bag_count=None, split_bags: bool = False):
     """``split_bags``: one workgroup per bag with wave-shuffle / LDS partial reductions (``pm_embbag_fwd_split``) -- for
     few, long bags; agrees with the default kernel to fp32 rounding, not bit for bit."""
-    op = ts.request(indices, offsets, B, psw, bag_begin, bag_count)
+    op = ts.request(indices, offsets, B, psw, bag_begin, bag_count, forward=True)
     _, _, shape = ts.out_desc(B)
     if out is None:
         out = torch.empty(shape, dtype=torch.float32, device=ts.device)
@@ -206,12 +253,13 @@ def _fwd_quantized(ts: _TableSet, indices, offsets, B, bitwidth: int, psw=None, 
     rb = quant.host_row_bytes(D, bitwidth)
     if D % 8 or D > 512:
         raise ValueError(f"quantised output needs an embedding dim that is a multiple of 8 and <= 512, got {D}")
-    qshape = (B, ts.T, rb) if ts.layout == "bd" else (ts.T, B, rb)
+    qshape = ((B, ts.T, rb) if ts.layout == "bd" else (ts.T, B, rb) if ts.layout == "tbd" else
+              (B // ts.block_bags, ts.T, ts.block_bags, rb))
     if out is None:
         out = torch.empty(qshape, dtype=torch.uint8, device=ts.device)
     elif out.dtype != torch.uint8 or out.numel() != B * ts.T * rb or not out.is_contiguous() or out.device != ts.device:
         raise ValueError(f"out must be a contiguous uint8 tensor of {B * ts.T * rb} bytes on {ts.device}")
-    op = ts.request(indices, offsets, B, psw, bag_begin, bag_count)
+    op = ts.request(indices, offsets, B, psw, bag_begin, bag_count, forward=True)
     L = _lib.load()
     rc = L.pm_embbag_fwd_quantized(ctypes.byref(op), out.data_ptr(), int(bitwidth), _stream_ptr())
     if rc == _lib.PM_ERR_UNSUPPORTED and (bag_begin, bag_count) in ((0, None), (0, B)):
@@ -454,18 +502,22 @@ class BatchedEmbeddingBagMI355(nn.Module):
 
     ``forward(indices, offsets, per_sample_weights=None)`` uses the TBE request layout
     (indices concatenated table-major, offsets ``[T*B+1]``) and returns ``[B, sum D]``
-    (``layout="bd"``) or ``[T, B, D]`` (``layout="tbd"``, dlrm.py's ``torch.stack`` shape).
+    (``layout="bd"``) or ``[T, B, D]`` (``layout="tbd"``, dlrm.py's ``torch.stack`` shape) or ``[B / block_bags, T, block_bags, D]``
+    (``layout="blocked"``: the send layout of a table-wise sharded exchange -- every peer's chunk contiguous, made of ``[block_bags, D]``
+    runs per table; forward whole-batch requests only).
     """
 
     def __init__(self, rows: Sequence[int], dims, dtype: torch.dtype = torch.float32, device="cuda",
                  layout: str = "bd", init: Optional[str] = "uniform_dlrm", seed: int = 0,
                  learning_rate: float = 0.01, fused_update: bool = True, optimizer: str = "sgd", eps: float = 1.0e-8,
-                 weight_decay: float = 0.0, weight_decay_mode=None, stochastic_rounding: bool = False):
+                 weight_decay: float = 0.0, weight_decay_mode=None, stochastic_rounding: bool = False,
+                 block_bags: Optional[int] = None):
         super().__init__()
         rows = [int(r) for r in rows]
         dims = [int(dims)] * len(rows) if isinstance(dims, int) else [int(d) for d in dims]
         assert len(rows) == len(dims) and len(rows) >= 1
         self.rows, self.dims, self.layout = rows, dims, layout
+        self.block_bags = block_bags      # layout="blocked": [B / block_bags, T, block_bags, D] (the per-rank batch of a sharded exchange)
         self.learning_rate, self.fused_update = learning_rate, fused_update
         if optimizer not in ("sgd", "rowwise_adagrad"):
             raise ValueError('optimizer must be "sgd" or "rowwise_adagrad"')
@@ -517,7 +569,7 @@ class BatchedEmbeddingBagMI355(nn.Module):
 
     def _tables(self) -> _TableSet:
         if self._ts is None or self._ts.ptrs[0] != self.table(0).data_ptr():
-            self._ts = _TableSet([self.table(t) for t in range(len(self.rows))], self.layout)
+            self._ts = _TableSet([self.table(t) for t in range(len(self.rows))], self.layout, self.block_bags)
         return self._ts
 
     def _batch_of(self, offsets, indices=None) -> int:

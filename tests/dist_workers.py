@@ -637,6 +637,83 @@ def sharded_exchange(rank, world, port, n_tables=3):
         dist.destroy_process_group()
 
 
+def sharded_exchange_blocked(rank, world, port):
+    """ShardedEmbeddingExchange with the BLOCKED send layout ([W][T_loc][B_local][D], ABI v6) against the same exchange in the
+    default [W * B_local, T_loc * D] layout: 3 tables per rank, one dim, a power-of-two per-rank batch.  Torch stand-ins write / read
+    each layout; what every rank RECEIVES (per source, per table), the self-check and what the backward accumulates must agree."""
+    from param_amd.comms.pt.pipeline import ShardedEmbeddingExchange
+
+    _env(rank, world, port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        T_loc, D, Bl, L, R = 3, 4, 4, 2, 30
+        B_glob = world * Bl
+        widths = [T_loc * D] * world
+        tables = {(r, t): torch.randn(R, D, generator=torch.Generator().manual_seed(50 * r + t)) for r in range(world) for t in range(T_loc)}
+
+        def request(owner, k):
+            gg = torch.Generator().manual_seed(100 * k + owner)
+            idx = torch.randint(0, R, (T_loc * B_glob * L,), generator=gg)
+            off = torch.arange(T_loc * B_glob + 1, dtype=torch.int64) * L
+            return idx, off
+
+        def pooled_tbd(owner, k):      # [T_loc, B_glob, D]
+            idx, off = request(owner, k)
+            return torch.stack([torch.nn.functional.embedding_bag(idx[t * B_glob * L:(t + 1) * B_glob * L], tables[(owner, t)],
+                                                                  off[:B_glob], mode="sum") for t in range(T_loc)])
+
+        results = {}
+        for layout in ("bd", "blocked"):
+            acc = {t: torch.zeros(R, D) for t in range(T_loc)}
+
+            def lookup(indices, offsets, out, layout=layout):
+                p = pooled_tbd(rank, lookup.k)
+                if layout == "bd":
+                    out.copy_(p.permute(1, 0, 2).reshape(B_glob, T_loc * D))
+                else:
+                    out.view(world, T_loc, Bl, D).copy_(p.view(T_loc, world, Bl, D).permute(1, 0, 2, 3))
+
+            def backward(grad, indices, offsets, layout=layout, acc=acc):
+                g = (grad.view(B_glob, T_loc, D).permute(1, 0, 2) if layout == "bd"
+                     else grad.view(world, T_loc, Bl, D).permute(1, 0, 2, 3).reshape(T_loc, B_glob, D))
+                for t in range(T_loc):
+                    for b in range(B_glob):
+                        for j in range(L):
+                            acc[t][indices[(t * B_glob + b) * L + j]] += g[t, b]
+
+            def make_grad(recv, grad_in):
+                grad_in.copy_(recv * float(rank + 2))
+
+            ex = ShardedEmbeddingExchange(lookup, backward, world, rank, Bl, widths, torch.device("cpu"), make_grad=make_grad,
+                                          layout=layout, dim=D)
+            recvd = []
+            for k in range(3):
+                lookup.k = k
+                ex.step_serial(*request(rank, k))
+                blocks = []
+                for src in range(world):
+                    blk = ex.recv_block(0, src)
+                    blocks.append(blk.clone() if layout == "blocked" else blk.view(Bl, T_loc, D).permute(1, 0, 2).clone())    # -> [T_src, Bl, D]
+                    exp = pooled_tbd(src, k)[:, rank * Bl:(rank + 1) * Bl]
+                    assert torch.allclose(blocks[-1], exp, atol=1e-6), (layout, k, src)
+                recvd.append(torch.stack(blocks))
+                chk = ex.selfcheck(0, lambda src: pooled_tbd(src, k)[0, rank * Bl:(rank + 1) * Bl], exact=False)
+                assert chk["a2a_selfcheck"] == "ok" and chk["peers_checked"] == world, (layout, chk)
+            results[layout] = (torch.stack(recvd), {t: a.clone() for t, a in acc.items()})
+        assert torch.equal(results["bd"][0], results["blocked"][0])
+        for t in range(T_loc):
+            assert torch.allclose(results["bd"][1][t], results["blocked"][1][t], atol=1e-5), t
+            assert results["bd"][1][t].abs().sum() > 0
+        # the blocked layout needs one dim dividing every width and fp32 payloads
+        try:
+            ShardedEmbeddingExchange(lambda *a: None, lambda *a: None, world, rank, Bl, [10] * world, torch.device("cpu"), layout="blocked", dim=4)
+            raise AssertionError("a width that is not a whole number of tables was accepted")
+        except ValueError:
+            pass
+    finally:
+        dist.destroy_process_group()
+
+
 def quantized_collectives(rank, world, port, outdir):
     """``--bitwidth < 32`` on 2 gloo ranks with host tensors: the quantised all_to_allv (uneven per-peer row counts) and the
     list-form all_to_all for every bit width against the numpy oracle of the row formats, the downcast all_reduce, the

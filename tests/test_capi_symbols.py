@@ -30,8 +30,10 @@ def test_library_loads_and_exports_every_symbol():
 
 
 def test_struct_layout_matches_header():
-    # 4 x int32, 4 x int64, 4 pointers, int64, 3 pointers, int64 = 16 + 32 + 32 + 8 + 24 + 8
-    assert ctypes.sizeof(_lib.pm_embbag_batch) == 120
+    # 4 x int32, 4 x int64, 4 pointers, int64, 3 pointers, int64 = 16 + 32 + 32 + 8 + 24 + 8; ABI v6: + 2 x int32 + int64 (blocked layouts)
+    assert ctypes.sizeof(_lib.pm_embbag_batch) == 136
+    assert _lib.pm_embbag_batch.table_group.offset == 120 and _lib.pm_embbag_batch.grad_block_shift.offset == 124
+    assert _lib.pm_embbag_batch.grad_block_extra.offset == 128
     assert _lib.pm_embbag_batch.fixed_pooling.offset == 112
     assert _lib.pm_embbag_batch.tables.offset == 48
     assert _lib.pm_embbag_batch.out_stride.offset == 80

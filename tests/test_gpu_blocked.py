@@ -1,0 +1,139 @@
+"""Blocked send layout ``[W][T][B_local][D]`` (ABI v6, include/param_amd.h ``pm_embbag_batch``) -- GPU parity (``pytest -m gpu``).
+
+The layout of a table-wise sharded exchange (reference: the pooled all-to-all of train/comms/pt/dlrm.py:858-878; the receiver's
+per-source view at :173-175 does not care how a source's chunk is ordered inside): every peer's chunk of the lookup output is one
+contiguous run made of ``[B_local, D]`` runs per table.  Forward: the same request read as T * W request tables of batch B_local
+(no kernel knows about it); backward: T weight tables, batch W * B_local, gradient addressed with a per-block term.  Bars: the
+forward equals the ``[T, B, D]`` forward block by block, bit for bit; the backward leaves the tables of the same gradient given in the
+``[B, sum D]`` layout, bit for bit (sorted, hybrid / fused, row-wise Adagrad), and the atomic kernel within 1e-5.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu_and_lib():
+    import param_amd
+
+    assert torch.cuda.is_available(), "gpu-marked tests need a ROCm device"
+    param_amd.load_library()
+    yield
+    param_amd.set_hybrid_tuning()
+    param_amd.set_forward_persist()
+
+
+def _models(rows, D, Bl, dtype=torch.float32, seed=3, **kw):
+    import param_amd
+
+    mk = lambda lay, **k: param_amd.BatchedEmbeddingBagMI355(rows, D, dtype=dtype, device=DEV, init="normal", layout=lay, seed=seed,  # noqa: E731
+                                                             fused_update=False, **k, **kw)
+    return mk("blocked", block_bags=Bl), mk("tbd"), mk("bd")
+
+
+def _to_blocked(x_tbd, Bl):
+    """[T, B, D] -> [W, T, Bl, D]"""
+    T, B, D = x_tbd.shape
+    return x_tbd.view(T, B // Bl, Bl, D).permute(1, 0, 2, 3).contiguous()
+
+
+@pytest.mark.parametrize("idt", [torch.int64, torch.int32])
+@pytest.mark.parametrize("wdt,D,T", [(torch.float32, 128, 8), (torch.float32, 64, 3), (torch.bfloat16, 128, 5)])
+def test_blocked_forward_equals_tbd_forward_block_by_block(wdt, D, T, idt):
+    from param_amd.indices import tbe_request
+
+    rows = [40_000 + 11 * t for t in range(T)]
+    Bl, W, L = 256, 4, 7
+    B = Bl * W
+    mb, mt, _ = _models(rows, D, Bl, wdt)
+    idx, off = tbe_request(rows, B, L, alpha=1.05, device=DEV, seed=T, index_dtype=idt)
+    psw = torch.randn(idx.numel(), device=DEV)
+    for w_ in (None, psw):
+        ob = mb.lookup(idx, off, w_, batch=B)
+        ot = mt.lookup(idx, off, w_, batch=B)
+        assert tuple(ob.shape) == (W, T, Bl, D)
+        assert torch.equal(ob, _to_blocked(ot, Bl)), (wdt, D, T, w_ is not None)
+    # every peer's chunk is ONE contiguous run of the buffer: chunk w = [T, Bl, D]
+    flat = ob.view(-1)
+    for w in range(W):
+        assert torch.equal(flat[w * T * Bl * D:(w + 1) * T * Bl * D].view(T, Bl, D), ot[:, w * Bl:(w + 1) * Bl])
+    # the persistent forward takes the same (T * W)-table request
+    import param_amd
+
+    param_amd.set_forward_persist(2)
+    assert torch.equal(mb.lookup(idx, off, batch=B), _to_blocked(mt.lookup(idx, off, batch=B), Bl))
+    param_amd.set_forward_persist()
+    with pytest.raises(ValueError):
+        mb.lookup(idx, off, batch=B, bag_begin=Bl, bag_count=Bl)          # whole-batch requests only
+
+
+def test_blocked_forward_quantised_rows():
+    from param_amd import quant
+    from param_amd.indices import tbe_request
+
+    rows, D, Bl, W, L = [30_000] * 4, 128, 128, 2, 5
+    B = Bl * W
+    mb, _, _ = _models(rows, D, Bl)
+    idx, off = tbe_request(rows, B, L, alpha=0.0, device=DEV, seed=1)
+    full = mb.lookup(idx, off, batch=B)
+    for bits in (16, 8):
+        q = mb.lookup_quantized(idx, off, bits, batch=B)
+        assert tuple(q.shape)[:3] == (W, len(rows), Bl)
+        assert torch.equal(q.view(-1), quant.quantize_rows(full, D, bits).view(-1)), bits
+
+
+@pytest.mark.parametrize("alpha_idx", [0.0, 1.05])
+@pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16])
+def test_blocked_backward_equals_bd_backward(wdt, alpha_idx):
+    """same request, same gradient values, given once as [W, T, Bl, D] and once as [B, T * D]: the sorted apply, the fused call
+    (hybrid under uniform indices: bag-major kernel + left-overs) and the atomic kernel read the same numbers"""
+    import param_amd
+    from param_amd.indices import tbe_request
+
+    T, D, Bl, W, L = 8, 128, 512, 4, 10
+    B = Bl * W
+    rows = [300_000] * T
+    idx, off = tbe_request(rows, B, L, alpha=alpha_idx, device=DEV, seed=9)
+    g_tbd = torch.randn(T, B, D, device=DEV)
+    g_blk = _to_blocked(g_tbd, Bl)
+    g_bd = g_tbd.permute(1, 0, 2).reshape(B, T * D).contiguous()
+    for en in (1, 0):                                                       # hybrid offered / not
+        param_amd.set_hybrid_tuning(en)
+        mb, _, md = _models(rows, D, Bl, wdt)
+        mb.scatter_add_(g_blk, idx, off, alpha=-0.25, batch=B)
+        md.scatter_add_(g_bd, idx, off, alpha=-0.25, batch=B)
+        st = mb.sort_status(idx, off, batch=B)
+        assert (st["hybrid_tables"] == T) == (en == 1 and alpha_idx == 0.0), st
+        assert torch.equal(mb.weights.data, md.weights.data), (wdt, alpha_idx, en)
+        # sort aside + presorted apply
+        mb.sort_indices(idx, off, batch=B)
+        mb.scatter_add_(g_blk, idx, off, alpha=0.5, batch=B, presorted=True)
+        md.scatter_add_(g_bd, idx, off, alpha=0.5, batch=B)
+        assert torch.equal(mb.weights.data, md.weights.data), (wdt, alpha_idx, en, "presorted")
+    param_amd.set_hybrid_tuning()
+    if wdt == torch.float32:
+        mb, _, md = _models(rows, D, Bl, wdt)
+        ref = mb.weights.data.clone()
+        mb.scatter_add_(g_blk, idx, off, alpha=-0.25, batch=B, method="atomic")
+        md.scatter_add_(g_bd, idx, off, alpha=-0.25, batch=B)
+        tol = 1e-5 * (ref.abs().max() + 0.25 * g_tbd.abs().max() * 64)
+        assert (mb.weights.data - md.weights.data).abs().max() <= tol
+
+
+def test_blocked_backward_rowwise_adagrad_equals_bd():
+    from param_amd.indices import tbe_request
+
+    T, D, Bl, W, L = 4, 64, 256, 2, 6
+    B = Bl * W
+    rows = [50_000] * T
+    idx, off = tbe_request(rows, B, L, alpha=1.05, device=DEV, seed=2)
+    g_tbd = torch.randn(T, B, D, device=DEV)
+    mb, _, md = _models(rows, D, Bl, optimizer="rowwise_adagrad", learning_rate=0.05)
+    mb.adagrad_step_(_to_blocked(g_tbd, Bl), idx, off, batch=B)
+    md.adagrad_step_(g_tbd.permute(1, 0, 2).reshape(B, T * D).contiguous(), idx, off, batch=B)
+    assert torch.equal(mb.weights.data, md.weights.data)
+    for t in range(T):
+        assert torch.equal(mb.momentum_table(t), md.momentum_table(t))
