@@ -76,6 +76,7 @@ struct UniqueArgs {
     int key_bytes;
     uint32_t* tile_cnt;          // [table][tile_cnt_stride]
     size_t tile_cnt_stride;
+    int bloom_wbits;             // log2 of the words of a table's dup map (hyb_slices x 16 384 words)
 };
 hipError_t bwd_unique_launch_f32(const SortedParams& sp, const KParams& kp, const UniqueArgs& ua, int max_dim, hipStream_t stream);
 hipError_t bwd_unique_launch_bf16(const SortedParams& sp, const KParams& kp, const UniqueArgs& ua, int max_dim, hipStream_t stream);

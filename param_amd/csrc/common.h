@@ -226,7 +226,19 @@ constexpr int kHybMaxTables = 128;              // tables eligible for the hybri
 constexpr int kBloomK = PM_BLOOM_K;             // slices of a table's map = mark workgroups per table (-DPM_BLOOM_K=8: experiment builds)
 constexpr int kBloomWords = (1 << 16) / kBloomK;   // 32-bit words per slice (4 slices: 64 KB each, seen + dup of a slice fill 128 KB of LDS)
 constexpr int kBloomTableWords = kBloomK * kBloomWords;   // 65 536 words = 256 KB per table
-constexpr uint32_t kHybMaxCount = 1u << 18;     // lookups per table beyond which a 2^21-bit map flags too many unique rows
+constexpr uint32_t kHybMaxCount = 1u << 18;     // lookups per table a map of kBloomK slices separates (beyond: a 2^21-bit map flags too many unique rows)
+// Round 5: the map GROWS with the table's lookups -- a rank of an N-GPU table-wise sharded step serves the GLOBAL batch for its
+// tables (N x 8192 bags: 327 K / 655 K / 1.3 M lookups per table at N = 2 / 4 / 8), and at 2^18 the hybrid path was an N = 1
+// optimisation only.  Slices per table (= mark workgroups per table, each rescanning the table's lookups): kBloomK up to 2^18
+// lookups, doubling with the count up to kBloomKMax; the number is a function of the request's sizes alone (N / T), so the
+// workspace query, the sort and the apply agree on it.
+constexpr int kBloomKMax = 64;
+__host__ __device__ inline int hyb_slices(int64_t n_lookups, int T) {
+    const int64_t per = T > 0 ? (n_lookups + T - 1) / T : 0;
+    int k = PM_BLOOM_K;
+    while (k < kBloomKMax && per > static_cast<int64_t>(k) * (kHybMaxCount / PM_BLOOM_K)) k *= 2;
+    return k;
+}
 constexpr uint32_t kHybMinCount = 8192;         // ... and below which a table is not worth three extra kernels
 constexpr int kUniqueBags = 128;                // bags per tile of the bag-major apply: ONE value for the sort-time guard, the apply's launch and
                                                 // the compaction of its per-tile lists (no knob: the three must agree)
@@ -241,13 +253,16 @@ struct HybTable {            // one per table (device): written by the sort's fi
                              // costs that a few small tables do not repay (Criteo uniform: 5 of 26 tables, 24 % of the lookups,
                              // 0.49 -> 0.57 ms)
 };
-__host__ __device__ inline uint32_t bloom_word(uint32_t row) { return (row * 0x9E3779B1u) >> 16; }     // 0 .. kBloomTableWords - 1
+// word of a row in a map of 2^wbits words (wbits = 14 + log2 slices: 16 for the four slices of a table of up to 2^18 lookups)
+__host__ __device__ inline uint32_t bloom_word(uint32_t row, int wbits) { return (row * 0x9E3779B1u) >> (32 - wbits); }
+__host__ __device__ inline int bloom_wbits(int slices) { int b = 14; while ((1 << (b - 14)) < slices) ++b; return b; }
 __host__ __device__ inline uint32_t bloom_mask(uint32_t row) {
     const uint32_t h = row * 0x85EBCA77u;
     return (1u << (h >> 27)) | (1u << ((h >> 22) & 31u)) | (1u << ((h >> 17) & 31u)) | (1u << ((h >> 12) & 31u));
 }
 struct HybArgs {             // hybrid part of a sort request
     int allow;               // 0: every table is classified "sort" and nothing else of the hybrid path runs; 1: on; 2: structural eligibility only (tests)
+    int slices;              // map slices per table (hyb_slices(N, T): a power of two, kBloomK .. kBloomKMax)
 };
 // (the per-table records, the dup bitmaps [min(T, kHybMaxTables)][kBloomTableWords] and the per-tile counts of flagged lookups
 // live in the sort's scratch: seg_sort_hyb_tab / seg_sort_bloom / seg_sort_tile_cnt)

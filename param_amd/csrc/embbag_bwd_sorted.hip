@@ -348,6 +348,7 @@ SegSortRequest seg_request(const KParams& p, const SortPlan& g, SortWs& ws) {
     rq.weighted = g.weighted;
     rq.zero4 = ws.fix_ctl;
     rq.hyb.allow = g.hyb;
+    rq.hyb.slices = hyb_slices(p.N, p.T);
     rq.spin_cap = g_spin_cap.load();
     return rq;
 }
@@ -606,6 +607,7 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
     ua.key_bytes = g.key_bytes;
     ua.tile_cnt = seg_sort_tile_cnt(ws.temp, static_cast<size_t>(p.N), p.T);
     ua.tile_cnt_stride = seg_sort_tile_cnt_stride(static_cast<size_t>(p.N));
+    ua.bloom_wbits = bloom_wbits(hyb_slices(p.N, p.T));
     // The bag-major kernel tiles the request by 128 bags whatever the forward's tiling (32 bags at L = 20; 8 for short-bag
     // requests: 26 624 workgroups for the Criteo request, most of which find a table that did not qualify and leave -- 15 us of
     // dispatch).  Measured at benchmark size, uniform indices, sort + apply ms, fp32 48 tables / bf16 64 tables (round 4, same box

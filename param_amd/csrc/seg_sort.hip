@@ -183,7 +183,10 @@ __global__ void __launch_bounds__(1024) seg_prep_tables_kernel(const void* indic
     // separates, a row count that makes repeats rare under uniform indices -- and if so, request a sample of 2048 lookups spread
     // over the table's slice now, so that their latency passes under the check of the offsets below.
     const int64_t n_rows = rows[t];
-    bool cand = t < kHybMaxTables && !bad && cnt >= kHybMinCount && cnt <= kHybMaxCount && cnt * 8 <= n_rows;     // workgroup-uniform
+    // (lookups <= rows / 4: under uniform indices at most ~22 % of the lookups then sit in rows looked up twice -- the N = 8 rank
+    //  shape, 1.3 M lookups into 10 M rows, has 12 %; round 4's rows / 8 excluded it)
+    bool cand = t < kHybMaxTables && !bad && cnt >= kHybMinCount && cnt <= static_cast<int64_t>(hyb.slices) * (kHybMaxCount / kBloomK) &&
+                cnt * 4 <= n_rows;     // workgroup-uniform
     const bool sample = cand && hyb.allow == 1;                // allow == 2 (tests): structural eligibility is enough; 0: nothing to decide
     uint32_t sr[2] = {0u, 0u};
     if (sample) {
@@ -1395,7 +1398,7 @@ Scratch scratch_layout(void* base, size_t n, int T) {
     s.bstart_all = reinterpret_cast<uint32_t*>(take(4 * static_cast<size_t>(T) * kLbRowWords));
     const size_t th = static_cast<size_t>(T < kHybMaxTables ? T : kHybMaxTables);
     s.hyb_tab = reinterpret_cast<HybTable*>(take(sizeof(HybTable) * static_cast<size_t>(T)));
-    s.bloom = reinterpret_cast<uint32_t*>(take(4 * th * kBloomTableWords));
+    s.bloom = reinterpret_cast<uint32_t*>(take(4 * th * static_cast<size_t>(hyb_slices(static_cast<int64_t>(n), T)) * kBloomWords));
     s.tile_cnt = reinterpret_cast<uint32_t*>(take(4 * th * tile_cnt_stride(n)));
     s.total = off;
     return s;
@@ -1489,9 +1492,9 @@ hipError_t seg_sort_part_a(const SegSortRequest& rq, void* scratch, hipStream_t 
     if (hyb.allow) {
         if (!seg_sort_hybrid_available()) return hipErrorInvalidValue;      // (sort_indices asks first and does not offer the path then)
         const int th = rq.T < kHybMaxTables ? rq.T : kHybMaxTables;
-        const unsigned grid = static_cast<unsigned>(kXcds * kBloomK * ((th + kXcds - 1) / kXcds));
+        const unsigned grid = static_cast<unsigned>(kXcds * hyb.slices * ((th + kXcds - 1) / kXcds));
         hipLaunchKernelGGL(hyb_mark_kernel, dim3(grid), dim3(kMarkThreads), 2 * kBloomWords * 4, stream, s.desc, s.hyb_tab, rq.indices, rq.idx64, th,
-                           rq.T, rq.N, s.bloom);
+                           rq.T, rq.N, s.bloom, hyb.slices);
     }
     return hipGetLastError();
 }
@@ -1508,8 +1511,9 @@ hipError_t seg_sort_part_b(const SegSortRequest& rq, int mode, K* keys_a, K* key
         // the flagged lookups of the hybrid tables (listed per tile by the bag-major apply) become those tables' segments of built pairs
         if (tiles.tiles_per_table < 1 || tiles.tiles_per_table > kCompactMaxTiles) return hipErrorInvalidValue;
         const int th = rq.T < kHybMaxTables ? rq.T : kHybMaxTables;
-        hipLaunchKernelGGL((hyb_compact_kernel<K>), dim3(th * kCompactParts), dim3(kT), 0, stream, s.desc, s.hyb_tab, th, s.tile_cnt,
-                           tile_cnt_stride(n), tiles, keys_b, vals_b, keys_a, vals_a);
+        const int parts = compact_parts(tiles.tiles_per_table);
+        hipLaunchKernelGGL((hyb_compact_kernel<K>), dim3(th * parts), dim3(kT), 0, stream, s.desc, s.hyb_tab, th, s.tile_cnt,
+                           tile_cnt_stride(n), tiles, keys_b, vals_b, keys_a, vals_a, parts);
     }
     {
         const int chunks = rq.bag_count > 0 ? static_cast<int>((rq.bag_count + kBuildBags - 1) / kBuildBags) : 0;

@@ -424,3 +424,32 @@ def test_sort_aside_consumes_the_request_and_only_fused_calls_defer(coracle):
     aside.scatter_add_(grad, work, off, alpha=-0.5, batch=B, presorted=True)      # ... and the apply still applies what was sorted
     for t in range(len(rows)):
         assert np.array_equal(aside.table(t).cpu().numpy(), exp[t]), t
+
+
+@pytest.mark.parametrize("lookups_per_table,rows", [(327_680, 3_000_000), (655_360, 6_000_000), (1_310_720, 10_000_000)])
+def test_hybrid_scales_its_dup_maps_with_the_tables_lookups(lookups_per_table, rows):
+    """Round 5: a rank of an N-GPU table-wise sharded step serves the GLOBAL batch for its tables -- 327 K / 655 K / 1.3 M lookups per
+    table at N = 2 / 4 / 8 -- and round 4's 2^18-lookup limit made the hybrid path an N = 1 optimisation.  The dup map now grows with
+    the table's lookups (8 / 16 / 32 slices of 16 384 words): such tables go hybrid, and the fused call leaves the tables of the fully
+    sorted path bit for bit (rows looked up <= 256 times: every row here)."""
+    import param_amd
+
+    T, D, L = 2, 32, 20
+    B = lookups_per_table // L
+    idx, off = _request([rows] * T, B, L, 0.0, 11)
+    grad = torch.randn(B, T * D, device=DEV)
+    out = {}
+    for en in (1, 0):
+        param_amd.set_hybrid_tuning(en)
+        m = _model([rows] * T, D, seed=8)
+        m.scatter_add_(grad, idx, off, alpha=-0.125, batch=B)
+        st = m.sort_status(idx, off, batch=B)
+        if en:
+            assert st["hybrid_launched"] == 1 and st["hybrid_tables"] == T, st
+            assert st["pairs_sorted"] < 0.3 * idx.numel(), st            # true repeats (5-12 % of the lookups) + ~1.5 % false positives
+        else:
+            assert st["hybrid_tables"] == 0 and st["pairs_sorted"] == idx.numel(), st
+        out[en] = m.weights.data.clone()
+        del m
+    param_amd.set_hybrid_tuning()
+    assert torch.equal(out[1], out[0])
