@@ -107,7 +107,9 @@ def test_no_experiment_branches_in_the_product_kernels():
             continue
         text = open(path).read()
         assert not re.search(r"PM_[A-Z0-9_]*EXP\b", text), path
-        assert "PM_FWD_STORE" not in text, path
+        assert "PM_FWD_STORE" not in text and "PM_FIX_TRACE" not in text, path
+        if not path.endswith("capi.hip"):
+            assert not re.search(r"(?<![a-z_])printf\s*\(", text), f"{path}: device-side printf"
     capi = open(os.path.join(root, "param_amd", "csrc", "capi.hip")).read()
     body = capi[capi.index("int make_params("):]
     assert "getenv" not in body, "capi.hip: getenv on a launch path"
