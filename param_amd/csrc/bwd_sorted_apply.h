@@ -17,9 +17,12 @@ constexpr int kFixGrid = 2048;      // workgroups of the fix-up kernel: one list
 constexpr int kMaxTablesLds = 1024;  // per-table metadata staged in LDS up to this many tables
 
 struct ChunkRec {
-    uint32_t lead_len;   // positions at the start of the chunk continuing a run begun earlier (0: none)
+    uint32_t lead_len;   // positions at the start of the chunk continuing a run begun earlier (0: none); bit 31 (kJoinedBit) on a
+                         // tile's first chunk: the whole TILE lies inside one run and that chunk's leading partial is the tile's sum
     uint32_t trail_len;  // positions at the end of the chunk starting a run that continues (0: none)
 };
+
+constexpr uint32_t kJoinedBit = 0x80000000u;
 
 struct SortedParams {
     ChunkRec* recs;          // per-chunk piece lengths of boundary-crossing runs (main -> fix-up)
@@ -60,6 +63,8 @@ struct SortedParams {
     int32_t xcd;             // 1: XCD-affine block -> tile mapping (needs seg_tiles); 2: XCD-contiguous (any request)
     const uint32_t* d_n;     // not NULL: the number of sorted pairs lives on the device (<= n), written by the segmented sort
     int32_t unique_wgs_per_cu;   // bag-major apply: > 0 = a grid of this many workgroups per CU that loop over the tiles (0: one per tile)
+    int32_t join_tiles;      // 1: a tile that lies wholly inside one run hands the fix-up ONE partial sum instead of one per chunk (set by
+                             // the apply's launcher: it needs every lane group to make the same number of column passes)
 };
 
 
