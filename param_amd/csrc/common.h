@@ -294,6 +294,8 @@ struct SegSortRequest {
     bool weighted;           // values = lookup positions (+ bag_of), every table through the key-building kernel
     uint32_t* zero4;         // not NULL: four words the sort's first kernel sets to zero (the apply's work-list control words)
     HybArgs hyb;
+    uint32_t* queue_a;       // hybrid: two idle arrays of N words each for the mark kernel's per-slice row queues (the sort's value
+    uint32_t* queue_b;       // buffers: nothing else touches them before the bag-major apply); NULL: every slice scans its table
     uint32_t spin_cap;       // look-back polls before a walk gives up (0 = default)
 };
 size_t seg_sort_scratch_bytes(size_t n_max, int T);

@@ -349,6 +349,8 @@ SegSortRequest seg_request(const KParams& p, const SortPlan& g, SortWs& ws) {
     rq.zero4 = ws.fix_ctl;
     rq.hyb.allow = g.hyb;
     rq.hyb.slices = hyb_slices(p.N, p.T);
+    rq.queue_a = ws.vals_a;
+    rq.queue_b = ws.vals_b;
     rq.spin_cap = g_spin_cap.load();
     return rq;
 }

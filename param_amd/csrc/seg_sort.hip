@@ -166,11 +166,12 @@ __device__ __forceinline__ void wave_lds_fence() {
 // prep 1: one workgroup (1024 threads) per table
 __global__ void __launch_bounds__(1024) seg_prep_tables_kernel(const void* indices, const void* offsets, int idx64, const int64_t* rows, int T,
                                                                int64_t B, int64_t N, int64_t bag_begin, int64_t bag_count, int force_ragged,
-                                                               SegDesc* desc, uint32_t* zero4, const HybArgs hyb, HybTable* hyb_tab) {
+                                                               SegDesc* desc, uint32_t* zero4, const HybArgs hyb, HybTable* hyb_tab, uint32_t* qtail) {
     __shared__ uint32_t s_sample[2048];      // classification: 2^16 hashed bits
     __shared__ uint32_t s_rep;
     const int t = blockIdx.x;
     if (zero4 && t == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0u;
+    if (qtail && t < kHybMaxTables && static_cast<int>(threadIdx.x) < hyb.slices) qtail[static_cast<size_t>(t) * hyb.slices + threadIdx.x] = 0u;   // hyb_part_kernel's queue lengths
     const int64_t TB = static_cast<int64_t>(T) * B;
     const int64_t g0 = static_cast<int64_t>(t) * B + bag_begin;
     auto off_at = [&](int64_t g) -> int64_t { return g < TB ? load_index(offsets, g, idx64) : N; };
@@ -1373,6 +1374,7 @@ struct Scratch {
     HybTable* hyb_tab;       // hybrid backward: per-table records
     uint32_t* bloom;         // ... dup bitmaps of the first kHybMaxTables tables
     uint32_t* tile_cnt;      // ... flagged lookups per tile of the bag-major apply, [T_h][tile_cnt_stride]
+    uint32_t* qtail;         // ... rows dealt to the queue of (table, slice), [T_h][slices]
     size_t total;
 };
 
@@ -1400,6 +1402,7 @@ Scratch scratch_layout(void* base, size_t n, int T) {
     s.hyb_tab = reinterpret_cast<HybTable*>(take(sizeof(HybTable) * static_cast<size_t>(T)));
     s.bloom = reinterpret_cast<uint32_t*>(take(4 * th * static_cast<size_t>(hyb_slices(static_cast<int64_t>(n), T)) * kBloomWords));
     s.tile_cnt = reinterpret_cast<uint32_t*>(take(4 * th * tile_cnt_stride(n)));
+    s.qtail = reinterpret_cast<uint32_t*>(take(4 * th * static_cast<size_t>(kBloomKMax)));
     s.total = off;
     return s;
 }
@@ -1488,13 +1491,31 @@ hipError_t seg_sort_part_a(const SegSortRequest& rq, void* scratch, hipStream_t 
     HybArgs hyb = rq.hyb;
     if (rq.weighted) hyb.allow = 0;
     hipLaunchKernelGGL(seg_prep_tables_kernel, dim3(rq.T), dim3(1024), 0, stream, rq.indices, rq.offsets, rq.idx64, rq.rows, rq.T, rq.B, rq.N,
-                       rq.bag_begin, rq.bag_count, rq.weighted ? 1 : 0, s.desc, rq.zero4, hyb, s.hyb_tab);
+                       rq.bag_begin, rq.bag_count, rq.weighted ? 1 : 0, s.desc, rq.zero4, hyb, s.hyb_tab, s.qtail);
     if (hyb.allow) {
         if (!seg_sort_hybrid_available()) return hipErrorInvalidValue;      // (sort_indices asks first and does not offer the path then)
         const int th = rq.T < kHybMaxTables ? rq.T : kHybMaxTables;
+        // deal the candidate tables' rows out to per-slice queues first (hyb_part_kernel): PARAM_AMD_HYB_PART = 0 never, 1 always,
+        // else (default) from `kPartMinSlices` slices per table on -- see the measurements in seg_hybrid.inc
+        static const int part_env = [] { const char* e = getenv("PARAM_AMD_HYB_PART"); return e ? atoi(e) : -1; }();          // once per process
+        const bool part = rq.queue_a && rq.queue_b && part_env != 0 && (part_env == 1 || hyb.slices >= kPartMinSlices);
+        if (part) {
+            const unsigned pgrid = static_cast<unsigned>((rq.N + kPartChunk - 1) / kPartChunk);
+#define PM_LAUNCH_PART(NB_)                                                                                                               \
+    hipLaunchKernelGGL((hyb_part_kernel<NB_>), dim3(pgrid), dim3(kMarkThreads), 0, stream, s.desc, s.hyb_tab, rq.indices, rq.idx64, th, rq.N, \
+                       hyb.slices, rq.queue_a, rq.queue_b, s.qtail)
+            switch (hyb.slices) {
+                case 4: PM_LAUNCH_PART(2); break;
+                case 8: PM_LAUNCH_PART(3); break;
+                case 16: PM_LAUNCH_PART(4); break;
+                case 32: PM_LAUNCH_PART(5); break;
+                default: PM_LAUNCH_PART(6); break;
+            }
+#undef PM_LAUNCH_PART
+        }
         const unsigned grid = static_cast<unsigned>(kXcds * hyb.slices * ((th + kXcds - 1) / kXcds));
         hipLaunchKernelGGL(hyb_mark_kernel, dim3(grid), dim3(kMarkThreads), 2 * kBloomWords * 4, stream, s.desc, s.hyb_tab, rq.indices, rq.idx64, th,
-                           rq.T, rq.N, s.bloom, hyb.slices);
+                           rq.T, rq.N, s.bloom, hyb.slices, part ? rq.queue_a : nullptr, part ? rq.queue_b : nullptr, part ? s.qtail : nullptr);
     }
     return hipGetLastError();
 }

@@ -453,3 +453,39 @@ def test_hybrid_scales_its_dup_maps_with_the_tables_lookups(lookups_per_table, r
         del m
     param_amd.set_hybrid_tuning()
     assert torch.equal(out[1], out[0])
+
+
+@pytest.mark.parametrize("idt", [torch.int64, torch.int32])
+def test_rows_dealt_out_to_slice_queues_overflow_and_batch_slices(idt):
+    """Round 5, hyb_part_kernel: from 8 map slices per table on (> 2^18 lookups) the candidate tables' rows are dealt out to one queue
+    per (table, slice) and the mark workgroups read their queue only.  A queue holds twice a slice's mean share: here half of table
+    0's lookups are ONE row (forced eligibility), its slice overflows and is scanned the old way; table 1 is uniform.  Every row
+    but the hot one keeps the fully sorted path's bits; the hot row (a run of 164 K lookups: chunk partials, whose boundaries
+    follow what else is in the sorted arrays) stays within 1e-5.  Then the same through a batch slice."""
+    import param_amd
+
+    T, D, L, R = 2, 32, 20, 3_000_000
+    B = 16384                                                          # 327 680 lookups per table: 8 slices
+    idx, off = _request([R] * T, B, L, 0.0, 21, index_dtype=idt)
+    idx = idx.clone()
+    idx[:B * L:2] = 7                                                  # every other lookup of table 0
+    grad = torch.randn(B, T * D, device=DEV)
+    for kw in ({}, {"bag_begin": 1024, "bag_count": B - 2048}):
+        out = {}
+        for en in (2, 0):
+            param_amd.set_hybrid_tuning(en)
+            m = _model([R] * T, D, seed=8)
+            m.scatter_add_(grad, idx, off, alpha=-0.125, batch=B, **kw)
+            st = m.sort_status(idx, off, batch=B, **kw)
+            assert st["hybrid_tables"] == (T if en else 0), (st, kw)
+            out[en] = [m.table(t).clone() for t in range(T)]
+            del m
+        assert torch.equal(out[2][1], out[0][1]), kw
+        keep = torch.ones(R, dtype=torch.bool, device=DEV)
+        keep[7] = False
+        assert torch.equal(out[2][0][keep], out[0][0][keep]), kw
+        n_hot = (B * L // 2) if not kw else ((B - 2048) * L // 2)
+        tol = 1e-5 * (0.125 * n_hot * 4.0 + 4.0)                       # |g| < 4 practically: sum of |contribution| bound
+        assert (out[2][0][7] - out[0][0][7]).abs().max() <= tol, kw
+    param_amd.set_hybrid_tuning()
+
