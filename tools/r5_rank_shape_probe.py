@@ -17,8 +17,8 @@ from param_amd.indices import tbe_request  # noqa: E402
 T = int(os.environ.get("PROBE_TABLES", "8"))
 W = {8: 8, 12: 4, 16: 4, 24: 2, 32: 2}[T]
 dev = torch.device("cuda", 0)
-R, D, Bl, L = 10_000_000, 128, 8192, 20
-B = Bl * W
+R, D, Bl, L = int(os.environ.get("PROBE_ROWS", "10000000")), 128, 8192, 20
+B = int(os.environ.get("PROBE_BATCH", str(Bl * W)))      # (PROBE_BATCH / PROBE_ROWS: shapes off the N-GPU line, to separate bags per table from tables)
 m = param_amd.BatchedEmbeddingBagMI355([R] * T, D, device=dev, init="normal", layout="bd", seed=7, fused_update=False)
 grad = torch.randn(B, T * D, device=dev)
 n = T * B * L
