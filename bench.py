@@ -480,6 +480,12 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python -m torch.distributed.run "
                          f"--nproc-per-node {a.gpus} bench.py --gpus {a.gpus} ...) or run `python bench.py --gpus {a.gpus}` with "
                          f"WORLD_SIZE unset, which launches itself")
+    # PARAM_AMD_BENCH_SHARED_GPU=1 (a development aid, never a measurement): every rank of an N > 1 launch uses GPU 0 and the ranks
+    # talk over gloo -- the whole N > 1 flow of this file (table partition, split lists, exchange self-check between REAL ranks, the
+    # max-over-ranks clocks, the JSON line) on a one-GPU box; the line it prints says so (`config.shared_gpu_debug`)
+    shared_gpu = os.environ.get("PARAM_AMD_BENCH_SHARED_GPU", "0") == "1" and world > 1
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -491,7 +497,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" IS RCCL on ROCm
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" IS RCCL on ROCm
         assert dist.get_world_size() == a.gpus, f"process group of {dist.get_world_size()} ranks for --gpus {a.gpus}"
         assert torch.cuda.device_count() > local_rank, f"rank {rank}: no GPU {local_rank} on this node"
 
@@ -688,6 +697,8 @@ def main():
             "lookups_per_step": lookups_step_all,
         },
     }
+    if shared_gpu:
+        result["config"]["shared_gpu_debug"] = f"{world} ranks on ONE GPU over gloo (PARAM_AMD_BENCH_SHARED_GPU=1): a flow check, not a measurement"
 
     # ---- roofline of the dominant kernel (forward lookup) ---------------------------------------------------
     if not multi:

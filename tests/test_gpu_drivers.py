@@ -413,3 +413,32 @@ def test_graph_launches_sweep_single_gpu():
     small_e = [r["p50_us"] for r in eager if r["memSize"] <= 65536]
     small_g = [r["p50_us"] for r in graph if r["memSize"] <= 65536]
     assert sum(small_g) < sum(small_e), (small_g, small_e)
+
+
+@pytest.mark.parametrize("n,extra,split", [(2, ["--tables", "16", "--rows", "1000000"], [8, 8]),
+                                           (4, ["--tables", "26", "--rows", "400000"], [7, 7, 6, 6]),
+                                           (2, ["--tables", "10", "--rows", "1000000", "--send-layout", "blocked"], [5, 5])])
+def test_bench_multi_rank_flow_on_one_gpu(n, extra, split, tmp_path):
+    """bench.py's N > 1 flow with REAL ranks: `torch.distributed.run` starts n processes, PARAM_AMD_BENCH_SHARED_GPU=1 puts all of
+    them on GPU 0 and lets them talk over gloo (a flow check, and the line says so) -- table partition (the reference's
+    `get_split_lengths_by_len`, dlrm.py:390-398: 26 tables on 4 ranks = [7, 7, 6, 6]), split lists, the exchange self-check (every rank
+    rebuilds every peer's block from seeds: bit-equal), max-over-ranks clocks, ONE JSON line from rank 0."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PARAM_AMD_BENCH_SHARED_GPU"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "2",
+           "--no-cpu-baseline", "--no-extra", "--batch", "2048"] + extra
+    r = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["tables_per_gpu"] == split and "shared_gpu_debug" in d["config"]
+    sc = d["all_to_all"]["selfcheck"]
+    assert sc["a2a_selfcheck"] == "ok" and sc["ranks"] == n and sc["min_peers_checked_over_ranks"] == n and sc["max_abs_diff"] == 0.0, sc
+    assert d["fwd_bwd_step"]["lookups_per_s"] > 0
