@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PM_ABI_VERSION 6
+#define PM_ABI_VERSION 7
 
 typedef void* pm_stream_t;
 
@@ -225,6 +225,10 @@ int pm_embbag_sorted_pairs(const pm_embbag_batch* op, int64_t max_rows, const vo
  *   pairs_sorted       lookups that went through the sort (all of them, or the hybrid path's left-overs)
  *   hybrid_tables      tables whose step took the hybrid path (rows looked up once applied bag-major, see pm_set_hybrid_tuning)
  *   hybrid_launched    0: the hybrid kernels were not launched for this sort (off, weighted or tiny request); else the mode they ran in
+ *   lds_pairs          (ABI v7) flagged lookups of hybrid tables that were sorted and applied inside LDS by the left-over kernel
+ *                      (pm_set_hybrid_rest) and therefore never reached the sort: a hybrid step applies
+ *                      num_indices - pairs_sorted - lds_pairs lookups bag-major
+ *   lds_tables         (ABI v7) hybrid tables finished that way
  * Replaces nothing of the reference: it reports on the replacement for the sort inside aten::_embedding_bag_dense_backward
  * (call sites as pm_embbag_bwd_sorted).
  */
@@ -233,6 +237,8 @@ typedef struct pm_sort_status {
     uint32_t pairs_sorted;
     uint32_t hybrid_tables;
     uint32_t hybrid_launched;
+    uint32_t lds_pairs;
+    uint32_t lds_tables;
 } pm_sort_status;
 int pm_embbag_sort_status(const pm_embbag_batch* op, int64_t max_rows, const void* workspace, pm_sort_status* out,
                           pm_stream_t stream);
@@ -417,6 +423,19 @@ int pm_set_sort_tuning(int32_t mode);
  * (which only the library can be) it returns PM_ERR_INVALID.
  */
 int pm_set_hybrid_tuning(int32_t enable, int64_t lookback_spin_cap);
+
+/*
+ * ABI v7.  What the bag-major kernel of the hybrid backward leaves of a table -- the lookups its dup map flags, ~3 % of a
+ * uniform-index request -- used to go through the whole key sort and the sorted apply: nine small dependent launches for a few
+ * thousand pairs per table (7 % of the fp32 benchmark step, 15 % of the bf16 one).  mode 1 (the default at -1; PARAM_AMD_HYB_REST=0
+ * in the environment changes it): ONE launch finishes them -- every hybrid table with at most 8192 flagged lookups is sorted
+ * by row inside LDS (stable: a row's lookups stay in lookup order) and applied run by run, destination row read once and written
+ * once, the arithmetic and order of the sorted apply (bit-identical to the sequential oracle for any run length); tables with
+ * more left-overs, and everything when mode is 0, take the round-5 route (lists compacted, key sort, sorted apply).  Which
+ * tables were finished is decided on the device from the request alone; the sort's launches follow either way and find no pairs
+ * for the tables that were.  Read when the apply is issued.  Same results in either mode for rows looked up at most 256 times.
+ */
+int pm_set_hybrid_rest(int32_t mode);
 
 /*
  * Forward with a row-wise QUANTISED output: the pooled vector of (bag b, table t) is written as one quantised row

@@ -13,7 +13,7 @@ import threading
 
 PM_F32, PM_BF16, PM_F16, PM_I32, PM_I64 = 0, 1, 2, 10, 11
 PM_OK, PM_ERR_INVALID, PM_ERR_UNSUPPORTED, PM_ERR_HIP, PM_ERR_INDEX = 0, -1, -2, -3, -4
-PM_ABI_VERSION = 6
+PM_ABI_VERSION = 7
 PM_WD_NONE, PM_WD_L2, PM_WD_DECOUPLE = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -55,6 +55,7 @@ EXPORTED_SYMBOLS = (
     "pm_radix_sort_pairs",
     "pm_embbag_sort_status",
     "pm_set_hybrid_tuning",
+    "pm_set_hybrid_rest",
 )
 
 
@@ -80,6 +81,8 @@ class pm_sort_status(ctypes.Structure):
         ("pairs_sorted", ctypes.c_uint32),
         ("hybrid_tables", ctypes.c_uint32),
         ("hybrid_launched", ctypes.c_uint32),
+        ("lds_pairs", ctypes.c_uint32),
+        ("lds_tables", ctypes.c_uint32),
     ]
 
 
@@ -208,6 +211,8 @@ def load() -> ctypes.CDLL:
         L.pm_embbag_sort_status.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, vp, ctypes.POINTER(pm_sort_status), vp]
         L.pm_set_hybrid_tuning.restype = ctypes.c_int
         L.pm_set_hybrid_tuning.argtypes = [i32, i64]
+        L.pm_set_hybrid_rest.restype = ctypes.c_int
+        L.pm_set_hybrid_rest.argtypes = [i32]
         if L.pm_abi_version() != PM_ABI_VERSION:
             raise ImportError(f"{LIB_PATH}: ABI version {L.pm_abi_version()} != {PM_ABI_VERSION}")
         _lib = L
@@ -266,3 +271,9 @@ def set_hybrid_tuning(enable: int = -1, lookback_spin_cap: int = 0) -> None:
     enable 0 off / 1 on (default; tables classified on the device at every sort) / 2 every structurally eligible table (tests);
     lookback_spin_cap > 0 lowers the number of polls after which a look-back walk counts for its predecessor (tests)."""
     check(load().pm_set_hybrid_tuning(enable, lookback_spin_cap))
+
+
+def set_hybrid_rest(mode: int = -1) -> None:
+    """``pm_set_hybrid_rest``: 1 (default) = what the bag-major kernel leaves of a hybrid table (the flagged lookups, at most 8192 of
+    them) is sorted in LDS and applied by ONE launch; 0 = the lists go through the key sort and the sorted apply (round 5)."""
+    check(load().pm_set_hybrid_rest(mode))

@@ -87,4 +87,22 @@ hipError_t bwd_unique_launch_f32(const SortedParams& sp, const KParams& kp, cons
 hipError_t bwd_unique_launch_bf16(const SortedParams& sp, const KParams& kp, const UniqueArgs& ua, int max_dim, hipStream_t stream);
 hipError_t bwd_unique_launch_f16(const SortedParams& sp, const KParams& kp, const UniqueArgs& ua, int max_dim, hipStream_t stream);
 
+// Round 6: the hybrid tables' left-overs that hyb_stage_kernel staged (common.h) -- sorted in LDS by each of `parts` workgroups of a
+// table (1024 threads, stable 8-bit rounds on the row bits) and applied run by run in place, every workgroup a slice of the sorted
+// positions.  Before: compact 8 + prep 2 5 + histogram 6.5 + scan 5 + 3 passes 28 + sorted apply 65 + fix-up 5 us for the 226 K pairs
+// of the uniform benchmark request.
+struct RestArgs {
+    const HybTable* hyb_tab;
+    int T_h;                     // tables that can be hybrid (min(T, kHybMaxTables))
+    const uint32_t* stage;       // [T_h][2][kRestCap]
+    const uint32_t* rest_n;      // [T_h]
+    const uint32_t* rbits;       // &SegDesc[0].rbits, stride sizeof(SegDesc) / 4 words: bits of table t's row ids
+    int rbits_stride;
+    int parts;                   // workgroups per table
+};
+int rest_parts(int T_h, int tiles_per_table);
+hipError_t bwd_rest_launch_f32(const SortedParams& sp, const KParams& kp, const RestArgs& ra, int max_dim, hipStream_t stream);
+hipError_t bwd_rest_launch_bf16(const SortedParams& sp, const KParams& kp, const RestArgs& ra, int max_dim, hipStream_t stream);
+hipError_t bwd_rest_launch_f16(const SortedParams& sp, const KParams& kp, const RestArgs& ra, int max_dim, hipStream_t stream);
+
 }  // namespace pm

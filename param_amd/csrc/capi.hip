@@ -382,13 +382,19 @@ int pm_set_hybrid_tuning(int32_t enable, int64_t lookback_spin_cap) {
     return PM_OK;
 }
 
+int pm_set_hybrid_rest(int32_t mode) {
+    if (mode < -1 || mode > 1) return fail(PM_ERR_INVALID, "mode must be -1 (default), 0 or 1");
+    pm::set_hybrid_rest(mode);
+    return PM_OK;
+}
+
 int pm_embbag_sort_status(const pm_embbag_batch* op, int64_t max_rows, const void* workspace, pm_sort_status* out, pm_stream_t stream) {
     pm::KParams p;
     int rc = make_params(op, op ? op->weight_dtype : -1, p);
     if (rc != PM_OK) return rc;
     if (max_rows < 1 || max_rows > (1LL << 31)) return fail(PM_ERR_INVALID, "max_rows must be in [1, 2^31]");
     if (!workspace || !out) return fail(PM_ERR_INVALID, "NULL argument");
-    uint32_t v[4] = {0, 0, 0, 0};
+    uint32_t v[6] = {0, 0, 0, 0, 0, 0};
     const hipError_t h = pm::sort_status(p, max_rows, op->max_dim, workspace, static_cast<hipStream_t>(stream), v);
     if (h == hipErrorInvalidValue) return fail(PM_ERR_INVALID, "no sort has been recorded for this workspace");
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_sort_status");
@@ -396,6 +402,8 @@ int pm_embbag_sort_status(const pm_embbag_batch* op, int64_t max_rows, const voi
     out->pairs_sorted = v[1];
     out->hybrid_tables = v[2];
     out->hybrid_launched = v[3];
+    out->lds_pairs = v[4];
+    out->lds_tables = v[5];
     return PM_OK;
 }
 

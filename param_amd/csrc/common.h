@@ -247,7 +247,7 @@ bool seg_sort_hybrid_available();               // the mark kernel's 128 KB of d
 struct HybTable {            // one per table (device): written by the sort's first kernel and by the compaction
     uint32_t mode;           // 0: every lookup through the sort; 1: hybrid.  Final verdict, written by hyb_mark_kernel's first workgroup
     uint32_t pooling;        // the table's pooling factor (hybrid tables have one)
-    uint32_t n_dup;          // lookups left to the sort (hybrid tables: written by hyb_compact_kernel)
+    uint32_t n_dup;          // lookups left to the sort (hybrid tables: written by hyb_rest_kernel; 0 for a table it finished in LDS)
     uint32_t cand;           // the table qualifies on its own (seg_prep_tables_kernel); it goes hybrid if the qualifying tables
                              // together hold at least half of the request's lookups -- the mark + bag-major kernels have fixed
                              // costs that a few small tables do not repay (Criteo uniform: 5 of 26 tables, 24 % of the lookups,
@@ -266,12 +266,16 @@ struct HybArgs {             // hybrid part of a sort request
 };
 // (the per-table records, the dup bitmaps [min(T, kHybMaxTables)][kBloomTableWords] and the per-tile counts of flagged lookups
 // live in the sort's scratch: seg_sort_hyb_tab / seg_sort_bloom / seg_sort_tile_cnt)
-struct HybTiles {            // how the bag-major apply tiled the request when it listed the flagged lookups (part B's compaction)
+struct HybTiles {            // how the bag-major apply tiled the request when it listed the flagged lookups (hyb_rest_kernel reads the lists)
     int bags_per_tile;       // KParams::bags_per_block of the apply
     int tiles_per_table;
 };
 // seg_sort.hip: the sorted backward's key sort over per-table segments established on the device
 constexpr int kSegSortMaxTables = 1024;
+#ifndef PM_SEG_TILE
+#define PM_SEG_TILE 4096
+#endif
+constexpr int kSegTile = PM_SEG_TILE;   // elements per radix tile of the key sort (16 per thread); -DPM_SEG_TILE=2048: experiment builds
 struct SegDesc {             // one per table, written by the sort's prep kernels (device memory, inside the sort scratch)
     uint32_t in_start;       // first lookup of the (sliced) table in the request's index array
     uint32_t count;          // lookups of the (sliced) table
@@ -307,13 +311,14 @@ const SegDesc* seg_sort_desc(const void* scratch, size_t n_max, int T);
 const uint32_t* seg_sort_count(const void* scratch, size_t n_max, int T);   // device uint32: pairs in the sorted arrays
 // The sort in two parts: part A (the tables' segments and verdicts + the hybrid tables' dup bitmaps: all the bag-major apply
 // needs) and part B (everything else).  When the hybrid kernels are launched (rq.hyb.allow) part B runs inside the APPLY call,
-// after the bag-major kernel, which lists the flagged lookups tile by tile as a by-product of its own staging (`tiles` says how
-// it tiled); otherwise seg_sort_pairs = A then B.
+// after the bag-major kernel -- which lists the flagged lookups tile by tile as a by-product of its own staging -- and
+// hyb_rest_kernel, which finishes the hybrid tables' lists in LDS or compacts them into the a buffers as built pairs (`hybrid_done`
+// says that has happened); otherwise seg_sort_pairs = A then B.
 template <typename K>
 hipError_t seg_sort_part_a(const SegSortRequest& rq, void* scratch, hipStream_t stream);
 template <typename K>
 hipError_t seg_sort_part_b(const SegSortRequest& rq, int mode, K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t* bag_of,
-                           void* scratch, hipStream_t stream, HybTiles tiles = HybTiles{0, 0});
+                           void* scratch, hipStream_t stream, bool hybrid_done = false);
 template <typename K>
 hipError_t seg_sort_pairs(const SegSortRequest& rq, int mode, K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t* bag_of,
                           void* scratch, hipStream_t stream);
@@ -322,6 +327,21 @@ const HybTable* seg_sort_hyb_tab(const void* scratch, size_t n_max, int T);
 const uint32_t* seg_sort_bloom(const void* scratch, size_t n_max, int T);
 uint32_t* seg_sort_tile_cnt(const void* scratch, size_t n_max, int T);     // [T][B / 4 + 1] at most: flagged lookups per tile of the bag-major apply
 size_t seg_sort_tile_cnt_stride(size_t n_max);
+uint32_t* seg_sort_rest_stat(void* scratch, size_t n_max, int T);         // two device words: pairs / tables hyb_rest_kernel finished in LDS (zeroed by every sort)
+// Round 6: what the bag-major kernel left of a hybrid table -- the flagged lookups it listed tile by tile, ~3 % of a uniform
+// request -- is STAGED by hyb_stage_kernel (seg_hybrid.inc): a table with at most kRestCap of them gets its lists copied back to
+// back (list = request-position order) as (row, bag) into its own slot of a staging area and its sort segment emptied; a table
+// with more gets them compacted into the sort's a buffers as "n built pairs" (what round 5 did for every table).  hyb_rest_kernel
+// (embbag_bwd_sorted_kernels.inc) then sorts each staged table inside LDS and applies it run by run; nothing of it reaches the
+// key sort, whose launches find no pairs for it.
+constexpr int kRestThreads = 1024;
+constexpr int kRestItems = 8;                           // pairs per thread in the LDS sort
+constexpr int kRestCap = kRestThreads * kRestItems;     // 8192 flagged lookups per table (benchmark shape: ~4 800)
+const uint32_t* seg_sort_rest_stage(const void* scratch, size_t n_max, int T);   // [T_h][2][kRestCap]: rows | bags of a staged table
+const uint32_t* seg_sort_rest_n(const void* scratch, size_t n_max, int T);       // [T_h]: staged pairs of table t (0: none / not staged)
+template <typename K>
+hipError_t seg_sort_stage_leftovers(const SegSortRequest& rq, const K* keys_b, const uint32_t* vals_b, K* keys_a, uint32_t* vals_a,
+                                    HybTiles tiles, int rest_enable, void* scratch, hipStream_t stream);
 
 // rowquant.hip: row-wise quantisation of fp32 rows (bits 16 / 8 / 4 / 2), dim a multiple of 8
 int64_t rows_quantized_row_bytes(int dim, int bits);
@@ -330,11 +350,41 @@ hipError_t launch_rows_dequantize(const void* src, int64_t n_rows, int dim, int 
 void set_backward_tuning(int sort_impl, int order, int xcd, int max_phases);   // -1 = default (environment)
 void set_sort_tuning(int mode);                                                // segmented sort: -1 default, 0 / 1 / 2
 void set_hybrid_tuning(int enable, uint32_t spin_cap);            // hybrid backward (embbag_bwd_sorted.hip); -1 = default
-hipError_t sort_status(const KParams& p, int64_t max_rows, int max_dim, const void* workspace, hipStream_t stream, uint32_t out[4]);
+void set_hybrid_rest(int mode);                                   // ... its left-overs finished in LDS (hyb_rest_kernel): -1 default, 0 / 1
+hipError_t sort_status(const KParams& p, int64_t max_rows, int max_dim, const void* workspace, hipStream_t stream, uint32_t out[6]);
 
 // DLRM input redistribution (dlrm_regroup.hip)
 hipError_t launch_dlrm_regroup(const int64_t* lengths, const int64_t* indices, int W, int F, int64_t B,
                                int64_t* out_indices, int64_t* out_offsets, int64_t* scratch, hipStream_t stream);
+
+// The lanes of the wave that hold the same NB-bit digit as this lane (gfx9 has no match instruction: one ballot per bit).
+// Returns, for a valid lane, how many lower lanes share its digit (`below`) and how many lanes do in all (`total`).
+// Written on 32-bit halves: per bit, the sign-extended bit (0 / -1), one compare for the ballot and m &= ~(ballot ^ bit) on
+// either half -- as 64-bit selects (`bit ? bal : ~bal`) the compiler spent ~115 vector instructions per element here, and the
+// sixteen elements of a thread made this loop half of a pass kernel's time.
+template <int NB = 8>
+__device__ __forceinline__ void match_digit(uint32_t d, bool valid, uint32_t& below, uint32_t& total) {
+    const uint64_t v = __ballot(valid);
+    uint32_t xlo = ~static_cast<uint32_t>(v), xhi = ~static_cast<uint32_t>(v >> 32);      // lanes that do NOT match, so far
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int32_t bm = static_cast<int32_t>(d << (31 - b)) >> 31;        // 0 or -1: bit b of the digit
+        const uint64_t bal = __ballot(bm != 0);
+        // x |= ballot ^ bit: one three-input bit operation per half (truth table 0xF6 = a | (b ^ c))
+        xlo = __builtin_amdgcn_bitop3_b32(xlo, static_cast<uint32_t>(bal), static_cast<uint32_t>(bm), 0xF6);
+        xhi = __builtin_amdgcn_bitop3_b32(xhi, static_cast<uint32_t>(bal >> 32), static_cast<uint32_t>(bm), 0xF6);
+    }
+    const uint32_t mlo = ~xlo, mhi = ~xhi;
+    below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+    total = static_cast<uint32_t>(__popc(mlo) + __popc(mhi));
+}
+
+// the lanes of a wave hand LDS data to each other: LDS operations of one wave execute in order, the compiler must keep them so
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // lanes per bag for a given widest row: next power of two >= max_dim / vec, clamped to [8, 64]
 inline int group_lanes(int max_dim, int vec) {

@@ -197,6 +197,16 @@ int env_int(const char* name, int dflt) {
     return (e && e[0] >= '0' && e[0] <= '9') ? atoi(e) : dflt;
 }
 int hyb_enable_knob() { return knob(g_hyb_enable, [] { return env_int("PARAM_AMD_BWD_HYBRID", 1); }); }
+// the hybrid tables' left-overs finished in LDS by hyb_rest_kernel (round 6; pm_set_hybrid_rest): 1 (default) on, 0 every list goes
+// through the key sort and the sorted apply as in round 5 (A/B runs, cross-check)                     PARAM_AMD_HYB_REST=0
+// (Round 6 also ran hyb_rest_kernel on a library-owned stream BESIDE the key sort's launches -- it touches the stage and its own
+//  tables' rows only; forked by an event after the staging kernel, joined by one after the chain's last kernel -- to hide the eight
+//  launches that find nothing to do (4.8 us each) under it.  Same box, modes taking turns, fused backward ms: fp32 uniform 1.549 (round-5
+//  route) / 1.534 (LDS kernel on the caller's stream) / 1.544 (side stream); bf16 1.162 / 1.150 / 1.155; and the Zipf step, which only
+//  pays for the fork and join, 0.957 / 0.957 / 0.972-0.981: two cross-stream event hand-offs cost more than the overlap returns.
+//  Removed; profiles/r06_rest_kernel_ab.md.)
+std::atomic<int> g_hyb_rest{-1};
+int hyb_rest_knob() { return knob(g_hyb_rest, [] { return env_int("PARAM_AMD_HYB_REST", 1) != 0 ? 1 : 0; }); }
 bool want_xcd() { return knob(g_bwd_xcd, [] { return env_is("PARAM_AMD_BWD_XCD", "0") ? 0 : 1; }) == 1; }
 //   max_phases 1 (default): one apply launch; 2: a phases = 2 sort lays a fixed-pooling request out for the two-phase
 //              apply (measured at benchmark size: uniform indices 1.60 -> 1.58 ms, Zipf 0.97 -> 1.12 ms: rows looked up in
@@ -630,18 +640,60 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
         default: rc = bwd_unique_launch_f16(sp, q, ua, max_dim, stream); break;
     }
     if (rc != hipSuccess) return rc;
+    // What the bag-major kernel listed (round 6): hyb_stage_kernel copies a table's few thousand flagged lookups into the staging area
+    // (its sort segment becomes empty) or compacts a longer list for the key sort; hyb_rest_kernel sorts the staged tables in LDS and
+    // applies them.  The key sort's chain is launched either way -- what was staged is known on the device only -- and finds no pairs
+    // for the staged tables.
+    const int rest_mode = hyb_rest_knob();
     const HybTiles tiles{q.bags_per_block, q.tiles_per_table};
+    const size_t nN = static_cast<size_t>(p.N);
+    if (g.key_bytes == 4) {
+        const SegSortRequest rq = seg_request<uint32_t>(p, g, ws);
+        rc = seg_sort_stage_leftovers<uint32_t>(rq, reinterpret_cast<const uint32_t*>(ws.keys_b), ws.vals_b, reinterpret_cast<uint32_t*>(ws.keys_a),
+                                                ws.vals_a, tiles, rest_mode != 0 ? 1 : 0, ws.temp, stream);
+    } else {
+        const SegSortRequest rq = seg_request<uint64_t>(p, g, ws);
+        rc = seg_sort_stage_leftovers<uint64_t>(rq, reinterpret_cast<const uint64_t*>(ws.keys_b), ws.vals_b, reinterpret_cast<uint64_t*>(ws.keys_a),
+                                                ws.vals_a, tiles, rest_mode != 0 ? 1 : 0, ws.temp, stream);
+    }
+    if (rc != hipSuccess) return rc;
+    if (rest_mode != 0) {
+        RestArgs ra;
+        ra.hyb_tab = ua.hyb_tab;
+        ra.T_h = p.T < kHybMaxTables ? p.T : kHybMaxTables;
+        ra.stage = seg_sort_rest_stage(ws.temp, nN, p.T);
+        ra.rest_n = seg_sort_rest_n(ws.temp, nN, p.T);
+        ra.rbits = &seg_sort_desc(ws.temp, nN, p.T)->rbits;
+        ra.rbits_stride = static_cast<int>(sizeof(SegDesc) / sizeof(uint32_t));
+        ra.parts = rest_parts(ra.T_h, q.tiles_per_table);
+        switch (dst_dtype) {
+            case PM_F32: rc = bwd_rest_launch_f32(sp, q, ra, max_dim, stream); break;
+            case PM_BF16: rc = bwd_rest_launch_bf16(sp, q, ra, max_dim, stream); break;
+            default: rc = bwd_rest_launch_f16(sp, q, ra, max_dim, stream); break;
+        }
+        if (rc != hipSuccess) return rc;
+    }
     if (g.key_bytes == 4) {
         const SegSortRequest rq = seg_request<uint32_t>(p, g, ws);
         rc = seg_sort_part_b<uint32_t>(rq, g.mode, reinterpret_cast<uint32_t*>(ws.keys_a), reinterpret_cast<uint32_t*>(ws.keys_b), ws.vals_a,
-                                       ws.vals_b, ws.bag_of, ws.temp, stream, tiles);
+                                       ws.vals_b, ws.bag_of, ws.temp, stream, true);
     } else {
         const SegSortRequest rq = seg_request<uint64_t>(p, g, ws);
         rc = seg_sort_part_b<uint64_t>(rq, g.mode, reinterpret_cast<uint64_t*>(ws.keys_a), reinterpret_cast<uint64_t*>(ws.keys_b), ws.vals_a,
-                                       ws.vals_b, ws.bag_of, ws.temp, stream, tiles);
+                                       ws.vals_b, ws.bag_of, ws.temp, stream, true);
     }
     if (rc != hipSuccess) return rc;
     return sorted_apply(stream);
+
+}
+
+void set_hybrid_rest(int mode) { g_hyb_rest.store(mode); }
+
+// workgroups per table of hyb_rest_kernel: enough to put a workgroup on every CU (T_h x parts ~ 256): a staged table's sorted
+// positions are dealt out over them
+int rest_parts(int T_h, int) {
+    const int p = T_h > 0 ? 256 / T_h : 1;
+    return p < 1 ? 1 : (p > 16 ? 16 : p);
 }
 
 void set_hybrid_tuning(int enable, uint32_t spin_cap) {
@@ -650,7 +702,7 @@ void set_hybrid_tuning(int enable, uint32_t spin_cap) {
 }
 
 // synchronous: what the last sort on this workspace left on the device
-hipError_t sort_status(const KParams& p, int64_t max_rows, int max_dim, const void* workspace, hipStream_t stream, uint32_t out[4]) {
+hipError_t sort_status(const KParams& p, int64_t max_rows, int max_dim, const void* workspace, hipStream_t stream, uint32_t out[6]) {
     SortPlan g;
     {
         std::lock_guard<std::mutex> lock(g_plan_mutex);
@@ -658,7 +710,7 @@ hipError_t sort_status(const KParams& p, int64_t max_rows, int max_dim, const vo
         if (it == g_plans.end()) return hipErrorInvalidValue;
         g = it->second;
     }
-    out[0] = out[1] = out[2] = out[3] = 0;
+    out[0] = out[1] = out[2] = out[3] = out[4] = out[5] = 0;
     if (!g.v2) return hipSuccess;
     SortWs ws;
     hipError_t rc = ws_layout(const_cast<void*>(workspace), p.N, p.T, ws_key_bytes(p, max_rows), ws_kbits_sort(p, max_rows), g.weighted,
@@ -669,6 +721,7 @@ hipError_t sort_status(const KParams& p, int64_t max_rows, int max_dim, const vo
     std::vector<HybTable> tab(static_cast<size_t>(p.T));
     if ((rc = hipMemcpyAsync(tab.data(), seg_sort_hyb_tab(ws.temp, static_cast<size_t>(p.N), p.T), sizeof(HybTable) * tab.size(),
                              hipMemcpyDeviceToHost, stream)) != hipSuccess) return rc;
+    if ((rc = hipMemcpyAsync(&out[4], seg_sort_rest_stat(ws.temp, static_cast<size_t>(p.N), p.T), 8, hipMemcpyDeviceToHost, stream)) != hipSuccess) return rc;
     if ((rc = hipStreamSynchronize(stream)) != hipSuccess) return rc;
     for (const HybTable& h : tab) out[2] += h.mode == 1u ? 1u : 0u;
     out[3] = static_cast<uint32_t>(g.hyb);

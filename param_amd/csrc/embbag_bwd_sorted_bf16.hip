@@ -16,4 +16,10 @@ hipError_t bwd_unique_launch_bf16(const SortedParams& sp, const KParams& kp, con
     return launch_unique_g<SDstBF16>(sp, kp, ua, max_dim, stream);
 }
 
+hipError_t bwd_rest_launch_bf16(const SortedParams& sp, const KParams& kp, const RestArgs& ra, int max_dim, hipStream_t stream) {
+    return launch_rest_g<SDstBF16>(sp, kp, ra, max_dim, stream);
+}
+
 }  // namespace pm
+
+PM_DEFINE_TRACE_READER(pm_experiment_trace_apply_bf16)      // experiment builds only (pm_experiments.h); nothing in the product

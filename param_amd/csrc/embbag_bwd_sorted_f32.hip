@@ -16,6 +16,10 @@ hipError_t bwd_unique_launch_f32(const SortedParams& sp, const KParams& kp, cons
     return launch_unique_g<SDstF32>(sp, kp, ua, max_dim, stream);
 }
 
+hipError_t bwd_rest_launch_f32(const SortedParams& sp, const KParams& kp, const RestArgs& ra, int max_dim, hipStream_t stream) {
+    return launch_rest_g<SDstF32>(sp, kp, ra, max_dim, stream);
+}
+
 }  // namespace pm
 
 PM_DEFINE_TRACE_READER(pm_experiment_trace_apply_f32)      // experiment builds only (pm_experiments.h); nothing in the product

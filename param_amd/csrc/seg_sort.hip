@@ -46,10 +46,7 @@ namespace {
 
 constexpr int kT = 256;                 // threads per workgroup
 constexpr int kWaves = kT / kWave;      // 4
-#ifndef PM_SEG_TILE
-#define PM_SEG_TILE 4096
-#endif
-constexpr int kTile = PM_SEG_TILE;      // elements per radix tile (16 per thread); -DPM_SEG_TILE=2048: experiment builds
+constexpr int kTile = kSegTile;         // elements per radix tile (16 per thread); common.h
 constexpr int kTileItems = kTile / kT;  // 16
 constexpr int kRadix = 256;
 constexpr int kRadixMax = 512;          // mode 0 sorts 9 bits per pass where that saves a pass
@@ -65,7 +62,9 @@ struct SegHeader {
     uint32_t n_l2;       // buckets on the second-level list (= second-level segments)
     uint32_t n_tiles2;   // radix tiles of the second level
     uint32_t lookback_timeouts;   // look-back walks that stopped waiting and counted a predecessor tile's digits themselves (a statistic)
-    uint32_t pad[11];
+    uint32_t rest_pairs;          // hybrid backward: flagged lookups / tables hyb_rest_kernel finished in LDS (zeroed by prep 1; statistics)
+    uint32_t rest_tables;
+    uint32_t pad[9];
 };
 
 // one per radix tile: a pass kernel's workgroup learns everything about its tile from one 32-byte load
@@ -116,27 +115,7 @@ __device__ __forceinline__ void local_bits(int mode, int rbits, int& lo, int& hi
     if (hi < lo) hi = lo;
 }
 
-// The lanes of the wave that hold the same NB-bit digit as this lane (gfx9 has no match instruction: one ballot per bit).
-// Returns, for a valid lane, how many lower lanes share its digit (`below`) and how many lanes do in all (`total`).
-// Written on 32-bit halves: per bit, the sign-extended bit (0 / -1), one compare for the ballot and m &= ~(ballot ^ bit) on
-// either half -- as 64-bit selects (`bit ? bal : ~bal`) the compiler spent ~115 vector instructions per element here, and the
-// sixteen elements of a thread made this loop half of a pass kernel's time.
-template <int NB = 8>
-__device__ __forceinline__ void match_digit(uint32_t d, bool valid, uint32_t& below, uint32_t& total) {
-    const uint64_t v = __ballot(valid);
-    uint32_t xlo = ~static_cast<uint32_t>(v), xhi = ~static_cast<uint32_t>(v >> 32);      // lanes that do NOT match, so far
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int32_t bm = static_cast<int32_t>(d << (31 - b)) >> 31;        // 0 or -1: bit b of the digit
-        const uint64_t bal = __ballot(bm != 0);
-        // x |= ballot ^ bit: one three-input bit operation per half (truth table 0xF6 = a | (b ^ c))
-        xlo = __builtin_amdgcn_bitop3_b32(xlo, static_cast<uint32_t>(bal), static_cast<uint32_t>(bm), 0xF6);
-        xhi = __builtin_amdgcn_bitop3_b32(xhi, static_cast<uint32_t>(bal >> 32), static_cast<uint32_t>(bm), 0xF6);
-    }
-    const uint32_t mlo = ~xlo, mhi = ~xhi;
-    below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
-    total = static_cast<uint32_t>(__popc(mlo) + __popc(mhi));
-}
+// (match_digit: common.h)
 
 // exclusive scan of one value per thread over the 256 threads of the workgroup; s_tmp: kWaves words
 __device__ __forceinline__ uint32_t block_excl_scan256(uint32_t v, uint32_t* s_tmp) {
@@ -155,22 +134,19 @@ __device__ __forceinline__ uint32_t block_excl_scan256(uint32_t v, uint32_t* s_t
     return base + incl - v;
 }
 
-// the lanes of a wave hand LDS data to each other: LDS operations of one wave execute in order, the compiler must keep them so
-__device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+// (wave_lds_fence: common.h)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // prep 1: one workgroup (1024 threads) per table
 __global__ void __launch_bounds__(1024) seg_prep_tables_kernel(const void* indices, const void* offsets, int idx64, const int64_t* rows, int T,
                                                                int64_t B, int64_t N, int64_t bag_begin, int64_t bag_count, int force_ragged,
-                                                               SegDesc* desc, uint32_t* zero4, const HybArgs hyb, HybTable* hyb_tab, uint32_t* qtail) {
+                                                               SegDesc* desc, uint32_t* zero4, const HybArgs hyb, HybTable* hyb_tab, uint32_t* qtail,
+                                                               uint32_t* rest_stat) {
     __shared__ uint32_t s_sample[2048];      // classification: 2^16 hashed bits
     __shared__ uint32_t s_rep;
     const int t = blockIdx.x;
     if (zero4 && t == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0u;
+    if (t == 0 && threadIdx.x < 2) rest_stat[threadIdx.x] = 0u;
     if (qtail && t < kHybMaxTables && static_cast<int>(threadIdx.x) < hyb.slices) qtail[static_cast<size_t>(t) * hyb.slices + threadIdx.x] = 0u;   // hyb_part_kernel's queue lengths
     const int64_t TB = static_cast<int64_t>(T) * B;
     const int64_t g0 = static_cast<int64_t>(t) * B + bag_begin;
@@ -1375,6 +1351,8 @@ struct Scratch {
     uint32_t* bloom;         // ... dup bitmaps of the first kHybMaxTables tables
     uint32_t* tile_cnt;      // ... flagged lookups per tile of the bag-major apply, [T_h][tile_cnt_stride]
     uint32_t* qtail;         // ... rows dealt to the queue of (table, slice), [T_h][slices]
+    uint32_t* rest_stage;    // ... staged left-overs of the tables hyb_rest_kernel finishes, [T_h][2][kRestCap]
+    uint32_t* rest_n;        // ... their numbers, [T_h]
     size_t total;
 };
 
@@ -1403,6 +1381,8 @@ Scratch scratch_layout(void* base, size_t n, int T) {
     s.bloom = reinterpret_cast<uint32_t*>(take(4 * th * static_cast<size_t>(hyb_slices(static_cast<int64_t>(n), T)) * kBloomWords));
     s.tile_cnt = reinterpret_cast<uint32_t*>(take(4 * th * tile_cnt_stride(n)));
     s.qtail = reinterpret_cast<uint32_t*>(take(4 * th * static_cast<size_t>(kBloomKMax)));
+    s.rest_stage = reinterpret_cast<uint32_t*>(take(4 * th * 2 * static_cast<size_t>(kRestCap)));
+    s.rest_n = reinterpret_cast<uint32_t*>(take(4 * th));
     s.total = off;
     return s;
 }
@@ -1423,6 +1403,9 @@ const HybTable* seg_sort_hyb_tab(const void* scratch, size_t n_max, int T) { ret
 const uint32_t* seg_sort_bloom(const void* scratch, size_t n_max, int T) { return scratch_layout(const_cast<void*>(scratch), n_max, T).bloom; }
 uint32_t* seg_sort_tile_cnt(const void* scratch, size_t n_max, int T) { return scratch_layout(const_cast<void*>(scratch), n_max, T).tile_cnt; }
 size_t seg_sort_tile_cnt_stride(size_t n_max) { return tile_cnt_stride(n_max); }
+uint32_t* seg_sort_rest_stat(void* scratch, size_t n_max, int T) { return &scratch_layout(scratch, n_max, T).hdr->rest_pairs; }
+const uint32_t* seg_sort_rest_stage(const void* scratch, size_t n_max, int T) { return scratch_layout(const_cast<void*>(scratch), n_max, T).rest_stage; }
+const uint32_t* seg_sort_rest_n(const void* scratch, size_t n_max, int T) { return scratch_layout(const_cast<void*>(scratch), n_max, T).rest_n; }
 
 // mode 0 sorts 9 bits per pass where that saves a global pass over the pairs: 25 .. 27 row bits (the 40 M-row Criteo tables:
 // 3 passes instead of 4), 17 / 18 bits (2 instead of 3), 9 bits.  Everywhere else 8: a 512-value digit costs LDS (three
@@ -1491,7 +1474,7 @@ hipError_t seg_sort_part_a(const SegSortRequest& rq, void* scratch, hipStream_t 
     HybArgs hyb = rq.hyb;
     if (rq.weighted) hyb.allow = 0;
     hipLaunchKernelGGL(seg_prep_tables_kernel, dim3(rq.T), dim3(1024), 0, stream, rq.indices, rq.offsets, rq.idx64, rq.rows, rq.T, rq.B, rq.N,
-                       rq.bag_begin, rq.bag_count, rq.weighted ? 1 : 0, s.desc, rq.zero4, hyb, s.hyb_tab, s.qtail);
+                       rq.bag_begin, rq.bag_count, rq.weighted ? 1 : 0, s.desc, rq.zero4, hyb, s.hyb_tab, s.qtail, &s.hdr->rest_pairs);
     if (hyb.allow) {
         if (!seg_sort_hybrid_available()) return hipErrorInvalidValue;      // (sort_indices asks first and does not offer the path then)
         const int th = rq.T < kHybMaxTables ? rq.T : kHybMaxTables;
@@ -1520,22 +1503,33 @@ hipError_t seg_sort_part_a(const SegSortRequest& rq, void* scratch, hipStream_t 
     return hipGetLastError();
 }
 
+// between the bag-major apply and part B of a hybrid sort: stage or compact what the apply listed (hyb_stage_kernel)
+template <typename K>
+hipError_t seg_sort_stage_leftovers(const SegSortRequest& rq, const K* keys_b, const uint32_t* vals_b, K* keys_a, uint32_t* vals_a,
+                                    HybTiles tiles, int rest_enable, void* scratch, hipStream_t stream) {
+    if (rq.N == 0) return hipSuccess;
+    if (rq.T < 1 || rq.T > kSegSortMaxTables || rq.N > 0xffffffffLL) return hipErrorInvalidValue;
+    if (tiles.tiles_per_table < 1 || tiles.tiles_per_table > kCompactMaxTiles) return hipErrorInvalidValue;
+    const size_t n = static_cast<size_t>(rq.N);
+    const Scratch s = scratch_layout(scratch, n, rq.T);
+    const int th = rq.T < kHybMaxTables ? rq.T : kHybMaxTables;
+    const int parts = stage_parts(tiles.tiles_per_table);
+    hipLaunchKernelGGL((hyb_stage_kernel<K>), dim3(th * parts), dim3(kT), 0, stream, s.desc, s.hyb_tab, th, s.tile_cnt, tile_cnt_stride(n), tiles,
+                       keys_b, vals_b, keys_a, vals_a, parts, rest_enable, rq.tshift, s.rest_stage, s.rest_n, &s.hdr->rest_pairs);
+    return hipGetLastError();
+}
+
 template <typename K>
 hipError_t seg_sort_part_b(const SegSortRequest& rq, int mode, K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t* bag_of,
-                           void* scratch, hipStream_t stream, HybTiles tiles) {
+                           void* scratch, hipStream_t stream, bool hybrid_done) {
     if (rq.N == 0) return hipSuccess;
     if (rq.T < 1 || rq.T > kSegSortMaxTables || rq.N > 0xffffffffLL) return hipErrorInvalidValue;
     const size_t n = static_cast<size_t>(rq.N);
     const Scratch s = scratch_layout(scratch, n, rq.T);
     const unsigned tm = static_cast<unsigned>(tiles_max(n, rq.T));
-    if (rq.hyb.allow && !rq.weighted) {
-        // the flagged lookups of the hybrid tables (listed per tile by the bag-major apply) become those tables' segments of built pairs
-        if (tiles.tiles_per_table < 1 || tiles.tiles_per_table > kCompactMaxTiles) return hipErrorInvalidValue;
-        const int th = rq.T < kHybMaxTables ? rq.T : kHybMaxTables;
-        const int parts = compact_parts(tiles.tiles_per_table);
-        hipLaunchKernelGGL((hyb_compact_kernel<K>), dim3(th * parts), dim3(kT), 0, stream, s.desc, s.hyb_tab, th, s.tile_cnt,
-                           tile_cnt_stride(n), tiles, keys_b, vals_b, keys_a, vals_a, parts);
-    }
+    // a hybrid sort's part B follows the bag-major kernel and hyb_stage_kernel (seg_sort_stage_leftovers), which has turned every
+    // hybrid table's segment into "no pairs" (staged for hyb_rest_kernel's LDS sort) or "n built pairs" (compacted into the a buffers)
+    if (rq.hyb.allow && !rq.weighted && !hybrid_done) return hipErrorInvalidValue;
     {
         const int chunks = rq.bag_count > 0 ? static_cast<int>((rq.bag_count + kBuildBags - 1) / kBuildBags) : 0;
         const dim3 gp(1u + static_cast<unsigned>(chunks) * static_cast<unsigned>(rq.T));
@@ -1603,12 +1597,14 @@ hipError_t seg_sort_pairs(const SegSortRequest& rq, int mode, K* keys_a, K* keys
     if (rq.hyb.allow) return hipErrorInvalidValue;      // the hybrid form's part B belongs to the apply call
     const hipError_t rc = seg_sort_part_a<K>(rq, scratch, stream);
     if (rc != hipSuccess) return rc;
-    return seg_sort_part_b<K>(rq, mode, keys_a, keys_b, vals_a, vals_b, bag_of, scratch, stream, HybTiles{0, 0});
+    return seg_sort_part_b<K>(rq, mode, keys_a, keys_b, vals_a, vals_b, bag_of, scratch, stream, false);
 }
 
 #define PM_SEG_INST(K_)                                                                                                              \
     template hipError_t seg_sort_part_a<K_>(const SegSortRequest&, void*, hipStream_t);                                              \
-    template hipError_t seg_sort_part_b<K_>(const SegSortRequest&, int, K_*, K_*, uint32_t*, uint32_t*, uint32_t*, void*, hipStream_t, HybTiles); \
+    template hipError_t seg_sort_part_b<K_>(const SegSortRequest&, int, K_*, K_*, uint32_t*, uint32_t*, uint32_t*, void*, hipStream_t, bool); \
+    template hipError_t seg_sort_stage_leftovers<K_>(const SegSortRequest&, const K_*, const uint32_t*, K_*, uint32_t*, HybTiles, int, void*,    \
+                                                     hipStream_t);                                                                              \
     template hipError_t seg_sort_pairs<K_>(const SegSortRequest&, int, K_*, K_*, uint32_t*, uint32_t*, uint32_t*, void*, hipStream_t);
 PM_SEG_INST(uint32_t)
 PM_SEG_INST(uint64_t)

@@ -330,13 +330,14 @@ def sorted_pairs(ts: _TableSet, indices, offsets, B, psw=None, bag_begin=0, bag_
 def sort_status(ts: _TableSet, indices, offsets, B, psw=None, bag_begin=0, bag_count=None) -> dict:
     """What the last ``_sort_indices`` / backward on this table set's workspace left on the device (``pm_embbag_sort_status``;
     SYNCHRONISES): ``lookback_fallbacks`` (look-back walks that counted a predecessor's digits themselves: harmless),
-    ``pairs_sorted``, ``hybrid_tables``, ``hybrid_launched``."""
+    ``pairs_sorted``, ``hybrid_tables``, ``hybrid_launched``, ``lds_pairs`` / ``lds_tables`` (flagged lookups / hybrid tables finished
+    inside LDS by the left-over kernel: they never reach the sort)."""
     op = ts.request(indices, offsets, B, psw, bag_begin, bag_count)
     ws = _workspace(ts, op)
     st = _lib.pm_sort_status()
     _lib.check(_lib.load().pm_embbag_sort_status(ctypes.byref(op), max(ts.rows), ws.data_ptr(), ctypes.byref(st), _stream_ptr()))
     return {"lookback_fallbacks": st.lookback_fallbacks, "pairs_sorted": st.pairs_sorted, "hybrid_tables": st.hybrid_tables,
-            "hybrid_launched": st.hybrid_launched}
+            "hybrid_launched": st.hybrid_launched, "lds_pairs": st.lds_pairs, "lds_tables": st.lds_tables}
 
 
 def _bwd(ts: _TableSet, grad, indices, offsets, B, dst_ptrs_dev, dst_dtype, alpha, psw=None,
