@@ -73,6 +73,9 @@ def parse():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--workload", choices=["uniform-tables", "criteo"], default="uniform-tables",
                    help="criteo: the 26 MLPerf DLRM-v2 tables with per-table multi-hot pooling (BASELINE.json configs[4])")
+    p.add_argument("--mixed-dims", action="store_true",
+                   help="criteo: per-table embedding dims by table size (rows >= 10 M -> 128, >= 100 K -> 64, >= 1 K -> 32, else 16: "
+                        "dataset.criteo_v2_mixed_dims) -- BASELINE configs[4]'s \"mixed-dim\"; output layout [B, sum D]")
     p.add_argument("--tables", type=int, default=64, help="logical table count of the workload (26 = BASELINE configs[3])")
     p.add_argument("--rows", type=int, default=10_000_000)
     p.add_argument("--dim", type=int, default=128)
@@ -96,9 +99,9 @@ def parse():
     p.add_argument("--atomic", action="store_true", help="also time the atomic backward kernel (slow: ~15 ms per step)")
     p.add_argument("--lookup-cus", type=int, default=-1,
                    help="N>1: run lookup / backward on a HIP stream masked to this many CUs (0 = all 256), leaving the rest to RCCL's "
-                        "kernels.  Default (-1): 224 for N>1 -- the only setting in which the 1-rank records of rounds 2-3 show the "
-                        "exchange overlapping the lookup (0.346 -> 0.283 ms per step at 26 tables); the same step on an unmasked stream "
-                        "is timed beside it (overlap.step_s_lookup_cus_256)")
+                        "kernels.  Default (-1): SELECTED IN THE RUN -- a few warm-up steps are timed on a 224-CU stream and on an "
+                        "unmasked one (max over ranks), the timed window runs on the faster (overlap.cu_mask_selected, both trial "
+                        "times beside it); the other one is timed again after the window (overlap.step_s_lookup_cus_*)")
     p.add_argument("--no-cu-sweep", action="store_true", help="N>1: skip the extra timing of the step on a 224-CU compute stream")
     p.add_argument("--a2a-bitwidth", type=int, default=32, choices=[32, 16, 8, 4, 2],
                    help="N>1: quantise the pooled all-to-all to this many bits (the reference's --bitwidth; row-wise formats of "
@@ -356,7 +359,10 @@ def cpu_baseline(spec: dict, budget_s: float = 20.0):
     best = modes[value_mode]
     quota = result.get("cgroup_cpu_quota")
     return {
-        "value": best["lookups_per_s"], "unit": "lookups/s", "cores": best["threads"], "kind": "port",
+        "value": best["lookups_per_s"], "unit": "lookups/s",
+        # `cores` = the CPUs' worth of time the winning mode can actually use: its thread pool, capped by the container's cgroup quota
+        # (128 threads under a 16-CPU quota are 16 cores of work in bursts); `threads` = the pool
+        "cores": best["threads"] if quota is None else min(best["threads"], max(1, int(quota))), "threads": best["threads"], "kind": "port",
         "min_s_per_step": best["s_per_step_min"], "value_best_repeat": best["lookups_per_s_best_repeat"],
         "unstable": bool(best["unstable"]), "spread": best["spread"], "repeats_kept": best["repeats_kept"],
         "repeats_dropped_throttled": best["repeats_dropped_throttled"],
@@ -375,47 +381,75 @@ def cpu_baseline(spec: dict, budget_s: float = 20.0):
 
 def profile_traffic(workload: str, phase: str):
     """L2 -> fabric bytes per step of a COMMITTED rocprofv3 --pmc profile (profiles/pmc_traffic.json["phases"], produced by
-    tools/r5_pmc.sh: never collected inside a bench run), as {"traffic_over_algorithmic": r, "from": ...}, or {} when there is none"""
+    tools/r5_pmc.sh: never collected inside a bench run).  Returned under ONE key that says so -- these numbers were not measured in
+    this run, on this build or on this box -- or {} when the file has no such phase."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        rec = json.load(open(path))
         ph = rec["phases"][f"{workload}.{phase}"]
-        return {"traffic_over_algorithmic": ph["traffic_over_algorithmic"], "traffic_bytes_per_step": ph["fabric_bytes_per_step"],
-                "traffic_from_profile": f"profiles/pmc_traffic.json[phases][{workload}.{phase}] <- {rec.get('phases_source', '')[:40]}"}
-    except Exception:
+        return {"committed_profile": {"traffic_over_algorithmic": ph["traffic_over_algorithmic"],
+                                      "traffic_bytes_per_step": ph["fabric_bytes_per_step"],
+                                      "file": f"profiles/pmc_traffic.json[phases][{workload}.{phase}]",
+                                      "collected": rec.get("phases_source", "")[:80],
+                                      "note": "rocprofv3 --pmc counters of a committed profile of this launch: not measured in this run"}}
+    except (FileNotFoundError, KeyError, ValueError):
         return {}
 
 
 # ---- compact extra blocks of the default N == 1 run -------------------------------------------------------------------
+REQUESTS_ROTATED = 4   # distinct requests cycled through the forward windows (the CPU leg cycles 8 index sets for the same reason)
+
+
 def extra_block(dev, rows, pools, D, dtype_name, B, alpha, n_sub, barrier, layout, pmc_key=None):
     """One more workload measured in the same run, compactly: BASELINE configs[2]'s bf16 half with ALL 64 tables resident (the
-    configuration the metric is quoted on: 64 x 10 M x 128 fits one GPU in bf16) and configs[4]'s Criteo tables.  Forward under Zipf
-    and uniform indices (the latter is the roofline fraction), the deterministic backward (sort + apply), the fwd + bwd step."""
+    configuration the metric is quoted on: 64 x 10 M x 128 fits one GPU in bf16), configs[4]'s Criteo tables, and the same tables
+    with MIXED embedding dims (``D`` a list: per-table dims; layout [B, sum D]).  Forward under Zipf and uniform indices (the latter
+    is the roofline fraction; REQUESTS_ROTATED distinct requests take turns, the single-request replay is reported beside it), the
+    deterministic backward (sort + apply), the fwd + bwd step."""
     dtype = _DT[dtype_name]
     esize = torch.empty(0, dtype=dtype).element_size()
     T = len(rows)
-    model = param_amd.BatchedEmbeddingBagMI355(rows, D, dtype=dtype, device=dev, init="normal", layout=layout, seed=1000, fused_update=False)
-    zi, zo = tbe_request(rows, B, pools, alpha=alpha, device=dev, seed=1)
-    ui, uo = tbe_request(rows, B, pools, alpha=0.0, device=dev, seed=2)
-    shape = (B, T * D) if layout == "bd" else (T, B, D)
+    dims = [int(D)] * T if isinstance(D, int) else [int(d) for d in D]
+    model = param_amd.BatchedEmbeddingBagMI355(rows, dims, dtype=dtype, device=dev, init="normal", layout=layout, seed=1000, fused_update=False)
+    zreq = [tbe_request(rows, B, pools, alpha=alpha, device=dev, seed=1 + 1000 * k) for k in range(REQUESTS_ROTATED)]
+    ureq = [tbe_request(rows, B, pools, alpha=0.0, device=dev, seed=2 + 1000 * k) for k in range(REQUESTS_ROTATED)]
+    (zi, zo), (ui, uo) = zreq[0], ureq[0]
+    shape = (B, sum(dims)) if layout == "bd" else (T, B, dims[0])
     out = torch.empty(shape, dtype=torch.float32, device=dev)
     grad = torch.randn(shape, dtype=torch.float32, device=dev)
     n = B * sum(pools)
-    fwd_bytes = sum(algorithmic_bytes(1, B, Lt, D, esize) for Lt in pools)
-    bwd_bytes = n * (2 * D * esize + 8) + T * B * (D * 4 + 8)
-    rec = {"tables": T, "dtype": dtype_name, "lookups_per_step": n, "table_bytes": sum(rows) * D * esize, "output_layout": "[B, sum D]" if layout == "bd" else "[T, B, D]",
+    # SURVEY 8d per-unit figures with the table's own D: per lookup D_t * e + 8 read, per bag 8 read + D_t * 4 written (backward:
+    # 2 * D_t * e + 8 per lookup, D_t * 4 + 8 per bag)
+    fwd_bytes = sum(algorithmic_bytes(1, B, Lt, Dt, esize) for Lt, Dt in zip(pools, dims))
+    bwd_bytes = sum(B * Lt * (2 * Dt * esize + 8) + B * (Dt * 4 + 8) for Lt, Dt in zip(pools, dims))
+    rec = {"tables": T, "dtype": dtype_name, "lookups_per_step": n, "table_bytes": sum(r * d for r, d in zip(rows, dims)) * esize,
+           "output_layout": "[B, sum D]" if layout == "bd" else "[T, B, D]",
            "fwd_bytes_per_lookup": fwd_bytes / n, "bwd_bytes_per_lookup": bwd_bytes / n}
-    _, fu = time_steps_med(lambda: model.lookup(ui, uo, out=out, batch=B), 2 * n_sub, 25, barrier)
-    _, fz = time_steps_med(lambda: model.lookup(zi, zo, out=out, batch=B), 2 * n_sub, 5, barrier)
-    rec["fwd"] = {"zipf_lookups_per_s": n / fz, "zipf_avg_launch_s": fz, "uniform_avg_launch_s": fu, "uniform_frac": fwd_bytes / fu / 1e9 / HBM_PEAK_GBPS}
+    if len(set(dims)) > 1:
+        rec["dims"] = {str(d): dims.count(d) for d in sorted(set(dims))}
+    k = [0]
+
+    def rot(reqs):
+        def f():
+            i, o = reqs[k[0] % len(reqs)]
+            k[0] += 1
+            model.lookup(i, o, out=out, batch=B)
+        return f
+
+    _, fu = time_steps_med(rot(ureq), 2 * n_sub, 25, barrier)
+    _, fz = time_steps_med(rot(zreq), 2 * n_sub, 5, barrier)
+    _, fu1 = time_steps_med(lambda: model.lookup(ui, uo, out=out, batch=B), 2 * n_sub, 5, barrier)
+    rec["fwd"] = {"zipf_lookups_per_s": n / fz, "zipf_avg_launch_s": fz, "uniform_avg_launch_s": fu, "uniform_frac": fwd_bytes / fu / 1e9 / HBM_PEAK_GBPS,
+                  "requests_rotated": REQUESTS_ROTATED, "uniform_single_request_frac": fwd_bytes / fu1 / 1e9 / HBM_PEAK_GBPS}
     if pmc_key:
-        rec["fwd"]["uniform_profile"] = profile_traffic(pmc_key, "fwd_uniform")
-        rec["fwd"]["zipf_profile"] = profile_traffic(pmc_key, "fwd_zipf")
+        rec["fwd"]["uniform_profile"] = profile_traffic(pmc_key, "fwd_uniform").get("committed_profile")
+        rec["fwd"]["zipf_profile"] = profile_traffic(pmc_key, "fwd_zipf").get("committed_profile")
     bwd = {}
     for tag, (i, o) in (("uniform", (ui, uo)), ("zipf", (zi, zo))):
         _, bs = time_steps_med(lambda: model.scatter_add_(grad, i, o, alpha=-1e-6, batch=B), n_sub, 10, barrier)
         st = model.sort_status(i, o, batch=B)
         bwd[tag] = {"avg_s_sort_plus_apply": bs, ("frac" if tag == "uniform" else "alg_frac"): bwd_bytes / bs / 1e9 / HBM_PEAK_GBPS,
-                    "hybrid_tables": st["hybrid_tables"], "pairs_sorted": st["pairs_sorted"],
+                    "hybrid_tables": st["hybrid_tables"], "pairs_sorted": st["pairs_sorted"], "lds_pairs": st["lds_pairs"],
                     **(profile_traffic(pmc_key, "bwd_" + tag) if pmc_key else {})}
 
         def fwd_bwd():
@@ -427,6 +461,44 @@ def extra_block(dev, rows, pools, D, dtype_name, B, alpha, n_sub, barrier, layou
     rec["bwd_scatter_add"] = bwd
     rec["timing"] = SECONDARY_TIMING
     return rec
+
+
+def _summary(r: dict) -> dict:
+    """the compact trailer of the JSON line: forward / backward / fwd + bwd fractions of the fp32 block (configs[1] / [2]), the bf16
+    64-table block (configs[2]), the Criteo block and its mixed-dim form (configs[4]); None where a block did not run"""
+    def g(d, *ks):
+        for k in ks:
+            d = d.get(k) if isinstance(d, dict) else None
+        return round(d, 4) if isinstance(d, (int, float)) else None
+
+    def ms(d, *ks):
+        for k in ks:
+            d = d.get(k) if isinstance(d, dict) else None
+        return round(d * 1e3, 4) if isinstance(d, (int, float)) else None
+
+    def block(b):
+        return {"fwd_u": g(b, "fwd", "uniform_frac"), "fwd_z_G": (lambda v: None if v is None else round(v / 1e9, 2))(g(b, "fwd", "zipf_lookups_per_s")),
+                "bwd_u": g(b, "bwd_scatter_add", "uniform", "frac"), "bwd_z_ms": ms(b, "bwd_scatter_add", "zipf", "avg_s_sort_plus_apply"),
+                "fwdbwd_u": g(b, "bwd_scatter_add", "uniform", "fwd_bwd_frac")}
+
+    s = {"fwd_u": g(r, "roofline", "frac"), "fwd_u_1req": g(r, "roofline", "single_request_frac"), "fwd_bd_u": g(r, "other_layout", "uniform_frac"),
+         "bwd_u": g(r, "bwd_scatter_add", "uniform", "frac"), "bwd_z_ms": ms(r, "bwd_scatter_add", "avg_s_sort_plus_apply"),
+         "fwdbwd_u": g(r, "fwd_bwd_step", "uniform", "frac"), "fwdbwd_z_ms": ms(r, "fwd_bwd_step", "avg_s"),
+         "sort_ms": ms(r, "bwd_scatter_add", "avg_s_whole_key_sort")}
+    for key, short in (("bf16_T64", "bf16"), ("criteo", "criteo"), ("criteo_mixed", "mixed")):
+        if isinstance(r.get(key), dict) and "fwd" in r[key]:
+            s[short] = block(r[key])
+    if isinstance(r.get("cpu_baseline"), dict) and r["cpu_baseline"].get("value"):
+        s["cpu_G"] = round(r["cpu_baseline"]["value"] / 1e9, 3)
+    return s
+
+
+def _rccl_version():
+    """RCCL's version as torch reports it ("nccl" IS RCCL on ROCm), or None under another backend (gloo in the shared-GPU flow check)"""
+    try:
+        return ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+        return None
 
 
 def self_launch_command(n_gpus: int, argv=None, port=None):
@@ -466,6 +538,7 @@ def main():
         # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, rank 0 prints the one JSON
         # line to the inherited stdout).  Round 4's bench silently measured ONE GPU here and reported n_gpus = 1.
         sys.exit(self_launch(a.gpus))
+    auto_cus = a.lookup_cus < 0      # N > 1: the compute stream (224 CUs or all) is chosen by a trial inside the run
     if a.lookup_cus < 0:
         a.lookup_cus = 224 if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or a.dist_debug) else 0
     # stdout must carry exactly ONE JSON line: RCCL prints a version banner to the C-level stdout and torch may warn there
@@ -536,8 +609,15 @@ def main():
 
         all_rows, all_pool, D = list(ds.criteo_v2_rows), list(ds.criteo_v2_multi_hot), ds.criteo_v2_dim
         a.tables = len(all_rows)
+        all_dims = ds.criteo_v2_mixed_dims(all_rows) if a.mixed_dims else [D] * len(all_rows)
     else:
+        if a.mixed_dims:
+            raise SystemExit("--mixed-dims goes with --workload criteo")
         all_rows, all_pool = [R] * a.tables, [L] * a.tables
+        all_dims = [D] * a.tables
+    mixed = len(set(all_dims)) > 1
+    if mixed:
+        a.layout = "bd"               # [T, B, D] needs one D
     free, total = torch.cuda.mem_get_info()
     if world == 1:
         if a.workload == "criteo":
@@ -556,27 +636,34 @@ def main():
         T_loc = split[rank]
     assert T_loc >= 1, "not enough HBM for one table / more ranks than tables"
     first = sum(split[:rank])
-    rows_list, pool_list = all_rows[first:first + T_loc], all_pool[first:first + T_loc]
-    widths = [s * D for s in split]
+    rows_list, pool_list, dims_list = all_rows[first:first + T_loc], all_pool[first:first + T_loc], all_dims[first:first + T_loc]
+    widths = [sum(all_dims[sum(split[:r]):sum(split[:r + 1])]) for r in range(len(split))]
     B_glob = B_local * world  # table-wise sharding: every rank serves the global batch for its tables
     table_bytes = R * D * esize
 
     blocked = multi and a.send_layout == "blocked"
     if blocked and (a.a2a_bitwidth < 32 or a.grad_bitwidth < 32 or B_local & (B_local - 1)):
         raise SystemExit("--send-layout blocked: fp32 payloads and a power-of-two --batch")
-    model = param_amd.BatchedEmbeddingBagMI355(rows_list, D, dtype=dtype, device=dev, init="normal",
+    if mixed and (blocked or a.a2a_bitwidth < 32 or a.grad_bitwidth < 32):
+        raise SystemExit("--mixed-dims: the [B, sum D] send layout with fp32 payloads only")
+    model = param_amd.BatchedEmbeddingBagMI355(rows_list, dims_list, dtype=dtype, device=dev, init="normal",
                                                layout=a.layout if not multi else ("blocked" if blocked else "bd"),
                                                block_bags=B_local if blocked else None, seed=1000 + rank, fused_update=False)
 
     def make_request(alpha, seed):
         return tbe_request(rows_list, B_glob, pool_list, alpha=alpha, device=dev, seed=seed + 17 * rank)
 
-    idx, off = make_request(a.alpha, 1)
+    # REQUESTS_ROTATED distinct requests take turns in the headline window and in the roofline window: a replayed request leaves up to
+    # 256 MB of its rows in the memory-side cache (6 % of a uniform launch's bytes, more of a Zipf launch's hot tail), and the CPU
+    # leg cycles index sets for the same reason.  Request 0 is the one every other block of this run replays (the reference's own
+    # protocol: pytorch_emb.py:48-69), and its single-request numbers are reported beside the rotated ones.
+    zreqs = [make_request(a.alpha, 1 + 1000 * k) for k in range(REQUESTS_ROTATED)]
+    idx, off = zreqs[0]
     lookups_step_rank = B_glob * sum(pool_list)
     lookups_step_all = rank_sum(lookups_step_rank)
     # SURVEY 8d per-unit figures summed over tables: per lookup D*e + 8 read, per bag 8 read + D*4 written
-    alg_bytes = sum(algorithmic_bytes(1, B_glob, Lt, D, esize) for Lt in pool_list)
-    bwd_bytes = lookups_step_rank * (2 * D * esize + 8) + T_loc * B_glob * (D * 4 + 8)
+    alg_bytes = sum(algorithmic_bytes(1, B_glob, Lt, Dt, esize) for Lt, Dt in zip(pool_list, dims_list))
+    bwd_bytes = sum(B_glob * Lt * (2 * Dt * esize + 8) + B_glob * (Dt * 4 + 8) for Lt, Dt in zip(pool_list, dims_list))
     n_sub = max(5, a.steps // 2)   # steps of the secondary measurements
 
     compute_stream = None
@@ -595,7 +682,7 @@ def main():
             cu_mask_note = cu_mask_note or "hipExtStreamCreateWithCUMask failed on another rank: unmasked compute stream"
 
     # ---- the step ---------------------------------------------------------------------------------------------
-    out_shape = (B_glob, T_loc * D) if (multi or a.layout == "bd") else (T_loc, B_glob, D)
+    out_shape = (B_glob, sum(dims_list)) if (multi or a.layout == "bd") else (T_loc, B_glob, D)
     if not multi:
         out = torch.empty(out_shape, dtype=torch.float32, device=dev)
 
@@ -649,26 +736,71 @@ def main():
     # whichever block runs first reads 3-4 % off the steady state.  The uniform block therefore takes 25 warm-up launches of
     # its own (its warm-up count is not the contract's W), and both it and the headline (W warm-ups, K timed steps, as given)
     # are measured in the steady state every later block of this run sees.
-    uni_s = None
+    rot_k = [0]
+
+    def rotating(fn, reqs):
+        def f():
+            i, o = reqs[rot_k[0] % len(reqs)]
+            rot_k[0] += 1
+            fn(i, o)
+        return f
+
+    uni_s = uni_single_s = None
     if not a.no_uniform and a.alpha != 0.0:
-        ui, uo = make_request(0.0, 2)
+        ureqs = [make_request(0.0, 2 + 1000 * k) for k in range(REQUESTS_ROTATED)]
+        ui, uo = ureqs[0]
         # 25 warm-ups (~20 ms: past the transient), then ONE window -- the average the roofline is defined on -- of at least
         # ROOFLINE_WINDOW_S of device time whatever --steps says: a 25-launch window is 19 ms, short enough for one clock / power
         # transient to BE the measurement (round 4's driver line: 0.706 beside 0.713-0.721 on the builder's boxes)
-        _, est = time_steps(lambda: lookup_only(ui, uo), 5, 25, barrier)
+        _, est = time_steps(rotating(lookup_only, ureqs), 5, 25, barrier)
         est, = rank_max(est)
         uni_steps = max(2 * n_sub, int(ROOFLINE_WINDOW_S / max(est, 1e-6)) + 1)
-        _, uni_s = time_steps(lambda: lookup_only(ui, uo), uni_steps, 0, barrier)
-        uni_s, = rank_max(uni_s)
+        _, uni_s = time_steps(rotating(lookup_only, ureqs), uni_steps, 0, barrier)
+        # ... and the reference's replay protocol (ONE request, every launch) beside it, half as long
+        _, uni_single_s = time_steps(lambda: lookup_only(ui, uo), max(n_sub, uni_steps // 2), 2, barrier)
+        uni_s, uni_single_s = rank_max(uni_s, uni_single_s)
 
-    wall, dev_s = time_steps(step, a.steps, a.warmup, barrier)   # the closing device sync covers exchanges still in flight
+    # ---- N > 1, --lookup-cus not given: which compute stream?  A few warm-up steps on the 224-CU stream and on an unmasked one (every
+    # rank runs both, the clocks are max-over-ranks, so every rank sees the same two numbers and makes the same choice); the timed
+    # window runs on the faster.  Until an 8-GPU run exists nobody knows whether RCCL's kernels want CUs of their own.
+    cu_trial = None
+    if multi and auto_cus and compute_stream is not None:
+        plain_stream = torch.cuda.Stream(device=dev)
+        trial = {}
+        for tag, st_ in (("224", compute_stream), ("256", plain_stream), ("224b", compute_stream), ("256b", plain_stream)):
+            flush()
+            st_.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st_):
+                _, t_ = time_steps(rotating(step, zreqs), max(3, min(a.warmup, 10)), 2, barrier)
+                flush()
+            torch.cuda.current_stream().wait_stream(st_)
+            trial[tag], = rank_max(t_)
+        t224, t256 = min(trial["224"], trial["224b"]), min(trial["256"], trial["256b"])
+        keep_mask = t224 <= t256
+        forced = os.environ.get("PARAM_AMD_BENCH_FORCE_CUS", "")      # tests: take this branch whatever the trial said
+        if forced in ("224", "256"):
+            keep_mask = forced == "224"
+        cu_trial = {"step_s_224_cus": t224, "step_s_256_cus": t256, "selected": 224 if keep_mask else 256,
+                    "rule": "the faster of two short trials each (min), clocks max-over-ranks: the same choice on every rank",
+                    **({"forced_by_env": forced} if forced in ("224", "256") else {})}
+        if not keep_mask:
+            torch.cuda.current_stream().synchronize()
+            compute_stream = plain_stream
+            torch.cuda.set_stream(plain_stream)
+            a.lookup_cus = 0
+
+    wall, dev_s = time_steps(rotating(step, zreqs), a.steps, a.warmup, barrier)   # the closing device sync covers exchanges still in flight
     if multi:
         flush()
     wall, dev_s = rank_max(wall, dev_s)
+    single_s = None
+    if not multi and not a.only_headline:      # the same launch replaying request 0 only (the reference's protocol), beside the rotated value
+        _, single_s = time_steps(step, n_sub, 2, barrier)
 
     wl = (f"batched EmbeddingBag(sum) fwd, {a.tables} tables x {R} rows x {D} dim {a.dtype}, batch {B_local}/rank, pool {L}, "
           if a.workload != "criteo" else
-          f"batched EmbeddingBag(sum) fwd, MLPerf DLRM-v2 Criteo tables (26 tables, {sum(all_rows)} rows, dim {D}, {a.dtype}), "
+          f"batched EmbeddingBag(sum) fwd, MLPerf DLRM-v2 Criteo tables (26 tables, {sum(all_rows)} rows, "
+          f"{'mixed dims 16 / 32 / 64 / 128 by table size' if mixed else f'dim {D}'}, {a.dtype}), "
           f"batch {B_local}/rank, multi-hot pooling {sum(all_pool)} lookups/sample, ")
     wl += f"Zipf alpha={a.alpha} (reference pmf, per-bag dedupe)"
     if world == 1 and T_loc < a.tables:
@@ -690,11 +822,12 @@ def main():
         "config": {
             "workload": wl,
             "tables_total": a.tables if world > 1 else T_loc, "tables_per_gpu": split if world > 1 else T_loc,
-            "rows": R if a.workload != "criteo" else "criteo_v2 (3 .. 40M rows, 204.2 M total)", "dim": D,
+            "rows": R if a.workload != "criteo" else "criteo_v2 (3 .. 40M rows, 204.2 M total)",
+            "dim": D if not mixed else {str(d): all_dims.count(d) for d in sorted(set(all_dims))},
             "batch_per_rank": B_local, "global_batch": B_glob, "pooling": L if a.workload != "criteo" else "criteo_v2 multi-hot",
             "alpha": a.alpha, "index_dtype": "int64", "output_layout": ("[W][T_loc][B_local][D] (blocked)" if blocked else "[B, sum D]") if (multi or a.layout == "bd") else "[T, B, D]",
             "parallelism": "1gpu" if world == 1 else f"table-wise x{world} + all-to-all",
-            "lookups_per_step": lookups_step_all,
+            "lookups_per_step": lookups_step_all, "requests_rotated": REQUESTS_ROTATED,
         },
     }
     if shared_gpu:
@@ -724,11 +857,18 @@ def main():
             "achieved": alg_bytes / uni_s / 1e9, "frac": alg_bytes / uni_s / 1e9 / HBM_PEAK_GBPS,
             "run": "uniform indices (alpha = 0): no reuse possible, algorithmic bytes == HBM bytes (the roofline-defining run); "
                    "same kernel, tables and shape as the Zipf launch `value` times",
-            "avg_launch_s": uni_s, "launches_timed": uni_steps, "lookups_per_s_kernel": lookups_step_rank / uni_s})
+            "avg_launch_s": uni_s, "launches_timed": uni_steps, "lookups_per_s_kernel": lookups_step_rank / uni_s,
+            "requests_rotated": REQUESTS_ROTATED if a.alpha != 0.0 else 1,
+            **({"single_request_frac": alg_bytes / uni_single_s / 1e9 / HBM_PEAK_GBPS, "single_request_avg_launch_s": uni_single_s,
+                "single_request_note": "the same launch replaying ONE request (the reference's protocol, pytorch_emb.py:48-69; what rounds 1-5 "
+                                       "reported): up to 256 MB of its rows can stay in the memory-side cache between launches"}
+               if uni_single_s else {})})
     else:
         roof.update({"achieved": None, "frac": None, "run": "uniform run skipped (--no-uniform): no roofline fraction reported"})
     roof["zipf"] = {
         "avg_launch_s": zipf_s, "lookups_per_s_kernel": lookups_step_rank / zipf_s, "algorithmic_GBps": zipf_alg,
+        "requests_rotated": REQUESTS_ROTATED,
+        **({"single_request_avg_launch_s": single_s, "single_request_lookups_per_s": lookups_step_rank / single_s} if single_s else {}),
         "alg_frac": zipf_alg / HBM_PEAK_GBPS,
         "note": "hot rows are served by L2, so algorithmic bytes exceed HBM bytes: alg_frac is a cache-assisted rate, not a roofline fraction",
         "fabric_side_frac": (prof["hbm_bytes_per_launch"] / zipf_s / 1e9 / HBM_PEAK_GBPS) if prof.get("hbm_bytes_per_launch") else None,
@@ -797,6 +937,7 @@ def main():
             result["config"]["grad_bitwidth"] = a.grad_bitwidth
         result["all_to_all"].update({
             "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+            "rccl": {"version": _rccl_version(), "nranks": dist.get_world_size(), "backend": dist.get_backend()},
             # what the reference's busBW is held against on a point-to-point xGMI mesh: (n - 1) links of ~153 GB/s per GPU
             "busbw_over_xgmi_bound": (result["all_to_all"]["busbw_GBps"] / ((world - 1) * 153.0)) if world > 1 else None})
 
@@ -813,11 +954,11 @@ def main():
 
                 def peer_block(src):
                     f0 = sum(split[:src])
-                    r0, p0 = all_rows[f0], all_pool[f0]
-                    key = (r0, D)
+                    r0, p0, d0 = all_rows[f0], all_pool[f0], all_dims[f0]
+                    key = (r0, d0)
                     if key not in scratch:
                         scratch.clear()
-                        scratch[key] = param_amd.EmbeddingBagMI355(r0, D, dtype=dtype, device=dev)
+                        scratch[key] = param_amd.EmbeddingBagMI355(r0, d0, dtype=dtype, device=dev)
                     emb = scratch[key]
                     param_amd.embedding_bag.fill_random_(emb.weight.data, "normal", 0.0, 1.0, seed=(1000 + src) * 1000003 + 0)
                     pi, po = tbe_request([r0], B_glob, [p0], alpha=a.alpha, device=dev, seed=1 + 17 * src)
@@ -836,6 +977,8 @@ def main():
         result["overlap"] = {"step_s": dev_s, "lookup_only_s": zipf_s, "all_to_all_only_s": a2a_s,
                              "overlap_eff": max(zipf_s, a2a_s) / dev_s, "serial_s": zipf_s + a2a_s,
                              "lookup_cus": a.lookup_cus or 256, **({"lookup_cus_note": cu_mask_note} if cu_mask_note else {}),
+                             "cu_mask_selected": (cu_trial["selected"] if cu_trial else (a.lookup_cus or 256)),
+                             "cu_mask_selection": cu_trial if cu_trial else "given on the command line (--lookup-cus)" if not auto_cus else "no masked stream available",
                              "definition": "max(lookup, exchange) / pipelined step: 1.0 = the shorter of the two is fully hidden"}
         # the same pipelined step on the OTHER kind of compute stream (unmasked if the run's is masked, 224 CUs if it is not): whether
         # RCCL's kernels want CUs of their own shows in the difference, on a real mesh
@@ -988,16 +1131,18 @@ def main():
         torch.cuda.empty_cache()
         from param_amd.compute.pt import dataset as ds
 
-        for key, rows_x, pools_x, dt_x, lay_x in (("bf16_T64", [R] * 64, [L] * 64, "bf16", a.layout),
-                                                    ("criteo", list(ds.criteo_v2_rows), list(ds.criteo_v2_multi_hot), "fp32", "bd")):
+        crows, cpool = list(ds.criteo_v2_rows), list(ds.criteo_v2_multi_hot)
+        for key, rows_x, pools_x, dt_x, lay_x, dims_x in (("bf16_T64", [R] * 64, [L] * 64, "bf16", a.layout, 128),
+                                                            ("criteo", crows, cpool, "fp32", "bd", 128),
+                                                            ("criteo_mixed", crows, cpool, "fp32", "bd", ds.criteo_v2_mixed_dims(crows))):
             try:
                 need = sum(rows_x) * ds.criteo_v2_dim * (2 if dt_x == "bf16" else 4) + (24 << 30)
                 free_now, _ = torch.cuda.mem_get_info()
                 if free_now < need:
                     result[key] = {"skipped": f"needs {need / 1e9:.0f} GB of free HBM, {free_now / 1e9:.0f} available after the fp32 block"}
                     continue
-                result[key] = extra_block(dev, rows_x, pools_x, 128, dt_x, B_local, a.alpha, n_sub, barrier, lay_x,
-                                          pmc_key="bf16" if key == "bf16_T64" else "criteo")
+                result[key] = extra_block(dev, rows_x, pools_x, dims_x, dt_x, B_local, a.alpha, n_sub, barrier, lay_x,
+                                          pmc_key={"bf16_T64": "bf16", "criteo": "criteo"}.get(key))
             except Exception as exc:
                 result[key] = {"error": str(exc)[:300]}
             gc.collect()
@@ -1007,6 +1152,9 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     sys.stdout.flush()
+    # LAST key of the line: every roofline fraction of BASELINE configs[1] / [2] / [4] in ~500 characters, so that a record that keeps
+    # only the tail of this line still holds them (fractions of 8 TB/s under uniform indices = *_u; Zipf steps in ms)
+    result["summary"] = _summary(result)
     if rank == 0:
         os.write(json_fd, (json.dumps(result) + "\n").encode())
     os.close(json_fd)

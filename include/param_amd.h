@@ -102,7 +102,18 @@ typedef struct pm_embbag_batch {
        t * B_local * D, out_stride = D, grad_block_extra = (T - 1) * B_local * D).  0 / 0 / 0: no blocking. */
     int32_t table_group;
     int32_t grad_block_shift;
-    int64_t grad_block_extra;
+    int64_t grad_block_extra;      /* (needs grad_block_shift >= 1: a block of one bag is the un-blocked layout) */
+    /* ABI v7: min_t dims[t] if the caller knows it on the host, 0 = not given (then treated as max_dim).  A hint that changes
+       speed only.  The forward sizes its lane groups for max_dim -- G lanes x 16 bytes >= the widest row -- and with one group per
+       bag a D = 16 fp32 table of a request whose widest table has D = 128 would keep 4 of every 32 lanes busy.  When
+       min_dim says the request is MIXED (its narrowest table needs a smaller power-of-two lane group than its widest) the
+       forward runs the flat-walk kernel with the lane group chosen PER TABLE on the device from dims[t] (sub-groups of 4 .. G
+       lanes: a D = 16 row is one 64-byte load by 4 lanes, eight bags per 32-lane slot) and tiles sized per table by their lookups.
+       Results are bit-identical to a max_dim-wide launch (a bag is pooled by one sub-group, additions in index order).  A table
+       narrower than min_dim merely wastes lanes.  Reference: mixed embedding dims, train/comms/pt/dlrm.py:384-385 (`mixed_dim`
+       -> torch.cat(ly, dim=1)), :506-557. */
+    int32_t min_dim;
+    int32_t reserved0;             /* 0 */
 } pm_embbag_batch;
 
 /* ABI / build identification. */
@@ -346,19 +357,6 @@ int pm_set_tuning(int32_t unroll, int32_t bags_per_block, int32_t xcd_affine, in
  * reads (uniform indices: 0.69 -> 0.72-0.74 of the HBM peak).
  */
 int pm_set_forward_tuning(int32_t stage_out);
-
-/*
- * Persistent forward (ABI v6; csrc/embbag_fwd_persist.hip): for requests the staged-burst kernel serves (fixed pooling,
- * fp32 output) the launch is `wgs_per_cu` workgroups per compute unit that loop over the request's tiles in the dispatch
- * order's (table, tile) sequence; each workgroup = `pool_waves` (4 or 7) pooling waves that issue row loads and LDS
- * accesses only + ONE helper wave that stages the coming tiles' offsets / indices into a ring of `slots` LDS slots and
- * writes finished tiles' pooled rows to memory -- no workgroup-wide barrier, no store in a pooling wave's memory queue.
- * A tile is (bags pooled concurrently) x `bags_per_group` bags.  mode: 0 = never (the default at -1: embbag_fwd_kernel's
- * launch of one workgroup per tile -- measured equal under uniform indices and 4-9 % faster under Zipf),
- * 1 = requests of at least 8 tiles per resident workgroup, 2 = every eligible request whatever its size (tests).  0 for the
- * other arguments = default.  Results are bit-identical in every setting.
- */
-int pm_set_forward_persist(int32_t mode, int32_t slots, int32_t bags_per_group, int32_t pool_waves, int32_t wgs_per_cu);
 
 /*
  * Tuning knobs of the sorted backward (process-wide; -1 = default, which the environment can change:

@@ -48,7 +48,6 @@ EXPORTED_SYMBOLS = (
     "pm_fill_random",
     "pm_set_tuning",
     "pm_set_forward_tuning",
-    "pm_set_forward_persist",
     "pm_set_backward_tuning",
     "pm_set_sort_tuning",
     "pm_radix_sort_scratch_bytes",
@@ -110,6 +109,8 @@ class pm_embbag_batch(ctypes.Structure):
         ("table_group", ctypes.c_int32),
         ("grad_block_shift", ctypes.c_int32),
         ("grad_block_extra", ctypes.c_int64),
+        ("min_dim", ctypes.c_int32),
+        ("reserved0", ctypes.c_int32),
     ]
 
 
@@ -194,8 +195,6 @@ def load() -> ctypes.CDLL:
         L.pm_set_tuning.argtypes = [i32, i32, i32, i32]
         L.pm_set_forward_tuning.restype = ctypes.c_int
         L.pm_set_forward_tuning.argtypes = [i32]
-        L.pm_set_forward_persist.restype = ctypes.c_int
-        L.pm_set_forward_persist.argtypes = [i32, i32, i32, i32, i32]
         L.pm_set_backward_tuning.restype = ctypes.c_int
         L.pm_set_backward_tuning.argtypes = [i32, i32, i32, i32]
         L.pm_embbag_sorted_pairs.restype = ctypes.c_int
@@ -231,12 +230,6 @@ def set_tuning(unroll: int = 0, bags_per_block: int = 0, xcd_affine: int = -1, n
 def set_forward_tuning(stage_out: int = -1) -> None:
     """``pm_set_forward_tuning``: 1 (default) = LDS-staged output burst per tile, 0 = one row store per finished bag"""
     check(load().pm_set_forward_tuning(stage_out))
-
-
-def set_forward_persist(mode: int = -1, slots: int = 0, bags_per_group: int = 0, pool_waves: int = 0, wgs_per_cu: int = 0) -> None:
-    """``pm_set_forward_persist``: the persistent forward (pooling waves + one helper wave per workgroup, looping over tiles):
-    mode 0 never (default) / 1 large requests / 2 every eligible request; 0 elsewhere = default.  Same bits in every setting."""
-    check(load().pm_set_forward_persist(mode, slots, bags_per_group, pool_waves, wgs_per_cu))
 
 
 def set_backward_tuning(sort_impl: int = -1, order: int = -1, xcd_affine: int = -1, max_phases: int = -1) -> None:

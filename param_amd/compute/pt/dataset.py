@@ -21,3 +21,11 @@ criteo_v2_rows = [40000000, 39060, 17295, 7424, 20265, 3, 7122, 1543, 63, 400000
                   11938, 155, 4, 976, 14, 40000000, 40000000, 40000000, 590152, 12973, 108, 36]
 criteo_v2_multi_hot = [3, 2, 1, 2, 6, 1, 1, 1, 1, 7, 3, 8, 1, 6, 9, 5, 1, 1, 1, 12, 100, 27, 10, 3, 1, 1]
 criteo_v2_dim = 128
+
+
+def criteo_v2_mixed_dims(rows=None):
+    """Embedding dims of a MIXED-dim DLRM over the Criteo tables (BASELINE configs[4] says "mixed-dim"; the reference's hook is
+    train/comms/pt/dlrm.py:384-385 ``mixed_dim -> torch.cat(ly, dim=1)``, dims from :506-557): by table size -- rows >= 10 M -> 128,
+    >= 100 K -> 64, >= 1 K -> 32, else 16 (the round-5 review's rule; the reference publishes none)."""
+    rows = criteo_v2_rows if rows is None else rows
+    return [128 if r >= 10_000_000 else 64 if r >= 100_000 else 32 if r >= 1_000 else 16 for r in rows]

@@ -20,21 +20,6 @@ std::atomic<int> g_bags_per_block{0};
 std::atomic<int> g_xcd_affine{-1};
 std::atomic<int> g_nt_loads{-1};
 std::atomic<int> g_stage_out{-1};
-// persistent forward (embbag_fwd_persist.hip; pm_set_forward_persist): mode 1 = for requests large enough to keep every
-// workgroup busy for several tiles, 0 (and -1, the default) = never, 2 = whenever the request is eligible (tests); the rest 0 = default.
-// OFF by default: measured on two boxes (profiles/r05_fwd_persist_*.jsonl), bit-identical and, at its best geometry (16-bag tiles, 4
-// workgroups per CU), within 1 % of embbag_fwd_kernel under uniform indices (746-752 vs 745-746 us) and 4-9 % behind it under Zipf
-// (371-388 vs 355 us): the launch is bound by the memory system (uniform: the fabric's random-row rate; Zipf: 6.3 TB/s through the
-// fabric at a 48 % L2 hit rate), not by the workgroup's barrier / burst / relaunch sequence the persistent form removes.
-std::atomic<int> g_ps_mode{-1};
-std::atomic<int> g_ps_slots{0};
-std::atomic<int> g_ps_bags_per_group{0};
-std::atomic<int> g_ps_pool_waves{0};
-std::atomic<int> g_ps_wgs_per_cu{0};
-constexpr int kPsDefaultSlots = 3;
-constexpr int kPsDefaultBagsPerGroup = 2;
-constexpr int kPsDefaultPoolWaves = 4;
-
 // destination-row cache policy of the sorted backward when pm_set_tuning leaves nt_loads at its default: plain loads,
 // agent-scope (sc1) stores.  The store writes through and drops the row's lines from the XCD's L2, so a row occupies L2 only
 // between its load and its store and the gradient rows -- re-read once per lookup of their bag -- keep the capacity
@@ -100,6 +85,8 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
         return fail(PM_ERR_UNSUPPORTED, "every dims[t] (and max_dim) must be a multiple of " +
                                             std::to_string(vec) + " for this element type");
     if (op->out_stride % 4 != 0) return fail(PM_ERR_UNSUPPORTED, "out_stride must be a multiple of 4 elements");
+    if (op->min_dim < 0 || op->min_dim > op->max_dim || (op->min_dim > 0 && op->min_dim % vec != 0))
+        return fail(PM_ERR_INVALID, "min_dim must be 0 (not given) or a multiple of the vector width in [1, max_dim]");
     if (op->fixed_pooling < 0 ||
         (op->fixed_pooling > 0 && op->fixed_pooling * op->batch * static_cast<int64_t>(op->num_tables) != op->num_indices))
         return fail(PM_ERR_INVALID, "fixed_pooling must be 0 or num_indices / (num_tables * batch)");
@@ -178,6 +165,12 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
     p.alpha = 1.0f;
     if (op->grad_block_shift < 0 || op->grad_block_shift > 31 || op->grad_block_extra < 0 || op->table_group < 0)
         return fail(PM_ERR_INVALID, "grad_block_shift must be in [0, 31], grad_block_extra and table_group >= 0");
+    // a blocked gradient needs blocks of at least two bags that tile the batch (shift 0 with a non-zero extra used to read
+    // the un-blocked layout without a word, and so did a batch that is not a whole number of blocks)
+    if (op->grad_block_shift == 0 && op->grad_block_extra != 0)
+        return fail(PM_ERR_INVALID, "grad_block_extra needs grad_block_shift >= 1 (a block of one bag is the un-blocked layout)");
+    if (op->grad_block_shift > 0 && (op->batch & ((static_cast<int64_t>(1) << op->grad_block_shift) - 1)) != 0)
+        return fail(PM_ERR_INVALID, "batch must be a multiple of 2^grad_block_shift bags");
     p.gblk_shift = op->grad_block_shift > 0 ? op->grad_block_shift : 31;
     p.gblk_extra = op->grad_block_shift > 0 ? op->grad_block_extra : 0;
     // LDS-staged output (forward): the tile's pooled rows leave in one burst at the end of the tile (embbag_fwd.hip).
@@ -191,7 +184,6 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
     p.stage_bags = 0;
     p.flat_bags = 0;
     p.flat_target = 0;
-    p.ps_slots = 0;
     if (forward) {
         const FwdEnv& env = fwd_env();
         int want = g_stage_out.load();
@@ -255,6 +247,33 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
             p.flat_target = tgt_env < 1 ? 1 : tgt_env;
             p.bags_per_block = p.flat_bags;   // sizes the LDS offsets array; stage_bags (the burst buffer) stays at NG rows
         }
+        // ABI v7, mixed embedding dims (min_dim given and its lane group narrower than max_dim's): the flat-walk kernel sizes the lane
+        // group PER TABLE on the device (embbag_fwd.hip), whatever the bags look like -- tiles are ~flat_target lookups of any pooling
+        // factor.  flat_bags = the bags the narrowest table's sub-groups pool at once (at least the usual 32): the LDS offsets array.
+        // Ragged requests keep the ordered kernel (longest bag first matters more there than idle lanes).
+        if (flat_on && op->min_dim > 0 && op->min_dim < op->max_dim && !p.ordered && g_bags_per_block.load() <= 0) {
+            int need = (op->min_dim + vec - 1) / vec, g_min = 4;          // sub-groups of 4 lanes at least: 64-byte pieces
+            while (g_min < need) g_min <<= 1;
+            if (g_min < G) {
+                const int ng_max = pm::kBlock / g_min;
+                const int64_t tiles_ng = (op->bag_count + NG - 1) / NG;   // the grid of the smallest tile: the widest table's NG bags
+                if (tiles_ng * op->num_tables <= 0x7fffffffLL) {
+                    if (p.flat_bags < ng_max) p.flat_bags = ng_max;
+                    if (p.flat_bags < 32) p.flat_bags = 32;
+                    if (p.flat_target <= 0) p.flat_target = env.flat_target < 1 ? 1 : env.flat_target;
+                    p.tiles_per_table = static_cast<int32_t>(tiles_ng);
+                    p.bags_per_block = p.flat_bags;
+                    p.stage_out = op->max_dim;
+                    p.stage_bags = NG;                                    // burst buffer: NG rows of max_dim floats (4 KB at D = 128 fp32)
+                    // index tile: twice what a tile holds on average -- ~flat_target lookups, or the narrowest table's ng_max bags
+                    int64_t cap2 = 2 * static_cast<int64_t>(ng_max) * avg_l;
+                    if (cap2 < 2 * static_cast<int64_t>(p.flat_target)) cap2 = 2 * static_cast<int64_t>(p.flat_target);
+                    cap2 = (cap2 + 255) / 256 * 256;
+                    p.idx_cap = static_cast<int32_t>(cap2 < 1024 ? 1024 : (cap2 > 4096 ? 4096 : cap2));
+                    if (p.xcd_affine == 3) p.xcd_affine = 0;             // eighths of the tile order assume equal tiles per table
+                }
+            }
+        }
         // Two tilings built and measured in round 3 for requests whose tables have very different pooling factors (Criteo
         // multi-hot 1 .. 100) -- both slower than the 8-bag tiles in table-major order, which stay:
         //  * WORK tiles (~640 lookups per tile whatever the pooling factor, tile boundaries derived on the device from the
@@ -270,52 +289,6 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
         if (p.xcd_affine != 1 && op->num_tables > 1 && tm_env > 0 && uneven) p.xcd_affine = 2;
     }
     return PM_OK;
-}
-
-// Persistent forward: decide and size.  Eligible = what the staged-burst kernel serves (fixed-pooling request, fp32 output,
-// bag-count tiles); the geometry of `p` is rewritten for embbag_fwd_persist_kernel (tile = bags pooled concurrently x bags per
-// lane group, one index slot sized for twice the tile's average lookups).  Returns false to keep the classic launch.
-bool configure_persist(const pm_embbag_batch* op, pm::KParams& p, int& pool_waves, int& wgs_per_cu) {
-    const int mode = g_ps_mode.load();
-    if (mode <= 0) return false;
-    if (!(p.stage_out > 0 && !p.ordered && p.flat_bags == 0 && p.out_bits == 0)) return false;
-    const int vec = (op->weight_dtype == PM_F32) ? 4 : 8;
-    const int G = pm::group_lanes(op->max_dim, vec);
-    pool_waves = g_ps_pool_waves.load() == 7 ? 7 : (g_ps_pool_waves.load() == 4 ? 4 : kPsDefaultPoolWaves);
-    const int NG = pool_waves * (pm::kWave / G);
-    int bpg = g_ps_bags_per_group.load();
-    if (bpg <= 0) bpg = kPsDefaultBagsPerGroup;
-    while (bpg > 1 && NG * bpg + 1 > pm::kWave) --bpg;           // the helper wave stages a tile's offsets one per lane
-    const int tb = NG * bpg;
-    if (tb + 1 > pm::kWave) return false;
-    int slots = g_ps_slots.load();
-    if (slots <= 0) slots = kPsDefaultSlots;
-    if (slots < 2) slots = 2;
-    if (slots > 8) slots = 8;
-    const int64_t total_bags = static_cast<int64_t>(op->num_tables) * op->batch;
-    const int64_t avg_l = total_bags > 0 ? (op->num_indices + total_bags - 1) / total_bags : 0;
-    int64_t cap = (2 * static_cast<int64_t>(tb) * avg_l + 63) / 64 * 64;
-    if (cap < 64) cap = 64;
-    if (cap > 4096) cap = 4096;
-    const bool weighted = op->per_sample_weights != nullptr;
-    size_t lds = pm::fwd_persist_lds_bytes(tb, static_cast<int>(cap), weighted, p.stage_out, slots);
-    while (lds > 64 * 1024 && slots > 2) lds = pm::fwd_persist_lds_bytes(tb, static_cast<int>(cap), weighted, p.stage_out, --slots);
-    if (lds > 64 * 1024) return false;
-    const int64_t tiles = (op->bag_count + tb - 1) / tb;
-    if (tiles * op->num_tables > 0x7fffffffLL) return false;
-    int by_lds = static_cast<int>((160 * 1024) / lds);
-    int by_waves = 32 / (pool_waves + 1);
-    wgs_per_cu = g_ps_wgs_per_cu.load();
-    if (wgs_per_cu <= 0) wgs_per_cu = by_lds < by_waves ? by_lds : by_waves;
-    if (wgs_per_cu < 1) wgs_per_cu = 1;
-    // worth it only when a workgroup loops over several tiles (start-up is one two-round-trip prologue per workgroup, as before)
-    if (mode != 2 && tiles * op->num_tables < 8LL * 256 * wgs_per_cu) return false;
-    p.bags_per_block = tb;
-    p.tiles_per_table = static_cast<int32_t>(tiles);
-    p.idx_cap = static_cast<int32_t>(cap);
-    p.stage_bags = tb;
-    p.ps_slots = slots;
-    return true;
 }
 
 }  // namespace
@@ -344,20 +317,6 @@ int pm_set_tuning(int32_t unroll, int32_t bags_per_block, int32_t xcd_affine, in
 int pm_set_forward_tuning(int32_t stage_out) {
     if (stage_out < -1 || stage_out > 1) return fail(PM_ERR_INVALID, "stage_out must be -1, 0 or 1");
     g_stage_out.store(stage_out);
-    return PM_OK;
-}
-
-int pm_set_forward_persist(int32_t mode, int32_t slots, int32_t bags_per_group, int32_t pool_waves, int32_t wgs_per_cu) {
-    if (mode < -1 || mode > 2) return fail(PM_ERR_INVALID, "mode must be -1 (default), 0 (off), 1 (large requests) or 2 (every eligible request)");
-    if (slots < 0 || slots == 1 || slots > 8) return fail(PM_ERR_INVALID, "slots must be 0 (default) or 2 .. 8");
-    if (bags_per_group < 0 || bags_per_group > 8) return fail(PM_ERR_INVALID, "bags_per_group must be 0 (default) or 1 .. 8");
-    if (pool_waves != 0 && pool_waves != 4 && pool_waves != 7) return fail(PM_ERR_INVALID, "pool_waves must be 0 (default), 4 or 7");
-    if (wgs_per_cu < 0 || wgs_per_cu > 8) return fail(PM_ERR_INVALID, "wgs_per_cu must be 0 (default) or 1 .. 8");
-    g_ps_mode.store(mode);
-    g_ps_slots.store(slots);
-    g_ps_bags_per_group.store(bags_per_group);
-    g_ps_pool_waves.store(pool_waves);
-    g_ps_wgs_per_cu.store(wgs_per_cu);
     return PM_OK;
 }
 
@@ -485,13 +444,7 @@ int pm_embbag_fwd(const pm_embbag_batch* op, float* out, pm_stream_t stream) {
     p.io = out;
     int unroll = g_unroll.load();
     if (unroll == 0) unroll = kDefaultUnroll;
-    int pool_waves = 0, wgs_per_cu = 0;
-    hipError_t h;
-    if (configure_persist(op, p, pool_waves, wgs_per_cu))
-        h = pm::launch_embbag_fwd_persist(p, op->weight_dtype, op->max_dim, unroll == 3 || unroll == 6 ? 2 : unroll, pool_waves, wgs_per_cu,
-                                          static_cast<hipStream_t>(stream));
-    else
-        h = pm::launch_embbag_fwd(p, op->weight_dtype, op->max_dim, unroll, static_cast<hipStream_t>(stream));
+    const hipError_t h = pm::launch_embbag_fwd(p, op->weight_dtype, op->max_dim, unroll, static_cast<hipStream_t>(stream));
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_fwd launch");
     return PM_OK;
 }
@@ -594,10 +547,25 @@ int pm_embbag_sort_indices_ex(const pm_embbag_batch* op, int64_t max_rows, int32
     return sort_request(op, max_rows, phases, workspace, workspace_bytes, stream, false);
 }
 
+// The fused calls validate what their APPLY half needs before the sort half launches anything (a NULL gradient or a bad
+// dtype used to be found after the sort's kernels -- and, on the hybrid path, after a deferred plan -- had been issued).
+static int fused_apply_args_ok(const pm_embbag_batch* op, const float* grad, void* const* tables, int32_t dtype) {
+    if (!op) return fail(PM_ERR_INVALID, "op is NULL");
+    if (!dtype_is_weight(dtype)) return fail(PM_ERR_INVALID, "weight/dst dtype must be PM_F32, PM_BF16 or PM_F16");
+    if (!grad || !tables) return fail(PM_ERR_INVALID, "grad / dst_tables is NULL");
+    return PM_OK;
+}
+
 int pm_embbag_bwd_fused(const pm_embbag_batch* op, const float* grad, void* const* dst_tables, int32_t dst_dtype, float alpha,
                         int64_t max_rows, void* workspace, int64_t workspace_bytes, pm_stream_t stream) {
     if (op && (op->num_indices == 0 || op->bag_count == 0)) return PM_OK;
-    int rc = sort_request(op, max_rows, 1, workspace, workspace_bytes, stream, true);
+    int rc = fused_apply_args_ok(op, grad, dst_tables, dst_dtype);
+    if (rc != PM_OK) return rc;
+    {
+        pm::KParams chk;                            // the apply builds its parameters for the DESTINATION dtype: its row-width rule too
+        if ((rc = make_params(op, dst_dtype, chk)) != PM_OK) return rc;
+    }
+    rc = sort_request(op, max_rows, 1, workspace, workspace_bytes, stream, true);
     if (rc != PM_OK) return rc;
     return pm_embbag_bwd_sorted(op, grad, dst_tables, dst_dtype, alpha, max_rows, workspace, workspace_bytes, stream);
 }
@@ -606,7 +574,19 @@ int pm_embbag_bwd_fused_adagrad(const pm_embbag_batch* op, const float* grad, vo
                                 float* const* momentum, const pm_rowwise_adagrad* opt, int64_t max_rows, void* workspace,
                                 int64_t workspace_bytes, pm_stream_t stream) {
     if (op && (op->num_indices == 0 || op->bag_count == 0)) return PM_OK;
-    int rc = sort_request(op, max_rows, 1, workspace, workspace_bytes, stream, true);
+    int rc = fused_apply_args_ok(op, grad, tables, table_dtype);
+    if (rc != PM_OK) return rc;
+    {
+        pm::KParams chk;
+        if ((rc = make_params(op, table_dtype, chk)) != PM_OK) return rc;
+    }
+    if (!opt) return fail(PM_ERR_INVALID, "optimizer options are NULL");
+    if (opt->weight_decay_mode != PM_WD_NONE && opt->weight_decay_mode != PM_WD_L2 && opt->weight_decay_mode != PM_WD_DECOUPLE)
+        return fail(PM_ERR_INVALID, "weight_decay_mode must be PM_WD_NONE, PM_WD_L2 or PM_WD_DECOUPLE");
+    if (!momentum) return fail(PM_ERR_INVALID, "grad / tables / momentum is NULL");
+    if (op->max_dim > 64 * ((table_dtype == PM_F32) ? 4 : 8))
+        return fail(PM_ERR_UNSUPPORTED, "row-wise Adagrad needs max_dim <= " + std::to_string(64 * ((table_dtype == PM_F32) ? 4 : 8)) + " for this table dtype");
+    rc = sort_request(op, max_rows, 1, workspace, workspace_bytes, stream, true);
     if (rc != PM_OK) return rc;
     return pm_embbag_bwd_sorted_adagrad_ex(op, grad, tables, table_dtype, momentum, opt, max_rows, workspace, workspace_bytes, stream);
 }

@@ -60,8 +60,6 @@ struct KParams {
     int32_t flat_target;         // ... lookups per tile aimed at
     int32_t gblk_shift;          // backward kernels: blocked gradient layout (ABI v6, pm_embbag_batch::grad_block_shift): bag b of table t at
     int64_t gblk_extra;          //   io + out_offsets[t] + b * out_stride + (b >> gblk_shift) * gblk_extra ; no blocking: extra = 0
-    int32_t ps_slots;            // forward: > 0 = the persistent kernel (embbag_fwd_persist.hip) with this many ring slots; bags_per_block is
-                                 // then its tile (a multiple of the bags pooled concurrently), idx_cap the index entries per slot
     float alpha;                 // bwd scale
 };
 
@@ -170,10 +168,6 @@ __host__ __device__ inline size_t tile_lds_bytes(int bags_per_block, int idx_cap
 // ---- host-side launchers implemented in the kernel files ----------------------------------
 hipError_t launch_embbag_fwd(const KParams& p, int weight_dtype, int max_dim, int unroll,
                              hipStream_t stream);
-// persistent forward (embbag_fwd_persist.hip): pool_waves 4 or 7 pooling waves + one helper wave per workgroup
-size_t fwd_persist_lds_bytes(int tile_bags, int idx_cap, bool weighted, int row_floats, int slots);
-hipError_t launch_embbag_fwd_persist(const KParams& p, int weight_dtype, int max_dim, int unroll, int pool_waves, int wgs_per_cu,
-                                     hipStream_t stream);
 hipError_t launch_embbag_fwd_split(const KParams& p, int weight_dtype, int max_dim, hipStream_t stream);
 hipError_t launch_embbag_bwd(const KParams& p, int dst_dtype, int max_dim, hipStream_t stream);
 hipError_t launch_embbag_check(const KParams& p, int32_t* d_err, int vec, int max_dim, int64_t fixed_pooling,
@@ -302,7 +296,7 @@ struct SegSortRequest {
     uint32_t* queue_b;       // buffers: nothing else touches them before the bag-major apply); NULL: every slice scans its table
     uint32_t spin_cap;       // look-back polls before a walk gives up (0 = default)
 };
-size_t seg_sort_scratch_bytes(size_t n_max, int T);
+size_t seg_sort_scratch_bytes(size_t n_max, int T, bool hybrid_possible = true);   // false (weighted requests): no dup maps / stage
 int seg_sort_radix_bits(int mode, int rbits_max);   // 8, or 9 where a 9-bit digit saves a global pass (mode 0)
 bool seg_sort_lookback(int mode, int rbits_max, int64_t n);   // mode 0 as one kernel per pass (tiles learn their prefixes from their predecessors in flight)
 int seg_sort_passes(int mode, int rbits_max);

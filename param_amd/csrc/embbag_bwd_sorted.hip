@@ -222,7 +222,7 @@ hipError_t ws_layout(void* base, int64_t n, int T, int key_bytes, int kbits_sort
     const size_t own = rs_scratch_bytes(static_cast<size_t>(n));
     if (own > tb) tb = own;
     if (T <= kSegSortMaxTables) {
-        const size_t seg = seg_sort_scratch_bytes(static_cast<size_t>(n), T);
+        const size_t seg = seg_sort_scratch_bytes(static_cast<size_t>(n), T, !weighted);
         if (seg > tb) tb = seg;
     }
     char* p = reinterpret_cast<char*>(base);

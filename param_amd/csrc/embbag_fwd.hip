@@ -283,14 +283,25 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
 //     ACROSS bag borders (a pooling-1 bag is one load: bag by bag, a group would have one load in flight); a bag's sum leaves
 //     when the walk passes its end.  Additions happen in index order inside every bag, from zero: same bits as the other kernel.
 
+//   * (round 6) the LANE GROUP is sized per table too: a request whose tables differ in width (mixed embedding dims, reference
+//     dlrm.py:384-385) is launched with G lanes x 16 bytes >= its WIDEST row, and a group of G lanes per bag would leave a D = 16
+//     fp32 table 4 busy lanes of 32.  A workgroup therefore cuts its 256 lanes into sub-groups of g = the next power of two >=
+//     D_t / VEC lanes (at least kBlock / flat_bags, so that a tile's bags still fit the LDS offsets array; at most G): a D = 16
+//     row is one 64-byte load by 4 lanes and a 32-lane slot pools eight bags at once.  The tile stays ~flat_target lookups
+//     whatever the width, so the index tile in LDS is what it was.  A bag is pooled by ONE sub-group, additions in index order
+//     from zero: the same bits whatever g.  Requests of one width compute g = G.
 template <typename WT, int G, int UNROLL, bool WEIGHTED>
 __global__ void __launch_bounds__(kBlock) embbag_fwd_flat_kernel(const KParams p) {
     constexpr int VEC = Elem<WT>::kVec;
-    constexpr int NG = kBlock / G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int t, tile;
     block_to_tile(p, t, tile);
     if (t >= p.T) return;
+    const int D = p.dims[t];
+    int g = kBlock / p.flat_bags;                  // narrowest sub-group the tile geometry allows (host: make_params)
+    if (g < 1) g = 1;
+    while (g < G && g * VEC < D) g <<= 1;
+    const int NG = kBlock / g;                     // bags pooled concurrently by this workgroup
     const int64_t g0 = static_cast<int64_t>(t) * p.B + p.bag_begin;
     const int64_t lo = bag_start_or_end(p, g0), hi = bag_start_or_end(p, g0 + p.bag_count);
     const int64_t avg = p.bag_count > 0 ? (hi - lo + p.bag_count - 1) / p.bag_count : 1;
@@ -308,23 +319,24 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_flat_kernel(const KParams p
     float* s_w;
     const bool staged = stage_tile_at<WEIGHTED>(p, t, bag0, nb, smem, s_off, s_idx, s_w);
     const int64_t base = s_off[0];
-    const int gid = threadIdx.x / G;
-    const int lig = threadIdx.x % G;
-    const int D = p.dims[t];
+    const int gid = threadIdx.x / g;
+    const int lig = threadIdx.x % g;
     constexpr int ES = 16 / VEC;
     const int64_t row_bytes = static_cast<int64_t>(D) * ES;
     const char* W = reinterpret_cast<const char*>(p.tables[t]);
     float* out_t = p.io + p.out_offsets[t];
     const bool nt = p.nt_loads != 0;
     float* s_out = reinterpret_cast<float*>(smem + tile_lds_bytes(p.bags_per_block, p.idx_cap, WEIGHTED));
-    const bool stage = p.stage_out > 0 && nb <= p.stage_bags;      // small tiles (long bags) leave in one burst, like the other kernel
+    // small tiles (long bags) leave in one burst, like the other kernel: the buffer holds stage_bags rows of stage_out floats -- a
+    // narrow table's tile has more, shorter rows
+    const bool stage = p.stage_out > 0 && static_cast<int64_t>(nb) * D <= static_cast<int64_t>(p.stage_bags) * p.stage_out;
     const int per = (nb + NG - 1) / NG;
     const int b_lo = gid * per;
     const int b_hi = b_lo + per < nb ? b_lo + per : nb;
 
     auto walk = [&](auto staged_c) {
         constexpr bool ST = decltype(staged_c)::value;
-        for (int c = lig * VEC; c < D; c += G * VEC) {
+        for (int c = lig * VEC; c < D; c += g * VEC) {
             const char* Wc = W + static_cast<int64_t>(c) * ES;
             float acc[VEC];
 #pragma unroll

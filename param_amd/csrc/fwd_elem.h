@@ -1,5 +1,4 @@
-// param_amd/csrc/fwd_elem.h -- element types and row-load helpers shared by the forward kernels (embbag_fwd.hip,
-// embbag_fwd_persist.hip).  gfx950 only.
+// param_amd/csrc/fwd_elem.h -- element types and row-load helpers of the forward kernels (embbag_fwd.hip).  gfx950 only.
 #pragma once
 
 #include "common.h"

@@ -1356,7 +1356,10 @@ struct Scratch {
     size_t total;
 };
 
-Scratch scratch_layout(void* base, size_t n, int T) {
+// hyb = the request can take the hybrid backward (unweighted): only then does the layout END with the dup maps (256 KB .. 4 MB per
+// table: up to 512 MB at 128 tables), the per-tile counts, the slice queues' lengths and the left-over stage.  Everything before them
+// sits where it sits either way, so the accessors below need not know (weighted requests used to reserve all of it).
+Scratch scratch_layout(void* base, size_t n, int T, bool hyb = true) {
     Scratch s;
     char* p = reinterpret_cast<char*>(base);
     size_t off = 0;
@@ -1378,11 +1381,12 @@ Scratch scratch_layout(void* base, size_t n, int T) {
     s.bstart_all = reinterpret_cast<uint32_t*>(take(4 * static_cast<size_t>(T) * kLbRowWords));
     const size_t th = static_cast<size_t>(T < kHybMaxTables ? T : kHybMaxTables);
     s.hyb_tab = reinterpret_cast<HybTable*>(take(sizeof(HybTable) * static_cast<size_t>(T)));
-    s.bloom = reinterpret_cast<uint32_t*>(take(4 * th * static_cast<size_t>(hyb_slices(static_cast<int64_t>(n), T)) * kBloomWords));
-    s.tile_cnt = reinterpret_cast<uint32_t*>(take(4 * th * tile_cnt_stride(n)));
-    s.qtail = reinterpret_cast<uint32_t*>(take(4 * th * static_cast<size_t>(kBloomKMax)));
-    s.rest_stage = reinterpret_cast<uint32_t*>(take(4 * th * 2 * static_cast<size_t>(kRestCap)));
-    s.rest_n = reinterpret_cast<uint32_t*>(take(4 * th));
+    const size_t hy = hyb ? 1 : 0;
+    s.bloom = reinterpret_cast<uint32_t*>(take(hy * 4 * th * static_cast<size_t>(hyb_slices(static_cast<int64_t>(n), T)) * kBloomWords));
+    s.tile_cnt = reinterpret_cast<uint32_t*>(take(hy * 4 * th * tile_cnt_stride(n)));
+    s.qtail = reinterpret_cast<uint32_t*>(take(hy * 4 * th * static_cast<size_t>(kBloomKMax)));
+    s.rest_stage = reinterpret_cast<uint32_t*>(take(hy * 4 * th * 2 * static_cast<size_t>(kRestCap)));
+    s.rest_n = reinterpret_cast<uint32_t*>(take(hy * 4 * th));
     s.total = off;
     return s;
 }
@@ -1390,7 +1394,7 @@ Scratch scratch_layout(void* base, size_t n, int T) {
 }  // namespace
 
 
-size_t seg_sort_scratch_bytes(size_t n_max, int T) { return scratch_layout(nullptr, n_max, T).total; }
+size_t seg_sort_scratch_bytes(size_t n_max, int T, bool hybrid_possible) { return scratch_layout(nullptr, n_max, T, hybrid_possible).total; }
 
 const SegDesc* seg_sort_desc(const void* scratch, size_t n_max, int T) { return scratch_layout(const_cast<void*>(scratch), n_max, T).desc; }
 const uint32_t* seg_sort_count(const void* scratch, size_t n_max, int T) {
@@ -1474,7 +1478,8 @@ hipError_t seg_sort_part_a(const SegSortRequest& rq, void* scratch, hipStream_t 
     HybArgs hyb = rq.hyb;
     if (rq.weighted) hyb.allow = 0;
     hipLaunchKernelGGL(seg_prep_tables_kernel, dim3(rq.T), dim3(1024), 0, stream, rq.indices, rq.offsets, rq.idx64, rq.rows, rq.T, rq.B, rq.N,
-                       rq.bag_begin, rq.bag_count, rq.weighted ? 1 : 0, s.desc, rq.zero4, hyb, s.hyb_tab, s.qtail, &s.hdr->rest_pairs);
+                       rq.bag_begin, rq.bag_count, rq.weighted ? 1 : 0, s.desc, rq.zero4, hyb, s.hyb_tab, hyb.allow ? s.qtail : nullptr,
+                       &s.hdr->rest_pairs);
     if (hyb.allow) {
         if (!seg_sort_hybrid_available()) return hipErrorInvalidValue;      // (sort_indices asks first and does not offer the path then)
         const int th = rq.T < kHybMaxTables ? rq.T : kHybMaxTables;

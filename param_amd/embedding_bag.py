@@ -94,6 +94,7 @@ class _TableSet:
         self._blk_cache: dict = {}
         self.T = len(tables)
         self.max_dim = max(self.dims)
+        self.min_dim = min(self.dims)
         self.total_dim = sum(self.dims)
         self.ptrs = [t.data_ptr() for t in tables]
         self.d_ptrs = torch.tensor(self.ptrs, dtype=torch.int64, device=self.device)
@@ -105,7 +106,7 @@ class _TableSet:
         self.col0 = col0
         self.d_col0 = torch.tensor(col0, dtype=torch.int64, device=self.device)
         self._tbd_cache: dict[int, torch.Tensor] = {}
-        self._req_key, self._req_op = None, None
+        self._req: dict = {}         # one cached descriptor per kind of request (forward of a blocked layout / everything else)
         self._pool_key, self._pool_val = None, 0
 
     def out_desc(self, B: int):
@@ -148,10 +149,14 @@ class _TableSet:
                offsets.data_ptr(), offsets.numel(), offsets.dtype, offsets.is_contiguous(), offsets.device, B,
                None if psw is None else (psw.data_ptr(), psw.numel(), psw.dtype, psw.is_contiguous(), psw.device),
                bag_begin, bag_count, None if d_ptrs is None else d_ptrs.data_ptr(), forward and self.layout == "blocked")
-        if key == self._req_key:
-            return self._req_op
+        # (two slots: with layout="blocked" the forward descriptor -- T * W request tables -- and the backward's -- T tables with a
+        # blocked gradient -- differ, and a training loop alternates between them)
+        slot = bool(forward and self.layout == "blocked")
+        hit = self._req.get(slot)
+        if hit is not None and hit[0] == key:
+            return hit[1]
         op = self._build_request(indices, offsets, B, psw, bag_begin, bag_count, d_ptrs, forward)
-        self._req_key, self._req_op = key, op
+        self._req[slot] = (key, op)
         return op
 
     def fixed_pooling(self, indices, offsets, B, claim: Optional[int] = None) -> int:
@@ -194,6 +199,7 @@ class _TableSet:
         op.weight_dtype = _WDTYPE[self.dtype]
         op.index_dtype = _IDTYPE[indices.dtype]
         op.max_dim = self.max_dim
+        op.min_dim = self.min_dim          # ABI v7: lets the forward pick its lane-group width per table for mixed-dim requests
         op.batch = B
         op.num_indices = indices.numel()
         op.bag_begin = bag_begin

@@ -31,7 +31,9 @@ def test_library_loads_and_exports_every_symbol():
 
 def test_struct_layout_matches_header():
     # 4 x int32, 4 x int64, 4 pointers, int64, 3 pointers, int64 = 16 + 32 + 32 + 8 + 24 + 8; ABI v6: + 2 x int32 + int64 (blocked layouts)
-    assert ctypes.sizeof(_lib.pm_embbag_batch) == 136
+    # ABI v7: + 2 x int32 (min_dim, reserved)
+    assert ctypes.sizeof(_lib.pm_embbag_batch) == 144
+    assert _lib.pm_embbag_batch.min_dim.offset == 136
     assert _lib.pm_embbag_batch.table_group.offset == 120 and _lib.pm_embbag_batch.grad_block_shift.offset == 124
     assert _lib.pm_embbag_batch.grad_block_extra.offset == 128
     assert _lib.pm_embbag_batch.fixed_pooling.offset == 112
@@ -86,14 +88,30 @@ def test_argument_validation_without_gpu():
     assert L.pm_embbag_bwd_fused(ctypes.byref(op), 8, 8, _lib.PM_F32, 1.0, 1000, None, 0, None) == _lib.PM_ERR_INVALID
     assert b"workspace" in L.pm_last_error()
     assert L.pm_embbag_bwd_fused_adagrad(ctypes.byref(op), 8, 8, _lib.PM_F32, 8, ctypes.byref(opt), 1000, None, 0, None) == _lib.PM_ERR_INVALID
+    #  ... including what only the APPLY half reads: a NULL gradient, a bad destination dtype, missing optimizer state --
+    # refused before the sort half could launch anything (a valid workspace pointer is never dereferenced on the host)
+    assert L.pm_embbag_bwd_fused(ctypes.byref(op), None, 8, _lib.PM_F32, 1.0, 1000, 8, 1 << 40, None) == _lib.PM_ERR_INVALID
+    assert b"grad" in L.pm_last_error()
+    assert L.pm_embbag_bwd_fused(ctypes.byref(op), 8, 8, 7, 1.0, 1000, 8, 1 << 40, None) == _lib.PM_ERR_INVALID
+    assert b"dtype" in L.pm_last_error()
+    good = _lib.pm_rowwise_adagrad(0.01, 1e-8, 0.0, _lib.PM_WD_NONE, 0, 0, 0)
+    assert L.pm_embbag_bwd_fused_adagrad(ctypes.byref(op), 8, 8, _lib.PM_F32, None, ctypes.byref(good), 1000, 8, 1 << 40, None) == _lib.PM_ERR_INVALID
+    assert b"momentum" in L.pm_last_error()
+    assert L.pm_embbag_bwd_fused_adagrad(ctypes.byref(op), 8, 8, _lib.PM_F32, 8, None, 1000, 8, 1 << 40, None) == _lib.PM_ERR_INVALID
+    #  a blocked gradient needs a block of at least two bags that tiles the batch
+    op.grad_block_extra = 64
+    assert L.pm_embbag_bwd_fused(ctypes.byref(op), 8, 8, _lib.PM_F32, 1.0, 1000, 8, 1 << 40, None) == _lib.PM_ERR_INVALID
+    assert b"grad_block_shift >= 1" in L.pm_last_error()
+    op.grad_block_shift = 3                                                         # blocks of 8 bags, batch 4
+    assert L.pm_embbag_bwd_fused(ctypes.byref(op), 8, 8, _lib.PM_F32, 1.0, 1000, 8, 1 << 40, None) == _lib.PM_ERR_INVALID
+    assert b"multiple of 2^grad_block_shift" in L.pm_last_error()
+    op.grad_block_shift, op.grad_block_extra = 0, 0
+    op.min_dim = 6                                                                   # ABI v7: min_dim is a width like max_dim
+    assert L.pm_embbag_fwd(ctypes.byref(op), 8, None) == _lib.PM_ERR_INVALID and b"min_dim" in L.pm_last_error()
+    op.min_dim = 0
     op.num_indices = 0                                                               # ... and an empty request succeeds without a device
     assert L.pm_embbag_bwd_fused(ctypes.byref(op), None, None, _lib.PM_F32, 1.0, 1000, None, 0, None) == _lib.PM_OK
     op.num_indices = 100
-    # ... and the persistent-forward knob takes only what the kernel was built for
-    assert L.pm_set_forward_persist(3, 0, 0, 0, 0) == _lib.PM_ERR_INVALID
-    assert L.pm_set_forward_persist(1, 1, 0, 0, 0) == _lib.PM_ERR_INVALID and L.pm_set_forward_persist(1, 9, 0, 0, 0) == _lib.PM_ERR_INVALID
-    assert L.pm_set_forward_persist(1, 0, 0, 5, 0) == _lib.PM_ERR_INVALID and b"pool_waves" in L.pm_last_error()
-    assert L.pm_set_forward_persist(2, 4, 2, 7, 3) == _lib.PM_OK and L.pm_set_forward_persist(-1, 0, 0, 0, 0) == _lib.PM_OK
 
 
 def test_graft_entry_build_runs():

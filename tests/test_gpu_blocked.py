@@ -23,7 +23,6 @@ def _need_gpu_and_lib():
     param_amd.load_library()
     yield
     param_amd.set_hybrid_tuning()
-    param_amd.set_forward_persist()
 
 
 def _models(rows, D, Bl, dtype=torch.float32, seed=3, **kw):
@@ -60,12 +59,6 @@ def test_blocked_forward_equals_tbd_forward_block_by_block(wdt, D, T, idt):
     flat = ob.view(-1)
     for w in range(W):
         assert torch.equal(flat[w * T * Bl * D:(w + 1) * T * Bl * D].view(T, Bl, D), ot[:, w * Bl:(w + 1) * Bl])
-    # the persistent forward takes the same (T * W)-table request
-    import param_amd
-
-    param_amd.set_forward_persist(2)
-    assert torch.equal(mb.lookup(idx, off, batch=B), _to_blocked(mt.lookup(idx, off, batch=B), Bl))
-    param_amd.set_forward_persist()
     with pytest.raises(ValueError):
         mb.lookup(idx, off, batch=B, bag_begin=Bl, bag_count=Bl)          # whole-batch requests only
 

@@ -415,10 +415,11 @@ def test_graph_launches_sweep_single_gpu():
     assert sum(small_g) < sum(small_e), (small_g, small_e)
 
 
-@pytest.mark.parametrize("n,extra,split", [(2, ["--tables", "16", "--rows", "1000000"], [8, 8]),
-                                           (4, ["--tables", "26", "--rows", "400000"], [7, 7, 6, 6]),
-                                           (2, ["--tables", "10", "--rows", "1000000", "--send-layout", "blocked"], [5, 5])])
-def test_bench_multi_rank_flow_on_one_gpu(n, extra, split, tmp_path):
+@pytest.mark.parametrize("n,extra,split,force", [(2, ["--tables", "16", "--rows", "1000000"], [8, 8], "224"),
+                                                 (4, ["--tables", "26", "--rows", "400000"], [7, 7, 6, 6], "256"),
+                                                 (2, ["--tables", "10", "--rows", "1000000", "--send-layout", "blocked"], [5, 5], ""),
+                                                 (2, ["--workload", "criteo", "--mixed-dims"], [13, 13], "")])
+def test_bench_multi_rank_flow_on_one_gpu(n, extra, split, force, tmp_path):
     """bench.py's N > 1 flow with REAL ranks: `torch.distributed.run` starts n processes, PARAM_AMD_BENCH_SHARED_GPU=1 puts all of
     them on GPU 0 and lets them talk over gloo (a flow check, and the line says so) -- table partition (the reference's
     `get_split_lengths_by_len`, dlrm.py:390-398: 26 tables on 4 ranks = [7, 7, 6, 6]), split lists, the exchange self-check (every rank
@@ -429,6 +430,8 @@ def test_bench_multi_rank_flow_on_one_gpu(n, extra, split, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["PARAM_AMD_BENCH_SHARED_GPU"] = "1"
+    if force:                       # round 6: the compute stream (224 CUs / all) is selected by a trial inside the run; take either branch
+        env["PARAM_AMD_BENCH_FORCE_CUS"] = force
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(_port()), os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "2",
            "--no-cpu-baseline", "--no-extra", "--batch", "2048"] + extra
@@ -442,3 +445,14 @@ def test_bench_multi_rank_flow_on_one_gpu(n, extra, split, tmp_path):
     sc = d["all_to_all"]["selfcheck"]
     assert sc["a2a_selfcheck"] == "ok" and sc["ranks"] == n and sc["min_peers_checked_over_ranks"] == n and sc["max_abs_diff"] == 0.0, sc
     assert d["fwd_bwd_step"]["lookups_per_s"] > 0
+    # round 6: the stream choice is made in the run and recorded, with both trial times; the line ends with the compact summary
+    sel = d["overlap"]["cu_mask_selection"]
+    assert isinstance(sel, dict) and sel["step_s_224_cus"] > 0 and sel["step_s_256_cus"] > 0, sel
+    assert d["overlap"]["cu_mask_selected"] == sel["selected"] and sel["selected"] in (224, 256)
+    assert d["overlap"]["lookup_cus"] == sel["selected"]
+    if force:
+        assert sel["selected"] == int(force) and sel["forced_by_env"] == force, sel
+    assert d["all_to_all"]["rccl"]["nranks"] == n
+    assert list(d)[-1] == "summary" and d["config"]["requests_rotated"] >= 4
+    if "--mixed-dims" in extra:
+        assert d["config"]["dim"] == {"16": 9, "32": 9, "64": 3, "128": 5}, d["config"]["dim"]

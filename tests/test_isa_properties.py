@@ -86,6 +86,17 @@ def test_flat_walk_forward_keeps_its_row_loads_in_flight(bundles):
     assert _row_loads_between_full_waits(text) >= 2
 
 
+@pytest.mark.parametrize("sym", ["22embbag_fwd_flat_kernelIfLi32ELi2ELb0E", "22embbag_fwd_flat_kernelIfLi8ELi2ELb0E",
+                                 "22embbag_fwd_flat_kernelINS_3fwd6bf16_tELi16ELi2ELb0E", "22embbag_fwd_flat_kernelIfLi32ELi2ELb1E"])
+def test_mixed_dim_forward_keeps_two_row_loads_in_flight_per_sub_group(bundles, sym):
+    """Round 6: mixed-dim requests run the flat-walk kernel with the lane group sized per table at run time (sub-groups of 4 .. G
+    lanes of the SAME instantiation: G = 32 is what a request whose widest fp32 table has D = 128 launches, G = 8 what an all-narrow
+    one does).  The sub-group width is a run-time value, the walk's load batch is not: UNROLL row loads are issued back to back
+    before the first wait, whatever the width -- in every instantiation a mixed request can reach."""
+    text = _kernel_text(bundles, f"{NS}{sym}")
+    assert _row_loads_between_full_waits(text) >= 2
+
+
 def test_apply_main_kernel_keeps_its_batch_in_flight(bundles):
     """4 positions x (gradient row + destination row) for fp32 tables, 2 x (2 x 16 B of gradient + row) for 16-bit ones"""
     text = _kernel_text(bundles, f"{NS}22bwd_sorted_main_kernelINS0_7SDstF32EjLi32ELb0ELi0ELi512E")
