@@ -355,8 +355,13 @@ int pm_set_tuning(int32_t unroll, int32_t bags_per_block, int32_t xcd_affine, in
  * tile's pooled rows in LDS and writes them in one burst when the tile is done (fixed-pooling requests whose tile of
  * rows fits 16 KB).  Results are bit-identical either way; it changes how the output write stream mixes with the row
  * reads (uniform indices: 0.69 -> 0.72-0.74 of the HBM peak).
+ * flat_grid (ABI v7; -1 = default, PARAM_AMD_FLAT_COMPACT in the environment changes it): launch shape of the flat-walk forward
+ * (short-bag and mixed-dim requests).  0 = one workgroup per (table, smallest tile): workgroups past their table's tile count
+ * leave (round 3's form); 1 = one set of workgroups sized by the library, each walking the table-major tile order b, b + grid, ...
+ * after establishing every table's tile count from the offsets (no workgroup is dispatched for a tile that does not exist);
+ * N > 1 = exactly N workgroups (sweeps).  Results are bit-identical in every setting.
  */
-int pm_set_forward_tuning(int32_t stage_out);
+int pm_set_forward_tuning(int32_t stage_out, int32_t flat_grid);
 
 /*
  * Tuning knobs of the sorted backward (process-wide; -1 = default, which the environment can change:

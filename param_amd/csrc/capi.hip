@@ -20,6 +20,7 @@ std::atomic<int> g_bags_per_block{0};
 std::atomic<int> g_xcd_affine{-1};
 std::atomic<int> g_nt_loads{-1};
 std::atomic<int> g_stage_out{-1};
+std::atomic<int> g_flat_grid{-1};   // pm_set_forward_tuning: launch shape of the flat-walk forward (-1: PARAM_AMD_FLAT_COMPACT, default 1)
 // destination-row cache policy of the sorted backward when pm_set_tuning leaves nt_loads at its default: plain loads,
 // agent-scope (sc1) stores.  The store writes through and drops the row's lines from the XCD's L2, so a row occupies L2 only
 // between its load and its store and the gradient rows -- re-read once per lookup of their bag -- keep the capacity
@@ -45,6 +46,7 @@ struct FwdEnv {
     int flat_target;  // PARAM_AMD_FLAT_TARGET (lookups per flat-walk tile)
     int flat_bags;    // PARAM_AMD_FLAT_BAGS (bags per flat-walk tile at most)
     int tile_major;   // PARAM_AMD_FWD_TILE_MAJOR=1
+    int flat_compact; // PARAM_AMD_FLAT_COMPACT=0: the flat-walk kernel's old grid (T x smallest-tile count); N > 1: exactly N workgroups
 };
 const FwdEnv& fwd_env() {
     static const FwdEnv e = [] {
@@ -57,6 +59,7 @@ const FwdEnv& fwd_env() {
         r.flat_target = num("PARAM_AMD_FLAT_TARGET", 256);
         r.flat_bags = num("PARAM_AMD_FLAT_BAGS", 32);
         r.tile_major = num("PARAM_AMD_FWD_TILE_MAJOR", -1);
+        r.flat_compact = num("PARAM_AMD_FLAT_COMPACT", 1);
         return r;
     }();
     return e;
@@ -184,6 +187,7 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
     p.stage_bags = 0;
     p.flat_bags = 0;
     p.flat_target = 0;
+    p.flat_compact = 0;
     if (forward) {
         const FwdEnv& env = fwd_env();
         int want = g_stage_out.load();
@@ -274,6 +278,24 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
                 }
             }
         }
+        // flat-walk launches are one resident set of workgroups walking the tile order (embbag_fwd.hip, round 6): 1 = the launcher asks
+        // the device how many that is
+        {
+            int fg = g_flat_grid.load();
+            if (fg < 0) fg = env.flat_compact;
+            if (p.flat_bags > 0 && op->num_tables <= 1024 && fg > 0) {
+                // the tiles the request will have, from its sizes (the tables' own pooling factors are on the device): ~flat_target
+                // lookups each, but at most flat_bags bags; a quarter more, because a table's tile is its average bag count rounded DOWN
+                // to whole lane-group rounds
+                const int64_t n_slice = op->batch > 0 ? (op->num_indices * op->bag_count + op->batch - 1) / op->batch : 0;
+                const int64_t by_lookups = (n_slice + p.flat_target - 1) / p.flat_target;
+                const int64_t by_bags = static_cast<int64_t>(op->num_tables) * ((op->bag_count + p.flat_bags - 1) / p.flat_bags);
+                int64_t est = (by_lookups > by_bags ? by_lookups : by_bags) * 5 / 4 + op->num_tables;
+                if (est < 1024) est = 1024;
+                if (est > (1 << 20)) est = 1 << 20;
+                p.flat_compact = fg > 1 ? fg : static_cast<int32_t>(est);
+            }
+        }
         // Two tilings built and measured in round 3 for requests whose tables have very different pooling factors (Criteo
         // multi-hot 1 .. 100) -- both slower than the 8-bag tiles in table-major order, which stay:
         //  * WORK tiles (~640 lookups per tile whatever the pooling factor, tile boundaries derived on the device from the
@@ -289,6 +311,22 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
         if (p.xcd_affine != 1 && op->num_tables > 1 && tm_env > 0 && uneven) p.xcd_affine = 2;
     }
     return PM_OK;
+}
+
+// Row loads in flight per lane group when pm_set_tuning leaves the choice to the library.  Two is the measured optimum of a launch
+// that fills the chip (eight workgroups per CU: occupancy provides the memory-level parallelism).  A SMALL request -- the reference
+// driver's batch 512 .. 4096 rows of one 14 M x 128 table, train/compute/pt/dataset.py:56-82 -- has one or two workgroups per CU,
+// each lane group a chain of pooling / 2 dependent round trips: there a deeper batch IS the parallelism.  Additions stay in index
+// order: same bits for every value.
+int small_request_unroll(const pm_embbag_batch* op, const pm::KParams& p) {
+    if (p.flat_bags > 0 || p.ordered) return kDefaultUnroll;
+    const int64_t wgs = static_cast<int64_t>(p.T) * p.tiles_per_table;
+    const int64_t bags = static_cast<int64_t>(op->num_tables) * op->batch;
+    const int64_t avg_l = bags > 0 ? op->num_indices / bags : 0;
+    // kernel us under rocprofv3 --kernel-trace (profiles/r06_small_batch_kernel_us.txt; batch 2 / 4 / 8): 64 workgroups 6.6 / 5.6 / 5.5,
+    // 128: 6.9 / 6.0 / 5.6, 256: 9.6 / 7.7 / 6.6, 512: 13.0 / 13.1 / 13.1, 1024: 22.4 / 22.6 / 23.1 -- it pays up to one workgroup per CU
+    if (wgs > 384) return kDefaultUnroll;
+    return avg_l >= 8 ? 8 : (avg_l >= 4 ? 4 : kDefaultUnroll);
 }
 
 }  // namespace
@@ -314,9 +352,11 @@ int pm_set_tuning(int32_t unroll, int32_t bags_per_block, int32_t xcd_affine, in
     return PM_OK;
 }
 
-int pm_set_forward_tuning(int32_t stage_out) {
+int pm_set_forward_tuning(int32_t stage_out, int32_t flat_grid) {
     if (stage_out < -1 || stage_out > 1) return fail(PM_ERR_INVALID, "stage_out must be -1, 0 or 1");
+    if (flat_grid < -1 || flat_grid > (1 << 20)) return fail(PM_ERR_INVALID, "flat_grid must be -1 (default), 0, 1 or a workgroup count up to 2^20");
     g_stage_out.store(stage_out);
+    g_flat_grid.store(flat_grid);
     return PM_OK;
 }
 
@@ -443,7 +483,7 @@ int pm_embbag_fwd(const pm_embbag_batch* op, float* out, pm_stream_t stream) {
     if (!out) return fail(PM_ERR_INVALID, "out is NULL");
     p.io = out;
     int unroll = g_unroll.load();
-    if (unroll == 0) unroll = kDefaultUnroll;
+    if (unroll == 0) unroll = small_request_unroll(op, p);
     const hipError_t h = pm::launch_embbag_fwd(p, op->weight_dtype, op->max_dim, unroll, static_cast<hipStream_t>(stream));
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_fwd launch");
     return PM_OK;

@@ -58,6 +58,9 @@ struct KParams {
     int32_t flat_bags;           // forward: > 0 = the flat-walk kernel (short-bag requests): bags per tile derived per table on the
                                  // device, at most this many (= bags_per_block, which sizes the LDS offsets array)
     int32_t flat_target;         // ... lookups per tile aimed at
+    int32_t flat_compact;        // ... > 0 (round 6): the launch is this many RESIDENT workgroups that each establish every table's tile
+                                 // count from the offsets (LDS prefix) and walk the table-major tile order b, b + grid, ...: no workgroup
+                                 // is dispatched for a tile that does not exist.  0: grid = T x tiles_per_table, surplus workgroups leave
     int32_t gblk_shift;          // backward kernels: blocked gradient layout (ABI v6, pm_embbag_batch::grad_block_shift): bag b of table t at
     int64_t gblk_extra;          //   io + out_offsets[t] + b * out_stride + (b >> gblk_shift) * gblk_extra ; no blocking: extra = 0
     float alpha;                 // bwd scale

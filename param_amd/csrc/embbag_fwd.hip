@@ -290,117 +290,193 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
 //     row is one 64-byte load by 4 lanes and a 32-lane slot pools eight bags at once.  The tile stays ~flat_target lookups
 //     whatever the width, so the index tile in LDS is what it was.  A bag is pooled by ONE sub-group, additions in index order
 //     from zero: the same bits whatever g.  Requests of one width compute g = G.
+//   * (round 6) NO EMPTY WORKGROUPS IN THE WAY (flat_compact): the grid used to be T x (the smallest tile's count), and a workgroup
+//     past its table's tile count left after one round trip.  The dispatcher is in order: the Criteo request launched 26 624
+//     workgroups for ~7 600 tiles, and a working workgroup queued behind hundreds of leavers that each held a slot for a round
+//     trip (mixed-dim Criteo: its five wide tables alone 123 us, its 21 narrow ones alone 24 us, together 161 us).  Now every
+//     workgroup reads every table's slice bounds (T + 1 offsets: one round trip, as before), keeps the tables' tile sizes and the
+//     prefix of their tile counts in LDS, and takes tiles blockIdx, blockIdx + grid, ... of the table-major tile order.  The grid
+//     is the host's estimate of the tile count (capi.hip): nearly one tile per workgroup, so the hardware dispatcher still
+//     balances the load -- a grid of exactly the resident workgroups, each walking ~5 tiles, fixes which workgroup gets the
+//     100-hot table's 3 x heavier tiles and lost 10 % to that imbalance (same process, grids taking turns: Criteo D = 128 uniform
+//     203 us old grid / 196 resident set / 174.5-179 at 4096-8192 workgroups; mixed dims 177 / 152-155 / 150: profiles/r06_flat_grid_ab.md).
+//     Which workgroup pools which tile changes no result.
+constexpr int kFlatMaxTables = 1024;   // tables a compact launch keeps in LDS (6 KB); larger requests keep the T x tiles grid
+
 template <typename WT, int G, int UNROLL, bool WEIGHTED>
 __global__ void __launch_bounds__(kBlock) embbag_fwd_flat_kernel(const KParams p) {
     constexpr int VEC = Elem<WT>::kVec;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int t, tile;
-    block_to_tile(p, t, tile);
-    if (t >= p.T) return;
-    const int D = p.dims[t];
-    int g = kBlock / p.flat_bags;                  // narrowest sub-group the tile geometry allows (host: make_params)
-    if (g < 1) g = 1;
-    while (g < G && g * VEC < D) g <<= 1;
-    const int NG = kBlock / g;                     // bags pooled concurrently by this workgroup
-    const int64_t g0 = static_cast<int64_t>(t) * p.B + p.bag_begin;
-    const int64_t lo = bag_start_or_end(p, g0), hi = bag_start_or_end(p, g0 + p.bag_count);
-    const int64_t avg = p.bag_count > 0 ? (hi - lo + p.bag_count - 1) / p.bag_count : 1;
-    int bags = static_cast<int>(p.flat_target / (avg > 0 ? avg : 1));
-    bags = bags > p.flat_bags ? p.flat_bags : bags;
-    bags = bags / NG * NG;
-    if (bags < NG) bags = NG;
-    const int64_t bag0 = p.bag_begin + static_cast<int64_t>(tile) * bags;
-    const int64_t left_bags = p.bag_begin + p.bag_count - bag0;
-    if (left_bags <= 0) return;
-    const int nb = left_bags < bags ? static_cast<int>(left_bags) : bags;
+    __shared__ int s_pref[kFlatMaxTables + 1];       // compact: tiles before table t (s_pref[T] = all tiles)
+    __shared__ uint16_t s_bags[kFlatMaxTables];      // compact: bags per tile of table t
 
-    int64_t* s_off;
-    int32_t* s_idx;
-    float* s_w;
-    const bool staged = stage_tile_at<WEIGHTED>(p, t, bag0, nb, smem, s_off, s_idx, s_w);
-    const int64_t base = s_off[0];
-    const int gid = threadIdx.x / g;
-    const int lig = threadIdx.x % g;
-    constexpr int ES = 16 / VEC;
-    const int64_t row_bytes = static_cast<int64_t>(D) * ES;
-    const char* W = reinterpret_cast<const char*>(p.tables[t]);
-    float* out_t = p.io + p.out_offsets[t];
-    const bool nt = p.nt_loads != 0;
-    float* s_out = reinterpret_cast<float*>(smem + tile_lds_bytes(p.bags_per_block, p.idx_cap, WEIGHTED));
-    // small tiles (long bags) leave in one burst, like the other kernel: the buffer holds stage_bags rows of stage_out floats -- a
-    // narrow table's tile has more, shorter rows
-    const bool stage = p.stage_out > 0 && static_cast<int64_t>(nb) * D <= static_cast<int64_t>(p.stage_bags) * p.stage_out;
-    const int per = (nb + NG - 1) / NG;
-    const int b_lo = gid * per;
-    const int b_hi = b_lo + per < nb ? b_lo + per : nb;
+    // lane group and tile of table t: g = the next power of two >= D_t / VEC lanes (at least kBlock / flat_bags, at most G);
+    // ~flat_target lookups per tile by the table's average bag, NG .. flat_bags bags, a multiple of NG
+    auto geometry = [&](int t, int& D, int& g, int& bags) {
+        D = p.dims[t];
+        g = kBlock / p.flat_bags;                    // narrowest sub-group the tile geometry allows (host: make_params)
+        if (g < 1) g = 1;
+        while (g < G && g * VEC < D) g <<= 1;
+        const int NG = kBlock / g;
+        const int64_t g0 = static_cast<int64_t>(t) * p.B + p.bag_begin;
+        const int64_t lo = bag_start_or_end(p, g0), hi = bag_start_or_end(p, g0 + p.bag_count);
+        const int64_t avg = p.bag_count > 0 ? (hi - lo + p.bag_count - 1) / p.bag_count : 1;
+        bags = static_cast<int>(p.flat_target / (avg > 0 ? avg : 1));
+        bags = bags > p.flat_bags ? p.flat_bags : bags;
+        bags = bags / NG * NG;
+        if (bags < NG) bags = NG;
+    };
 
-    auto walk = [&](auto staged_c) {
-        constexpr bool ST = decltype(staged_c)::value;
-        for (int c = lig * VEC; c < D; c += g * VEC) {
-            const char* Wc = W + static_cast<int64_t>(c) * ES;
-            float acc[VEC];
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
-            auto emit = [&](int bg) {                       // the finished sum of bag bg leaves, the accumulator starts over
-                if (stage) {
-                    f32x4* o4 = reinterpret_cast<f32x4*>(s_out + static_cast<size_t>(bg) * D + c);
-#pragma unroll
-                    for (int k = 0; k < VEC; k += 4) o4[k / 4] = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
-                } else {
-                    f32x4* o4 = reinterpret_cast<f32x4*>(out_t + (bag0 + bg) * p.out_stride + c);
-#pragma unroll
-                    for (int k = 0; k < VEC; k += 4) {
-                        f32x4 v = {acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
-                        __builtin_nontemporal_store(v, o4 + k / 4);
-                    }
-                }
+    auto do_tile = [&](int t, int tile, int D, int g, int bags) {
+        const int NG = kBlock / g;                   // bags pooled concurrently by this workgroup
+        const int64_t bag0 = p.bag_begin + static_cast<int64_t>(tile) * bags;
+        const int64_t left_bags = p.bag_begin + p.bag_count - bag0;
+        if (left_bags <= 0) return;
+        const int nb = left_bags < bags ? static_cast<int>(left_bags) : bags;
+
+        int64_t* s_off;
+        int32_t* s_idx;
+        float* s_w;
+        const bool staged = stage_tile_at<WEIGHTED>(p, t, bag0, nb, smem, s_off, s_idx, s_w);
+        const int64_t base = s_off[0];
+        const int gid = threadIdx.x / g;
+        const int lig = threadIdx.x % g;
+        constexpr int ES = 16 / VEC;
+        const int64_t row_bytes = static_cast<int64_t>(D) * ES;
+        const char* W = reinterpret_cast<const char*>(p.tables[t]);
+        float* out_t = p.io + p.out_offsets[t];
+        const bool nt = p.nt_loads != 0;
+        float* s_out = reinterpret_cast<float*>(smem + tile_lds_bytes(p.bags_per_block, p.idx_cap, WEIGHTED));
+        // small tiles (long bags) leave in one burst, like the other kernel: the buffer holds stage_bags rows of stage_out floats -- a
+        // narrow table's tile has more, shorter rows
+        const bool stage = p.stage_out > 0 && static_cast<int64_t>(nb) * D <= static_cast<int64_t>(p.stage_bags) * p.stage_out;
+        const int per = (nb + NG - 1) / NG;
+        const int b_lo = gid * per;
+        const int b_hi = b_lo + per < nb ? b_lo + per : nb;
+
+        auto walk = [&](auto staged_c) {
+            constexpr bool ST = decltype(staged_c)::value;
+            for (int c = lig * VEC; c < D; c += g * VEC) {
+                const char* Wc = W + static_cast<int64_t>(c) * ES;
+                float acc[VEC];
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
-            };
-            int cur = b_lo;
-            int64_t cur_end = s_off[cur + 1];
-            const int64_t e = s_off[b_hi];
-            for (int64_t j = s_off[b_lo]; j < e; j += UNROLL) {
-                u32x4 raw[UNROLL];
-                float w[UNROLL];
-                int64_t r[UNROLL];
+                auto emit = [&](int bg) {                       // the finished sum of bag bg leaves, the accumulator starts over
+                    if (stage) {
+                        f32x4* o4 = reinterpret_cast<f32x4*>(s_out + static_cast<size_t>(bg) * D + c);
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {           // straight-line: positions past the run read its last lookup again
-                    const int64_t jj = j + u < e ? j + u : e - 1;
-                    r[u] = ST ? static_cast<int64_t>(s_idx[jj - base]) : load_index(p.indices, jj, p.idx64);
-                    if (WEIGHTED) w[u] = ST ? s_w[jj - base] : as_global<float>(p.psw)[jj];
-                }
+                        for (int k = 0; k < VEC; k += 4) o4[k / 4] = f32x4{acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+                    } else {
+                        f32x4* o4 = reinterpret_cast<f32x4*>(out_t + (bag0 + bg) * p.out_stride + c);
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) raw[u] = load16(Wc + row_offset<ST>(r[u], row_bytes), nt);
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                    if (j + u < e) {
-                        while (j + u >= cur_end) {           // the walk passed the end of bag `cur` (and of any empty bags after it)
-                            emit(cur);
-                            ++cur;
-                            cur_end = s_off[cur + 1];
+                        for (int k = 0; k < VEC; k += 4) {
+                            f32x4 v = {acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+                            __builtin_nontemporal_store(v, o4 + k / 4);
                         }
-                        float f[VEC];
-                        Elem<WT>::widen(raw[u], f);
+                    }
 #pragma unroll
-                        for (int k = 0; k < VEC; ++k) acc[k] = WEIGHTED ? fmaf(w[u], f[k], acc[k]) : acc[k] + f[k];
+                    for (int k = 0; k < VEC; ++k) acc[k] = 0.0f;
+                };
+                int cur = b_lo;
+                int64_t cur_end = s_off[cur + 1];
+                const int64_t e = s_off[b_hi];
+                for (int64_t j = s_off[b_lo]; j < e; j += UNROLL) {
+                    u32x4 raw[UNROLL];
+                    float w[UNROLL];
+                    int64_t r[UNROLL];
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u) {           // straight-line: positions past the run read its last lookup again
+                        const int64_t jj = j + u < e ? j + u : e - 1;
+                        r[u] = ST ? static_cast<int64_t>(s_idx[jj - base]) : load_index(p.indices, jj, p.idx64);
+                        if (WEIGHTED) w[u] = ST ? s_w[jj - base] : as_global<float>(p.psw)[jj];
+                    }
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u) raw[u] = load16(Wc + row_offset<ST>(r[u], row_bytes), nt);
+#pragma unroll
+                    for (int u = 0; u < UNROLL; ++u) {
+                        if (j + u < e) {
+                            while (j + u >= cur_end) {           // the walk passed the end of bag `cur` (and of any empty bags after it)
+                                emit(cur);
+                                ++cur;
+                                cur_end = s_off[cur + 1];
+                            }
+                            float f[VEC];
+                            Elem<WT>::widen(raw[u], f);
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) acc[k] = WEIGHTED ? fmaf(w[u], f[k], acc[k]) : acc[k] + f[k];
+                        }
                     }
                 }
+                for (; cur < b_hi; ++cur) emit(cur);            // the last bag walked, then the empty ones behind it (zeros)
             }
-            for (; cur < b_hi; ++cur) emit(cur);            // the last bag walked, then the empty ones behind it (zeros)
+        };
+        if (b_lo < b_hi) {
+            if (staged) walk(std::true_type{}); else walk(std::false_type{});
+        }
+        if (stage) {
+            __syncthreads();
+            const int q = D / 4;
+            for (int i = threadIdx.x; i < nb * q; i += kBlock) {
+                const int bg = i / q, c4 = i % q;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(s_out + static_cast<size_t>(bg) * D + c4 * 4);
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out_t + (bag0 + bg) * p.out_stride + c4 * 4));
+            }
         }
     };
-    if (b_lo < b_hi) {
-        if (staged) walk(std::true_type{}); else walk(std::false_type{});
-    }
-    if (stage) {
-        __syncthreads();
-        const int q = D / 4;
-        for (int i = threadIdx.x; i < nb * q; i += kBlock) {
-            const int bg = i / q, c4 = i % q;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(s_out + static_cast<size_t>(bg) * D + c4 * 4);
-            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out_t + (bag0 + bg) * p.out_stride + c4 * 4));
+
+    const bool compact = p.flat_compact > 0;
+    if (compact) {
+        // every table's tile size and count (one thread per table), then the prefix of the counts (one wave)
+        for (int t = threadIdx.x; t < p.T; t += kBlock) {
+            int D, g, bags;
+            geometry(t, D, g, bags);
+            s_bags[t] = static_cast<uint16_t>(bags);
+            s_pref[t + 1] = static_cast<int>((p.bag_count + bags - 1) / bags);
         }
+        __syncthreads();
+        if (threadIdx.x < kWave) {
+            int running = 0;
+            for (int b0 = 0; b0 < p.T; b0 += kWave) {
+                const int i = b0 + static_cast<int>(threadIdx.x);
+                int v = i < p.T ? s_pref[i + 1] : 0;
+#pragma unroll
+                for (int d = 1; d < kWave; d <<= 1) {
+                    const int o = __shfl_up(v, d, kWave);
+                    if (static_cast<int>(threadIdx.x) >= d) v += o;
+                }
+                if (i < p.T) s_pref[i + 1] = running + v;
+                running += __shfl(v, kWave - 1, kWave);
+            }
+            if (threadIdx.x == 0) s_pref[0] = 0;
+        }
+        __syncthreads();
+    }
+    // compact: tiles blockIdx, + grid, ... of the table-major order; otherwise ONE trip -- one workgroup per (table, tile of the
+    // smallest size), surplus workgroups leave
+    const int total = compact ? s_pref[p.T] : static_cast<int>(blockIdx.x) + 1;
+    const int step = compact ? static_cast<int>(gridDim.x) : 1;
+    for (int v = blockIdx.x; v < total; v += step) {
+        int t, tile, D, g, bags;
+        if (compact) {
+            int lo = 0, hi = p.T;                    // the table whose tiles [s_pref[t], s_pref[t + 1]) hold v (uniform: LDS broadcasts)
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_pref[mid] <= v) lo = mid; else hi = mid;
+            }
+            t = lo;
+            tile = v - s_pref[t];
+            D = p.dims[t];
+            g = kBlock / p.flat_bags;
+            if (g < 1) g = 1;
+            while (g < G && g * VEC < D) g <<= 1;
+            bags = s_bags[t];
+        } else {
+            block_to_tile(p, t, tile);
+            if (t >= p.T) return;
+            geometry(t, D, g, bags);
+        }
+        do_tile(t, tile, D, g, bags);
+        if (compact) __syncthreads();                // the next tile restages the LDS arrays this one's walk and burst read
     }
 }
 
@@ -411,6 +487,16 @@ hipError_t launch_w(const KParams& p, hipStream_t stream) {
     size_t lds = tile_lds_bytes(p.bags_per_block, p.idx_cap, weighted);
     if (p.flat_bags > 0) {   // short-bag requests with per-table pooling (capi.hip decides)
         lds += static_cast<size_t>(p.stage_bags) * p.stage_out * sizeof(float);
+        if (p.flat_compact > 0) {
+            // p.flat_compact = the workgroup count capi.hip chose: about as many as the request has tiles (an estimate from its sizes: the
+            // tiles' true count is on the device), so nearly every workgroup pools ONE tile and the dispatcher balances the load; where
+            // the estimate falls short workgroups walk on (b + grid, ...), where it overshoots the surplus leaves after the prologue --
+            // at the END of the dispatch order, behind no one
+            const int g2 = p.flat_compact < grid ? p.flat_compact : grid;
+            if (weighted) hipLaunchKernelGGL((embbag_fwd_flat_kernel<WT, G, UNROLL, true>), dim3(g2), dim3(kBlock), lds, stream, p);
+            else hipLaunchKernelGGL((embbag_fwd_flat_kernel<WT, G, UNROLL, false>), dim3(g2), dim3(kBlock), lds, stream, p);
+            return hipGetLastError();
+        }
         if (weighted) hipLaunchKernelGGL((embbag_fwd_flat_kernel<WT, G, UNROLL, true>), dim3(grid), dim3(kBlock), lds, stream, p);
         else hipLaunchKernelGGL((embbag_fwd_flat_kernel<WT, G, UNROLL, false>), dim3(grid), dim3(kBlock), lds, stream, p);
         return hipGetLastError();

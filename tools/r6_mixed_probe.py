@@ -46,13 +46,15 @@ def timed(fn, n):
 
 
 for subset in a.subsets.split(","):
-    if subset == "all":
+    if subset in ("all", "all128"):
         sel = list(range(26))
     elif subset == "narrow":
         sel = [t for t in range(26) if dims_all[t] < 128]
     else:
         sel = [t for t in range(26) if dims_all[t] == int(subset)]
     rows, pools, dims = [rows_all[t] for t in sel], [pools_all[t] for t in sel], [dims_all[t] for t in sel]
+    if subset == "all128":
+        dims = [128] * 26
     m = param_amd.BatchedEmbeddingBagMI355(rows, dims, dtype=torch.float32, device=dev, init="normal", layout="bd", seed=1, fused_update=False)
     out = torch.empty(B, sum(dims), device=dev)
     grad = torch.randn(B, sum(dims), device=dev)
@@ -75,7 +77,7 @@ for subset in a.subsets.split(","):
             s = timed(f, a.iters)
             rec = {"exp": "mixed_fwd", "subset": subset, "tables": len(sel), "hint": hint, "indices": name, "lookups": n,
                    "us": round(s * 1e6, 2), "alg_frac": round(fwd_bytes / s / 8e12, 4), "alg_MB": round(fwd_bytes / 1e6, 1),
-                   "flat_target": os.environ.get("PARAM_AMD_FLAT_TARGET"), "flat_bags": os.environ.get("PARAM_AMD_FLAT_BAGS")}
+                   "flat_target": os.environ.get("PARAM_AMD_FLAT_TARGET"), "flat_bags": os.environ.get("PARAM_AMD_FLAT_BAGS"), "compact": os.environ.get("PARAM_AMD_FLAT_COMPACT")}
             print(json.dumps(rec), flush=True)
         if a.backward:
             i, o = reqs[0]
