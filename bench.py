@@ -96,7 +96,7 @@ def parse():
     p.add_argument("--no-uniform", action="store_true", help="skip the uniform-index (roofline-defining) measurement")
     p.add_argument("--no-bwd", action="store_true", help="skip the backward / fwd+bwd measurements")
     p.add_argument("--bwd", action="store_true", help="(default now; kept for old command lines)")
-    p.add_argument("--atomic", action="store_true", help="also time the atomic backward kernel (slow: ~15 ms per step)")
+    p.add_argument("--atomic", action="store_true", help="also time the atomic backward kernel (slow: ~15 ms per step; needs the alternates build, make -C param_amd/csrc alt)")
     p.add_argument("--lookup-cus", type=int, default=-1,
                    help="N>1: run lookup / backward on a HIP stream masked to this many CUs (0 = all 256), leaving the rest to RCCL's "
                         "kernels.  Default (-1): SELECTED IN THE RUN -- a few warm-up steps are timed on a 224-CU stream and on an "

@@ -142,7 +142,8 @@ int pm_embbag_fwd(const pm_embbag_batch* op, float* out, pm_stream_t stream);
 int pm_embbag_fwd_split(const pm_embbag_batch* op, float* out, pm_stream_t stream);
 
 /*
- * Backward scatter-add:
+ * ALTERNATES BUILD ONLY (libparam_amd_alt.so, `make alt`, -DPM_ALTERNATES: tests and tools; not in the product library -- the
+ * deterministic backward below is the path, and 25 x faster).  Backward scatter-add with hardware atomics:
  *     dst_t[indices[j], :] += alpha * psw[j] * grad(t, bag(j))[:]
  * `grad` is addressed like `out` above.  dst_tables is a device array [T] of
  * destination base pointers with element type dst_dtype and the tables' shapes:
@@ -154,8 +155,10 @@ int pm_embbag_fwd_split(const pm_embbag_batch* op, float* out, pm_stream_t strea
  * Accumulation uses hardware float atomics (order not fixed; duplicates allowed).
  * dst_dtype: PM_F32, or PM_BF16 / PM_F16 (packed 16-bit atomics, one rounding per add).
  */
+#ifdef PM_ALTERNATES
 int pm_embbag_bwd(const pm_embbag_batch* op, const float* grad, void* const* dst_tables,
                   int32_t dst_dtype, float alpha, pm_stream_t stream);
+#endif
 
 /*
  * Deterministic backward without atomics (the default path of the Python modules):
@@ -369,8 +372,11 @@ int pm_set_forward_tuning(int32_t stage_out, int32_t flat_grid);
  *   sort_impl   0 (default): the segmented sort of round 3 -- per-table segments, per-table pooling factors and (for batch
  *               slices) the pair count are established ON THE DEVICE from the offsets, so ragged / multi-hot / sliced /
  *               weighted requests take the same fast path as fixed-pooling ones and the fixed_pooling field of the request is
- *               not needed (nor trusted); 1: rocPRIM's radix_sort_pairs; 2: round 2's own LSD sort with host-side plans
- *               (pm_radix_sort_pairs; uses fixed_pooling) -- 1 and 2 are kept as measured alternatives and cross-checks.
+ *               not needed (nor trusted).  The product library has this sort and no other: requests of more than 1024
+ *               tables are refused (PM_ERR_UNSUPPORTED: split the request), and sort_impl 1 / 2 are PM_ERR_UNSUPPORTED.
+ *               ALTERNATES BUILD ONLY (libparam_amd_alt.so, `make alt`): 1: rocPRIM's radix_sort_pairs; 2: round 2's own LSD
+ *               sort with host-side plans (pm_radix_sort_pairs; uses fixed_pooling; also serves more than 1024 tables) --
+ *               measured alternatives and independent cross-checks for tests/ and tools/.
  *               order / max_phases below apply to 1 and 2 only; xcd_affine to all (sort_impl 0: XCD-contiguous tiles)
  *   order       1 (default): pairs ordered by (table, [bag phase,] row, position); 0: (row, table, position) -- only
  *               the row bits are sorted, the request being table-major already (one radix pass fewer, a slower apply)
@@ -473,8 +479,9 @@ int pm_rows_quantize(const float* src, int64_t n_rows, int32_t dim, int32_t bitw
 int pm_rows_dequantize(const void* src, int64_t n_rows, int32_t dim, int32_t bitwidth, float* dst, pm_stream_t stream);
 
 /*
+ * ALTERNATES BUILD ONLY (round 2's sort: the product library sorts per-table segments with csrc/seg_sort.hip).
  * Stable LSD radix sort of (key, uint32 value) pairs by key bits [begin_bit, end_bit) -- the sort the sorted
- * backward runs on its (table,row) keys (replaces the sort inside aten::_embedding_bag_dense_backward /
+ * backward ran on its (table,row) keys in round 2 (replaces the sort inside aten::_embedding_bag_dense_backward /
  * fbgemm's TBE backward at the call sites of pm_embbag_bwd_sorted).  key_bytes: 4 or 8.  The pairs start in
  * (keys_a, vals_a); 8-bit passes alternate between the a and b buffers and *result_in_b says where the sorted
  * pairs ended up.  n_max <= 2^32 - 1 elements; if d_count is not NULL the number of elements is read from that
@@ -482,11 +489,13 @@ int pm_rows_dequantize(const void* src, int64_t n_rows, int32_t dim, int32_t bit
  * round trip.  segment_len > 0 (a multiple of 4096 dividing n_max, d_count NULL): the array is a sequence of segments of
  * that many pairs, each sorted on its own.  scratch: pm_radix_sort_scratch_bytes(n_max) bytes of device memory.
  */
+#ifdef PM_ALTERNATES
 int64_t pm_radix_sort_scratch_bytes(int64_t n_max);
 int pm_radix_sort_pairs(void* keys_a, void* keys_b, uint32_t* vals_a, uint32_t* vals_b, int64_t n_max,
                         const uint32_t* d_count, int32_t key_bytes, int32_t begin_bit, int32_t end_bit,
                         int64_t segment_len, void* scratch, int64_t scratch_bytes, int32_t* result_in_b,
                         pm_stream_t stream);
+#endif
 
 
 #ifdef __cplusplus

@@ -18,6 +18,9 @@ PM_WD_NONE, PM_WD_L2, PM_WD_DECOUPLE = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PARAM_AMD_LIB") or os.path.join(_HERE, "libparam_amd.so")   # PARAM_AMD_LIB: kernel experiments only
+# the ALTERNATES build (make -C param_amd/csrc alt, -DPM_ALTERNATES): the product library's sources plus the measured alternatives and
+# cross-checks -- atomic backward, round 2's LSD sort, rocPRIM's radix sort.  tests/ and tools/ only (use_alternates() below).
+ALT_LIB_PATH = os.path.join(_HERE, "libparam_amd_alt.so")
 
 # every symbol include/param_amd.h declares (tests/test_capi_symbols.py parses the header
 # and checks this list and the loaded library against it)
@@ -27,7 +30,6 @@ EXPORTED_SYMBOLS = (
     "pm_last_error",
     "pm_embbag_fwd",
     "pm_embbag_fwd_split",
-    "pm_embbag_bwd",
     "pm_embbag_bwd_sorted_workspace",
     "pm_embbag_sort_indices",
     "pm_embbag_sort_indices_ex",
@@ -50,8 +52,6 @@ EXPORTED_SYMBOLS = (
     "pm_set_forward_tuning",
     "pm_set_backward_tuning",
     "pm_set_sort_tuning",
-    "pm_radix_sort_scratch_bytes",
-    "pm_radix_sort_pairs",
     "pm_embbag_sort_status",
     "pm_set_hybrid_tuning",
     "pm_set_hybrid_rest",
@@ -120,102 +120,146 @@ class ParamAmdError(RuntimeError):
         self.code = code
 
 
+# ... and what the header declares under #ifdef PM_ALTERNATES (libparam_amd_alt.so exports these as well)
+ALTERNATE_SYMBOLS = (
+    "pm_embbag_bwd",
+    "pm_radix_sort_scratch_bytes",
+    "pm_radix_sort_pairs",
+)
+
 _lock = threading.Lock()
-_lib = None
+_lib = None          # the library load() hands out: the product library, or the alternates build inside use_alternates()
+_product = None
+_alt = None
 
 
-def load() -> ctypes.CDLL:
-    """Load libparam_amd.so once; raise ImportError (loudly) if it is not built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    with _lock:
-        if _lib is not None:
-            return _lib
-        if not os.path.exists(LIB_PATH):
-            raise ImportError(
-                f"{LIB_PATH} is not built. There is no CPU/eager fallback for the MI355X "
-                "embedding path: run `make -C param_amd/csrc` (hipcc --offload-arch=gfx950) first.")
-        L = ctypes.CDLL(LIB_PATH)
-        missing = [s for s in EXPORTED_SYMBOLS if not hasattr(L, s)]
-        if missing:
-            raise ImportError(f"{LIB_PATH} lacks symbols {missing}; rebuild it")
-        vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
-        L.pm_abi_version.restype = ctypes.c_int
-        L.pm_abi_version.argtypes = []
-        L.pm_build_info.restype = ctypes.c_char_p
-        L.pm_build_info.argtypes = []
-        L.pm_last_error.restype = ctypes.c_char_p
-        L.pm_last_error.argtypes = []
-        L.pm_embbag_fwd.restype = ctypes.c_int
-        L.pm_embbag_fwd.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp]
-        L.pm_embbag_fwd_split.restype = ctypes.c_int
-        L.pm_embbag_fwd_split.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp]
+def _open(path: str, alternates: bool) -> ctypes.CDLL:
+    """dlopen one build of the library, check its exports against the header's list and give every entry point its signature"""
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is not built. There is no CPU/eager fallback for the MI355X embedding path: run "
+            f"`make -C param_amd/csrc{' alt' if alternates else ''}` (hipcc --offload-arch=gfx950) first.")
+    L = ctypes.CDLL(path)
+    want = EXPORTED_SYMBOLS + (ALTERNATE_SYMBOLS if alternates else ())
+    missing = [s for s in want if not hasattr(L, s)]
+    if missing:
+        raise ImportError(f"{path} lacks symbols {missing}; rebuild it")
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    L.pm_abi_version.restype = ctypes.c_int
+    L.pm_abi_version.argtypes = []
+    L.pm_build_info.restype = ctypes.c_char_p
+    L.pm_build_info.argtypes = []
+    L.pm_last_error.restype = ctypes.c_char_p
+    L.pm_last_error.argtypes = []
+    L.pm_embbag_fwd.restype = ctypes.c_int
+    L.pm_embbag_fwd.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp]
+    L.pm_embbag_fwd_split.restype = ctypes.c_int
+    L.pm_embbag_fwd_split.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp]
+    L.pm_embbag_bwd_sorted_workspace.restype = ctypes.c_int64
+    L.pm_embbag_bwd_sorted_workspace.argtypes = [ctypes.POINTER(pm_embbag_batch), i64]
+    L.pm_embbag_sort_indices.restype = ctypes.c_int
+    L.pm_embbag_sort_indices.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, vp, i64, vp]
+    L.pm_embbag_sort_indices_ex.restype = ctypes.c_int
+    L.pm_embbag_sort_indices_ex.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, i32, vp, i64, vp]
+    L.pm_embbag_fwd_quantized.restype = ctypes.c_int
+    L.pm_embbag_fwd_quantized.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, i32, vp]
+    L.pm_embbag_check_ex.restype = ctypes.c_int
+    L.pm_embbag_check_ex.argtypes = [ctypes.POINTER(pm_embbag_batch), i32, vp, vp]
+    L.pm_rows_quantized_bytes.restype = i64
+    L.pm_rows_quantized_bytes.argtypes = [i64, i32, i32]
+    L.pm_rows_quantize.restype = ctypes.c_int
+    L.pm_rows_quantize.argtypes = [vp, i64, i32, i32, vp, vp]
+    L.pm_rows_dequantize.restype = ctypes.c_int
+    L.pm_rows_dequantize.argtypes = [vp, i64, i32, i32, vp, vp]
+    L.pm_embbag_sort_plan.restype = ctypes.c_int
+    L.pm_embbag_sort_plan.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, i32, ctypes.c_char_p, i32]
+    L.pm_embbag_bwd_sorted.restype = ctypes.c_int
+    L.pm_embbag_bwd_sorted.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, ctypes.c_float, i64, vp,
+                                       i64, vp]
+    L.pm_embbag_bwd_sorted_adagrad.restype = ctypes.c_int
+    L.pm_embbag_bwd_sorted_adagrad.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, vp, ctypes.c_float,
+                                               ctypes.c_float, i64, vp, i64, vp]
+    L.pm_embbag_bwd_sorted_adagrad_ex.restype = ctypes.c_int
+    L.pm_embbag_bwd_sorted_adagrad_ex.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, vp,
+                                                  ctypes.POINTER(pm_rowwise_adagrad), i64, vp, i64, vp]
+    L.pm_embbag_bwd_fused.restype = ctypes.c_int
+    L.pm_embbag_bwd_fused.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, ctypes.c_float, i64, vp, i64, vp]
+    L.pm_embbag_bwd_fused_adagrad.restype = ctypes.c_int
+    L.pm_embbag_bwd_fused_adagrad.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, vp,
+                                              ctypes.POINTER(pm_rowwise_adagrad), i64, vp, i64, vp]
+    L.pm_dlrm_regroup.restype = ctypes.c_int
+    L.pm_dlrm_regroup.argtypes = [vp, vp, i32, i32, i64, vp, vp, vp, vp]
+    L.pm_embbag_check.restype = ctypes.c_int
+    L.pm_embbag_check.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp]
+    L.pm_fill_random.restype = ctypes.c_int
+    L.pm_fill_random.argtypes = [vp, i64, i32, i32, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, vp]
+    L.pm_set_tuning.restype = ctypes.c_int
+    L.pm_set_tuning.argtypes = [i32, i32, i32, i32]
+    L.pm_set_forward_tuning.restype = ctypes.c_int
+    L.pm_set_forward_tuning.argtypes = [i32, i32]
+    L.pm_set_backward_tuning.restype = ctypes.c_int
+    L.pm_set_backward_tuning.argtypes = [i32, i32, i32, i32]
+    L.pm_embbag_sorted_pairs.restype = ctypes.c_int
+    L.pm_embbag_sorted_pairs.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, vp, ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                         ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.pm_set_sort_tuning.restype = ctypes.c_int
+    L.pm_set_sort_tuning.argtypes = [i32]
+    L.pm_embbag_sort_status.restype = ctypes.c_int
+    L.pm_embbag_sort_status.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, vp, ctypes.POINTER(pm_sort_status), vp]
+    L.pm_set_hybrid_tuning.restype = ctypes.c_int
+    L.pm_set_hybrid_tuning.argtypes = [i32, i64]
+    L.pm_set_hybrid_rest.restype = ctypes.c_int
+    L.pm_set_hybrid_rest.argtypes = [i32]
+    if alternates:
         L.pm_embbag_bwd.restype = ctypes.c_int
         L.pm_embbag_bwd.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, ctypes.c_float, vp]
-        L.pm_embbag_bwd_sorted_workspace.restype = ctypes.c_int64
-        L.pm_embbag_bwd_sorted_workspace.argtypes = [ctypes.POINTER(pm_embbag_batch), i64]
-        L.pm_embbag_sort_indices.restype = ctypes.c_int
-        L.pm_embbag_sort_indices.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, vp, i64, vp]
-        L.pm_embbag_sort_indices_ex.restype = ctypes.c_int
-        L.pm_embbag_sort_indices_ex.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, i32, vp, i64, vp]
-        L.pm_embbag_fwd_quantized.restype = ctypes.c_int
-        L.pm_embbag_fwd_quantized.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, i32, vp]
-        L.pm_embbag_check_ex.restype = ctypes.c_int
-        L.pm_embbag_check_ex.argtypes = [ctypes.POINTER(pm_embbag_batch), i32, vp, vp]
-        L.pm_rows_quantized_bytes.restype = i64
-        L.pm_rows_quantized_bytes.argtypes = [i64, i32, i32]
-        L.pm_rows_quantize.restype = ctypes.c_int
-        L.pm_rows_quantize.argtypes = [vp, i64, i32, i32, vp, vp]
-        L.pm_rows_dequantize.restype = ctypes.c_int
-        L.pm_rows_dequantize.argtypes = [vp, i64, i32, i32, vp, vp]
-        L.pm_embbag_sort_plan.restype = ctypes.c_int
-        L.pm_embbag_sort_plan.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, i32, ctypes.c_char_p, i32]
-        L.pm_embbag_bwd_sorted.restype = ctypes.c_int
-        L.pm_embbag_bwd_sorted.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, ctypes.c_float, i64, vp,
-                                           i64, vp]
-        L.pm_embbag_bwd_sorted_adagrad.restype = ctypes.c_int
-        L.pm_embbag_bwd_sorted_adagrad.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, vp, ctypes.c_float,
-                                                   ctypes.c_float, i64, vp, i64, vp]
-        L.pm_embbag_bwd_sorted_adagrad_ex.restype = ctypes.c_int
-        L.pm_embbag_bwd_sorted_adagrad_ex.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, vp,
-                                                      ctypes.POINTER(pm_rowwise_adagrad), i64, vp, i64, vp]
-        L.pm_embbag_bwd_fused.restype = ctypes.c_int
-        L.pm_embbag_bwd_fused.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, ctypes.c_float, i64, vp, i64, vp]
-        L.pm_embbag_bwd_fused_adagrad.restype = ctypes.c_int
-        L.pm_embbag_bwd_fused_adagrad.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, vp,
-                                                  ctypes.POINTER(pm_rowwise_adagrad), i64, vp, i64, vp]
-        L.pm_dlrm_regroup.restype = ctypes.c_int
-        L.pm_dlrm_regroup.argtypes = [vp, vp, i32, i32, i64, vp, vp, vp, vp]
-        L.pm_embbag_check.restype = ctypes.c_int
-        L.pm_embbag_check.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp]
-        L.pm_fill_random.restype = ctypes.c_int
-        L.pm_fill_random.argtypes = [vp, i64, i32, i32, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, vp]
-        L.pm_set_tuning.restype = ctypes.c_int
-        L.pm_set_tuning.argtypes = [i32, i32, i32, i32]
-        L.pm_set_forward_tuning.restype = ctypes.c_int
-        L.pm_set_forward_tuning.argtypes = [i32, i32]
-        L.pm_set_backward_tuning.restype = ctypes.c_int
-        L.pm_set_backward_tuning.argtypes = [i32, i32, i32, i32]
-        L.pm_embbag_sorted_pairs.restype = ctypes.c_int
-        L.pm_embbag_sorted_pairs.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, vp, ctypes.POINTER(vp), ctypes.POINTER(vp),
-                                             ctypes.POINTER(vp), ctypes.POINTER(i32), ctypes.POINTER(i32)]
-        L.pm_set_sort_tuning.restype = ctypes.c_int
-        L.pm_set_sort_tuning.argtypes = [i32]
         L.pm_radix_sort_scratch_bytes.restype = ctypes.c_int64
         L.pm_radix_sort_scratch_bytes.argtypes = [i64]
         L.pm_radix_sort_pairs.restype = ctypes.c_int
         L.pm_radix_sort_pairs.argtypes = [vp, vp, vp, vp, i64, vp, i32, i32, i32, i64, vp, i64, ctypes.POINTER(ctypes.c_int32), vp]
-        L.pm_embbag_sort_status.restype = ctypes.c_int
-        L.pm_embbag_sort_status.argtypes = [ctypes.POINTER(pm_embbag_batch), i64, vp, ctypes.POINTER(pm_sort_status), vp]
-        L.pm_set_hybrid_tuning.restype = ctypes.c_int
-        L.pm_set_hybrid_tuning.argtypes = [i32, i64]
-        L.pm_set_hybrid_rest.restype = ctypes.c_int
-        L.pm_set_hybrid_rest.argtypes = [i32]
-        if L.pm_abi_version() != PM_ABI_VERSION:
-            raise ImportError(f"{LIB_PATH}: ABI version {L.pm_abi_version()} != {PM_ABI_VERSION}")
-        _lib = L
+    if L.pm_abi_version() != PM_ABI_VERSION:
+        raise ImportError(f"{path}: ABI version {L.pm_abi_version()} != {PM_ABI_VERSION}")
+    return L
+
+
+def load() -> ctypes.CDLL:
+    """The library the package calls: libparam_amd.so, loaded once; raises ImportError (loudly) if it is not built."""
+    global _lib, _product
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if _product is None:
+                _product = _open(LIB_PATH, alternates=False)
+            _lib = _product
     return _lib
+
+
+def load_alternates() -> ctypes.CDLL:
+    """libparam_amd_alt.so (tests / tools): every product entry point plus ALTERNATE_SYMBOLS.  Its knobs and its records of sorted
+    workspaces are its own: a sort issued through one library is applied through the same one."""
+    global _alt
+    with _lock:
+        if _alt is None:
+            _alt = _open(ALT_LIB_PATH, alternates=True)
+    return _alt
+
+
+class use_alternates:
+    """``with _lib.use_alternates():`` -- every call of the package goes to the alternates build inside the block (tests that cross-check
+    the product path against round 2's sort / rocPRIM / the atomic kernel; tools that time them).  Not re-entrant across threads."""
+
+    def __enter__(self):
+        global _lib
+        load()
+        self._prev = _lib
+        _lib = load_alternates()
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._prev
+        return False
 
 
 def check(rc: int) -> None:

@@ -103,21 +103,26 @@ class MI355XBackend(backendFunctions):
             timer.incrTimeNS(float(time.monotonic_ns() - t0))
         return out
 
-    @staticmethod
-    def _host_quant_ops(bits):
-        q = torch.ops.quantized
-        return {8: (q.embedding_bag_byte_prepack, q.embedding_bag_byte_unpack),
-                4: (q.embedding_bag_4bit_prepack, q.embedding_bag_4bit_unpack),
-                2: (q.embedding_bag_2bit_prepack, q.embedding_bag_2bit_unpack)}[bits]
+    # Row codec for HOST tensors: ``bits -> (prepack(rows_f32[n, dim]) -> uint8[n, row_bytes], unpack(uint8[n, row_bytes]) -> f32[n, dim])``.
+    # None in the product: the quantised collectives run on the HIP row quantisers (param_amd.quant) and a host tensor raises.  The
+    # gloo tests, which drive this plug-in without a GPU (``--device cpu``), inject torch's CPU operators for the same formats here
+    # (tests/dist_workers.py) -- the operators oracle/rowquant.py is pinned to; they are a checker, not a fallback the backend ships.
+    host_row_codec = None
+
+    def _host_codec(self, bits):
+        if self.host_row_codec is None:
+            raise RuntimeError("param_amd: quantised collectives run on ROCm tensors only (HIP row quantisers, no CPU fallback); "
+                               "a host-tensor run needs MI355XBackend.host_row_codec to be injected (tests/dist_workers.py)")
+        return self.host_row_codec(bits)
 
     def _quantize_rows(self, t, dim, bits, out=None):
         """fp32 -> quantised rows, flat uint8.  GPU tensors: the HIP kernels (no fallback).  Host tensors (``--device cpu``,
-        the gloo mode the plug-in is tested in without GPUs): torch's own CPU operators for the same formats."""
+        the gloo mode the plug-in is tested in without GPUs): the injected ``host_row_codec``, else an error."""
         if t.is_cuda:
             from ... import quant
             return quant.quantize_rows(t, dim, bits, out=out).view(-1)
         q = (t.reshape(-1).to(torch.float16).view(torch.uint8) if bits == 16
-             else self._host_quant_ops(bits)[0](t.reshape(-1, dim)).reshape(-1))
+             else self._host_codec(bits)[0](t.reshape(-1, dim)).reshape(-1))
         if out is not None:
             out.view(-1).copy_(q)
             return out.view(-1)
@@ -130,7 +135,7 @@ class MI355XBackend(backendFunctions):
             return out
         from ...quant import host_row_bytes
         d = (q.view(torch.float16).to(torch.float32) if bits == 16
-             else self._host_quant_ops(bits)[1](q.view(-1, host_row_bytes(dim, bits))))
+             else self._host_codec(bits)[1](q.view(-1, host_row_bytes(dim, bits))))
         out.view(-1).copy_(d.reshape(-1))
         return out
 

@@ -363,6 +363,11 @@ int pm_set_forward_tuning(int32_t stage_out, int32_t flat_grid) {
 int pm_set_backward_tuning(int32_t sort_impl, int32_t order, int32_t xcd_affine, int32_t max_phases) {
     if (sort_impl < -1 || sort_impl > 2 || order < -1 || order > 1 || xcd_affine < -1 || xcd_affine > 1)
         return fail(PM_ERR_INVALID, "sort_impl must be -1 .. 2, order / xcd_affine -1, 0 or 1");
+#ifndef PM_ALTERNATES
+    if (sort_impl > 0)
+        return fail(PM_ERR_UNSUPPORTED, "sort_impl 1 (rocPRIM) and 2 (round 2's LSD sort) exist in the alternates build only "
+                                        "(libparam_amd_alt.so: make -C param_amd/csrc alt)");
+#endif
     if (max_phases != -1 && max_phases != 1 && max_phases != 2) return fail(PM_ERR_INVALID, "max_phases must be -1, 1 or 2");
     pm::set_backward_tuning(sort_impl, order, xcd_affine, max_phases);
     return PM_OK;
@@ -406,6 +411,7 @@ int pm_embbag_sort_status(const pm_embbag_batch* op, int64_t max_rows, const voi
     return PM_OK;
 }
 
+#ifdef PM_ALTERNATES
 int64_t pm_radix_sort_scratch_bytes(int64_t n_max) {
     if (n_max < 0 || n_max > 0xffffffffLL) return fail(PM_ERR_INVALID, "n_max must be in [0, 2^32)");
     return static_cast<int64_t>(pm::rs_scratch_bytes(static_cast<size_t>(n_max)));
@@ -435,6 +441,7 @@ int pm_radix_sort_pairs(void* keys_a, void* keys_b, uint32_t* vals_a, uint32_t* 
     if (h != hipSuccess) return hip_fail(h, "pm_radix_sort_pairs");
     return PM_OK;
 }
+#endif
 
 static int rowquant_args_ok(int64_t n_rows, int32_t dim, int32_t bitwidth) {
     if (n_rows < 0) return fail(PM_ERR_INVALID, "n_rows is negative");
@@ -526,6 +533,7 @@ int pm_embbag_fwd_split(const pm_embbag_batch* op, float* out, pm_stream_t strea
     return PM_OK;
 }
 
+#ifdef PM_ALTERNATES
 int pm_embbag_bwd(const pm_embbag_batch* op, const float* grad, void* const* dst_tables, int32_t dst_dtype,
                   float alpha, pm_stream_t stream) {
     pm::KParams p;
@@ -540,11 +548,17 @@ int pm_embbag_bwd(const pm_embbag_batch* op, const float* grad, void* const* dst
     if (h != hipSuccess) return hip_fail(h, "pm_embbag_bwd launch");
     return PM_OK;
 }
+#endif
 
 static int sorted_args_ok(const pm_embbag_batch* op, int64_t max_rows) {
     if (max_rows < 1 || max_rows > (1LL << 31)) return fail(PM_ERR_INVALID, "max_rows must be in [1, 2^31]");
     if (op->num_indices >= (1LL << 32) || static_cast<int64_t>(op->batch) >= (1LL << 32))
         return fail(PM_ERR_UNSUPPORTED, "sorted backward needs num_indices and batch below 2^32");
+#ifndef PM_ALTERNATES
+    if (op->num_tables > pm::kSegSortMaxTables)
+        return fail(PM_ERR_UNSUPPORTED, "sorted backward: at most " + std::to_string(pm::kSegSortMaxTables) +
+                                            " tables per request (split the request by tables: the calls are independent)");
+#endif
     return PM_OK;
 }
 

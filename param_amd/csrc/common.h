@@ -172,7 +172,9 @@ __host__ __device__ inline size_t tile_lds_bytes(int bags_per_block, int idx_cap
 hipError_t launch_embbag_fwd(const KParams& p, int weight_dtype, int max_dim, int unroll,
                              hipStream_t stream);
 hipError_t launch_embbag_fwd_split(const KParams& p, int weight_dtype, int max_dim, hipStream_t stream);
-hipError_t launch_embbag_bwd(const KParams& p, int dst_dtype, int max_dim, hipStream_t stream);
+#ifdef PM_ALTERNATES
+hipError_t launch_embbag_bwd(const KParams& p, int dst_dtype, int max_dim, hipStream_t stream);   // the atomic backward (embbag_bwd.hip)
+#endif
 hipError_t launch_embbag_check(const KParams& p, int32_t* d_err, int vec, int max_dim, int64_t fixed_pooling,
                                int uniform_dims, hipStream_t stream);
 hipError_t launch_fill_random(void* dst, int64_t count, int dtype, int dist, float lo, float hi,
@@ -192,6 +194,7 @@ std::string sort_plan_describe(const KParams& p, int64_t max_rows, int64_t fixed
 hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, int max_dim, const void* workspace,
                             float* const* momentum, const pm_rowwise_adagrad* opt, hipStream_t stream);
 
+#ifdef PM_ALTERNATES
 // own stable LSD radix sort of (key, uint32) pairs (radix_sort.hip); element count optionally read from device memory
 size_t rs_scratch_bytes(size_t n_max);
 int rs_num_passes(int begin_bit, int end_bit);   // result lands in the b buffers iff odd
@@ -205,6 +208,7 @@ template <typename K>
 hipError_t rs_sort_pairs(K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n_max, const uint32_t* d_count,
                          int begin_bit, int end_bit, void* scratch, hipStream_t stream, size_t seg_len = 0,
                          const RsSource* src = nullptr);
+#endif
 
 // Hybrid backward (round 4): tables whose lookups are (nearly) all to distinct rows skip the sort.  The sort's first kernel
 // classifies every table on the device; a HYBRID table's lookups are tested against four hashed "this row was looked up twice"

@@ -9,8 +9,9 @@
 //   2. sorts the pairs with a stable LSD radix sort by the ROW bits only (radix_sort.hip: own kernels, 3 passes of 8 bits
 //      for 10 M-row tables).  The request is table-major, so after a stable sort by row the lookups of one (table, row)
 //      are still contiguous and in lookup order -- the order is (row, table, position), which is all step 3 needs: it
-//      finds runs by key equality.  (Sorting the table bits too would be a fourth pass for nothing.)  rocPRIM's
-//      radix_sort_pairs stays compiled in as the measured alternative: PARAM_AMD_SORT=rocprim.
+//      finds runs by key equality.  (Sorting the table bits too would be a fourth pass for nothing.)  (That was round 2; the
+//      product library sorts with seg_sort.hip -- per-table segments established on the device.  Round 2's sort and rocPRIM's
+//      radix_sort_pairs are measured alternatives and cross-checks of the ALTERNATES build only: make alt, -DPM_ALTERNATES.)
 //   3. streams the sorted pairs: every run of equal keys is owned by ONE lane group, which
 //      reads the destination row once, adds the run's gradient rows in sorted (= original
 //      index) order in fp32 registers and writes the row back once      (bwd_sorted_kernel)
@@ -35,7 +36,9 @@
 #include <unordered_map>
 #include <vector>
 
+#ifdef PM_ALTERNATES
 #include <rocprim/device/device_radix_sort.hpp>
+#endif
 
 #include "bwd_sorted_apply.h"
 
@@ -46,6 +49,7 @@ constexpr int kDefaultSortMode = 0;
 // (kSortTile, SortedParams, the destination types, the kernels and their launchers: bwd_sorted_apply.h / _impl.inc)
 
 // ---------------------------------------------------------------------------------------------
+#ifdef PM_ALTERNATES      // (round 2's sort only: the segmented sort forms its keys itself)
 // step 1: keys / values, same tiling and LDS offset staging as the forward
 template <typename K, bool WEIGHTED>
 __global__ void __launch_bounds__(kBlock) build_keys_kernel(const KParams p, K* keys, uint32_t* vals,
@@ -87,6 +91,7 @@ __global__ void __launch_bounds__(kBlock) build_keys_kernel(const KParams p, K* 
         }
     }
 }
+#endif
 
 
 
@@ -130,6 +135,7 @@ inline int64_t max_chunks(int64_t n, int max_dim) {
 
 inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
+#ifdef PM_ALTERNATES
 template <typename K>
 hipError_t rocprim_temp_bytes(int64_t n, int kbits_sort, size_t& bytes) {
     bytes = 0;
@@ -138,6 +144,7 @@ hipError_t rocprim_temp_bytes(int64_t n, int kbits_sort, size_t& bytes) {
     return rocprim::radix_sort_pairs(nullptr, bytes, kn, kn, vn, vn, static_cast<size_t>(n), 0u,
                                      static_cast<unsigned>(kbits_sort), hipStream_t(0));
 }
+#endif
 
 // Backward tuning knobs (pm_set_backward_tuning; -1 = default, which the environment can override once):
 //   sort_impl  0 own radix sort (radix_sort.hip), 1 rocPRIM radix_sort_pairs              PARAM_AMD_SORT=rocprim
@@ -164,7 +171,12 @@ int knob(std::atomic<int>& k, F env_default) {
 // sort_impl: 0 (default) the segmented sort of round 3 (seg_sort.hip: per-table segments established on the device);
 //            1 rocPRIM radix_sort_pairs (PARAM_AMD_SORT=rocprim); 2 round 2's own LSD sort with host-side plans
 //            (PARAM_AMD_SORT=legacy) -- both kept as measured alternatives and as independent checks of the new path
+//            (the alternates build only; the product library has the segmented sort and nothing else)
+#ifdef PM_ALTERNATES
 int sort_impl_knob() { return knob(g_sort_impl, [] { return env_is("PARAM_AMD_SORT", "rocprim") ? 1 : env_is("PARAM_AMD_SORT", "legacy") ? 2 : 0; }); }
+#else
+int sort_impl_knob() { return 0; }
+#endif
 bool use_rocprim_sort() { return sort_impl_knob() == 1; }
 // how the segmented sort orders a table's pairs (pm_set_sort_tuning, PARAM_AMD_SORT_MODE): 0 LSD passes over all row bits
 // (ascending rows; one kernel per pass, tiles learn their prefixes from their predecessors in flight), 1 one partition pass on
@@ -216,11 +228,15 @@ int max_phases() { return knob(g_max_phases, [] { return env_is("PARAM_AMD_BWD_P
 
 hipError_t ws_layout(void* base, int64_t n, int T, int key_bytes, int kbits_sort, bool weighted, int max_dim, SortWs& ws) {
     size_t tb = 0;
+#ifdef PM_ALTERNATES
     hipError_t rc = key_bytes == 4 ? rocprim_temp_bytes<uint32_t>(n, kbits_sort > 32 ? 32 : kbits_sort, tb)
                                    : rocprim_temp_bytes<uint64_t>(n, kbits_sort, tb);
     if (rc != hipSuccess) return rc;
     const size_t own = rs_scratch_bytes(static_cast<size_t>(n));
     if (own > tb) tb = own;
+#else
+    if (T > kSegSortMaxTables) return hipErrorInvalidValue;      // (capi.hip refuses such a request with a message before it gets here)
+#endif
     if (T <= kSegSortMaxTables) {
         const size_t seg = seg_sort_scratch_bytes(static_cast<size_t>(n), T, !weighted);
         if (seg > tb) tb = seg;
@@ -315,6 +331,7 @@ SortPlan make_plan(const KParams& p, int64_t max_rows, int64_t fixed_pooling, in
         g.fused_keys = !g.weighted;
         return g;
     }
+#ifdef PM_ALTERNATES
     const bool fixed = fixed_pooling > 0 && !g.sliced && p.T >= 1 && p.B > 0 &&
                        fixed_pooling * p.B * static_cast<int64_t>(p.T) == p.N;
     g.H = 1;
@@ -334,6 +351,24 @@ SortPlan make_plan(const KParams& p, int64_t max_rows, int64_t fixed_pooling, in
     else g.sort_end_bit = table_major_order() ? g.kbits : g.rbits;
     g.in_b = g.rocprim || (rs_num_passes(0, g.sort_end_bit) % 2 == 1);
     g.fused_keys = g.segmented && g.H == 1 && !g.weighted && !g.sliced && g.sort_end_bit > 0 && fused_keys_allowed();
+#else
+    // (more than kSegSortMaxTables tables: refused by capi.hip; the fields below keep the record well-formed)
+    g.H = 1;
+    g.hbits = 0;
+    g.tshift = g.rbits;
+    g.kbits = g.tshift + bits_for(p.T);
+    g.key_bytes = (g.kbits + 1 <= 32) ? 4 : 8;
+    g.phase_bags = 0;
+    g.seg_len = 0;
+    g.seg_tiles = 0;
+    g.segmented = false;
+    g.xcd = false;
+    g.sort_end_bit = g.kbits;
+    g.in_b = false;
+    g.fused_keys = false;
+    (void)fixed_pooling;
+    (void)phases;
+#endif
     return g;
 }
 
@@ -367,13 +402,6 @@ SegSortRequest seg_request(const KParams& p, const SortPlan& g, SortWs& ws) {
 
 template <typename K>
 hipError_t sort_impl(const KParams& p, const SortPlan& g, SortWs& ws, hipStream_t stream) {
-    KParams q = p;
-    q.bag_begin = 0;
-    q.bag_count = p.B;
-    q.tiles_per_table = static_cast<int32_t>((p.B + p.bags_per_block - 1) / p.bags_per_block);
-    q.xcd_affine = 0;
-    const int grid = q.T * q.tiles_per_table;
-    const size_t lds = static_cast<size_t>(q.bags_per_block + 2) * sizeof(int64_t);
     K* ka = reinterpret_cast<K*>(ws.keys_a);
     K* kb = reinterpret_cast<K*>(ws.keys_b);
     if (g.v2) {
@@ -382,6 +410,14 @@ hipError_t sort_impl(const KParams& p, const SortPlan& g, SortWs& ws, hipStream_
         if (rc != hipSuccess || g.hyb) return rc;      // hybrid: the rest of the sort follows the bag-major kernel, in the apply call
         return seg_sort_part_b<K>(rq, g.mode, ka, kb, ws.vals_a, ws.vals_b, ws.bag_of, ws.temp, stream);
     }
+#ifdef PM_ALTERNATES
+    KParams q = p;
+    q.bag_begin = 0;
+    q.bag_count = p.B;
+    q.tiles_per_table = static_cast<int32_t>((p.B + p.bags_per_block - 1) / p.bags_per_block);
+    q.xcd_affine = 0;
+    const int grid = q.T * q.tiles_per_table;
+    const size_t lds = static_cast<size_t>(q.bags_per_block + 2) * sizeof(int64_t);
     // the apply's work-list control words start at zero (the segmented sort's first kernel does this itself)
     hipError_t zrc = hipMemsetAsync(ws.fix_ctl, 0, 4 * sizeof(uint32_t), stream);
     if (zrc != hipSuccess) return zrc;
@@ -410,6 +446,9 @@ hipError_t sort_impl(const KParams& p, const SortPlan& g, SortWs& ws, hipStream_
                                          static_cast<unsigned>(g.sort_end_bit), stream);
     return rs_sort_pairs<K>(ka, kb, ws.vals_a, ws.vals_b, static_cast<size_t>(p.N), nullptr, 0, g.sort_end_bit, ws.temp, stream,
                             g.segmented ? static_cast<size_t>(g.seg_len) : 0);
+#else
+    return hipErrorInvalidValue;      // (only the segmented sort exists in the product library)
+#endif
 }
 
 // the workspace is sized for the widest key the request can get (two phases), whatever plan is used later
@@ -483,7 +522,11 @@ hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, int64_t
 // human-readable form of the plan a sort of this request would use (host-only; tests and sweeps)
 std::string sort_plan_describe(const KParams& p, int64_t max_rows, int64_t fixed_pooling, int phases) {
     const SortPlan g = make_plan(p, max_rows, fixed_pooling, phases);
+#ifdef PM_ALTERNATES
     const int passes = g.rocprim ? -1 : g.v2 ? seg_sort_passes(g.mode, g.rbits) : rs_num_passes(0, g.sort_end_bit);
+#else
+    const int passes = g.v2 ? seg_sort_passes(g.mode, g.rbits) : -1;
+#endif
     char buf[640];
     if (g.v2) {
         snprintf(buf, sizeof(buf),

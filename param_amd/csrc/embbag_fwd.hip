@@ -301,14 +301,21 @@ __global__ void __launch_bounds__(kBlock) embbag_fwd_kernel(const KParams p) {
 //     100-hot table's 3 x heavier tiles and lost 10 % to that imbalance (same process, grids taking turns: Criteo D = 128 uniform
 //     203 us old grid / 196 resident set / 174.5-179 at 4096-8192 workgroups; mixed dims 177 / 152-155 / 150: profiles/r06_flat_grid_ab.md).
 //     Which workgroup pools which tile changes no result.
-constexpr int kFlatMaxTables = 1024;   // tables a compact launch keeps in LDS (6 KB); larger requests keep the T x tiles grid
+// (capi.hip offers the compact launch to requests of up to 1024 tables: 6 bytes of LDS each; larger ones keep the T x tiles grid)
+// LDS of the flat-walk kernel: [offsets | index tile (| weights)] [burst buffer: stage_bags x stage_out floats] [compact: prefix, tile sizes]
+__host__ __device__ inline size_t flat_tables_offset(const KParams& p, bool weighted) {
+    return (tile_lds_bytes(p.bags_per_block, p.idx_cap, weighted) + static_cast<size_t>(p.stage_bags) * p.stage_out * sizeof(float) + 15) / 16 * 16;
+}
 
 template <typename WT, int G, int UNROLL, bool WEIGHTED>
 __global__ void __launch_bounds__(kBlock) embbag_fwd_flat_kernel(const KParams p) {
     constexpr int VEC = Elem<WT>::kVec;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int s_pref[kFlatMaxTables + 1];       // compact: tiles before table t (s_pref[T] = all tiles)
-    __shared__ uint16_t s_bags[kFlatMaxTables];      // compact: bags per tile of table t
+    // compact: tiles before table t (s_pref[T] = all tiles) and bags per tile of table t -- behind the tile's arrays and the burst
+    // buffer, sized by the launcher for the request's T tables (6 bytes per table: as static arrays for kFlatMaxTables they were
+    // 6 KB per workgroup and cost the kernel its seventh workgroup per CU)
+    int* const s_pref = reinterpret_cast<int*>(smem + flat_tables_offset(p, WEIGHTED));
+    uint16_t* const s_bags = reinterpret_cast<uint16_t*>(s_pref + p.T + 1);
 
     // lane group and tile of table t: g = the next power of two >= D_t / VEC lanes (at least kBlock / flat_bags, at most G);
     // ~flat_target lookups per tile by the table's average bag, NG .. flat_bags bags, a multiple of NG
@@ -488,6 +495,7 @@ hipError_t launch_w(const KParams& p, hipStream_t stream) {
     if (p.flat_bags > 0) {   // short-bag requests with per-table pooling (capi.hip decides)
         lds += static_cast<size_t>(p.stage_bags) * p.stage_out * sizeof(float);
         if (p.flat_compact > 0) {
+            lds = flat_tables_offset(p, weighted) + static_cast<size_t>(p.T + 1) * 4 + static_cast<size_t>(p.T) * 2;
             // p.flat_compact = the workgroup count capi.hip chose: about as many as the request has tiles (an estimate from its sizes: the
             // tiles' true count is on the device), so nearly every workgroup pools ONE tile and the dispatcher balances the load; where
             // the estimate falls short workgroups walk on (b + grid, ...), where it overshoots the surplus leaves after the prologue --

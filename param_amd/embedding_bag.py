@@ -351,7 +351,7 @@ def sort_status(ts: _TableSet, indices, offsets, B, psw=None, bag_begin=0, bag_c
 def _bwd(ts: _TableSet, grad, indices, offsets, B, dst_ptrs_dev, dst_dtype, alpha, psw=None,
          bag_begin=0, bag_count=None, method: str = "sorted", presorted: bool = False, pooling: Optional[int] = None):
     """``method="sorted"`` (default): deterministic, bit-identical to a sequential scatter-add;
-    ``method="atomic"``: hardware float atomics (order not fixed)."""
+    ``method="atomic"``: hardware float atomics (order not fixed; tests / tools: the alternates build)."""
     _require_device(grad, "grad")
     _, _, shape = ts.out_desc(B)
     if grad.dtype != torch.float32 or tuple(grad.shape) != tuple(shape):
@@ -360,8 +360,12 @@ def _bwd(ts: _TableSet, grad, indices, offsets, B, dst_ptrs_dev, dst_dtype, alph
     op = ts.request(indices, offsets, B, psw, bag_begin, bag_count)
     L = _lib.load()
     if method == "atomic":
-        _lib.check(L.pm_embbag_bwd(ctypes.byref(op), grad.data_ptr(), dst_ptrs_dev.data_ptr(),
-                                   _WDTYPE[dst_dtype], float(alpha), _stream_ptr()))
+        # the atomic kernel is a measured baseline and a cross-check (25 x slower): it lives in the ALTERNATES build only
+        # (libparam_amd_alt.so, `make -C param_amd/csrc alt`; ImportError if that is not built)
+        A = _lib.load_alternates()
+        rc = A.pm_embbag_bwd(ctypes.byref(op), grad.data_ptr(), dst_ptrs_dev.data_ptr(), _WDTYPE[dst_dtype], float(alpha), _stream_ptr())
+        if rc != _lib.PM_OK:
+            raise _lib.ParamAmdError(rc, A.pm_last_error().decode())
         return
     if method != "sorted":
         raise ValueError('method must be "sorted" or "atomic"')

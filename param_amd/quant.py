@@ -7,10 +7,9 @@ is not published).  Row formats: fp16 for 16 bits, fbgemm's fused row-wise forma
 row's codes) for 8 / 4 / 2 bits -- the same bytes as torch's ``quantized::embedding_bag_*_prepack`` operators.
 
 There is no CPU path in this module: tensors must live on the GPU, and a GPU tensor is only ever quantised by the HIP
-kernels.  (The comms plug-in, ``MI355XBackend._quantize_rows``, additionally accepts HOST tensors -- ``--device cpu``, the
-gloo mode it is tested in without GPUs -- and hands those to torch's own ``quantized::embedding_bag_*_prepack`` operators,
-i.e. to the operators ``oracle/rowquant.py`` is pinned to: that branch is test plumbing, no parity claim rests on it, and a
-device tensor can not reach it -- the branch is taken on ``tensor.is_cuda`` alone.)
+kernels.  (The comms plug-in refuses HOST tensors too unless a test injects a codec: ``MI355XBackend.host_row_codec``, set by the gloo
+workers of ``tests/dist_workers.py`` to torch's own ``quantized::embedding_bag_*_prepack`` operators -- the operators
+``oracle/rowquant.py`` is pinned to.  Round 6 moved them out of the product backend.)
 """
 from __future__ import annotations
 

@@ -41,10 +41,20 @@ def _env(rank, world, port):
     torch.set_num_threads(1)
 
 
+def _torch_host_row_codec(bits):
+    """torch's CPU operators for the row-wise quantised formats (the operators oracle/rowquant.py is pinned to): what the gloo
+    workers inject as ``MI355XBackend.host_row_codec`` -- the product backend has no host codec of its own"""
+    q = torch.ops.quantized
+    return {8: (q.embedding_bag_byte_prepack, q.embedding_bag_byte_unpack),
+            4: (q.embedding_bag_4bit_prepack, q.embedding_bag_4bit_unpack),
+            2: (q.embedding_bag_2bit_prepack, q.embedding_bag_2bit_unpack)}[bits]
+
+
 def _backend(rank, world, port):
     from param_amd.comms.pt import comms_utils
     from param_amd.comms.pt.mi355_backend import MI355XBackend
 
+    MI355XBackend.host_row_codec = staticmethod(_torch_host_row_codec)      # (class-level: the sweep driver builds its own instance)
     env = comms_utils.read_comms_env_vars()
     assert env == {"world_size": world, "local_size": world, "global_rank": rank, "local_rank": rank}
     info = comms_utils.bootstrap_info_holder("127.0.0.1", str(port), 0, env)

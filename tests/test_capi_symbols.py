@@ -12,21 +12,52 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared():
+    """(product symbols, alternates-only symbols): what include/param_amd.h declares outside / inside `#ifdef PM_ALTERNATES`"""
     src = open(os.path.join(ROOT, "include", "param_amd.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(pm_[a-z_0-9]+)\s*\(", src)))
+    alt_blocks = re.findall(r"#ifdef PM_ALTERNATES(.*?)#endif", src, flags=re.S)
+    product = re.sub(r"#ifdef PM_ALTERNATES.*?#endif", "", src, flags=re.S)
+    names = lambda text: sorted(set(re.findall(r"\b(pm_[a-z_0-9]+)\s*\(", text)))        # noqa: E731
+    return names(product), names("\n".join(alt_blocks))
 
 
 def test_header_symbols_match_binding_list():
-    assert _declared() == sorted(_lib.EXPORTED_SYMBOLS)
+    product, alternates = _declared()
+    assert product == sorted(_lib.EXPORTED_SYMBOLS)
+    assert alternates == sorted(_lib.ALTERNATE_SYMBOLS) and not set(product) & set(alternates)
 
 
 def test_library_loads_and_exports_every_symbol():
     L = _lib.load()
-    for name in _declared():
+    product, alternates = _declared()
+    for name in product:
         assert hasattr(L, name), name
     assert L.pm_abi_version() == _lib.PM_ABI_VERSION
     assert b"gfx950" in L.pm_build_info()
+    A = _lib.load_alternates()                              # tests / tools build: everything, plus the alternates
+    for name in product + alternates:
+        assert hasattr(A, name), name
+    assert A.pm_abi_version() == _lib.PM_ABI_VERSION
+
+
+def test_product_library_holds_the_winning_path_only():
+    """Round 6: rocPRIM's radix sort, round 2's LSD sort and the atomic backward are measured alternatives and cross-checks -- they
+    live in libparam_amd_alt.so (`make alt`, -DPM_ALTERNATES).  The product library exports none of their entry points, contains no
+    rocPRIM symbol and none of their kernels, and refuses to be switched to them."""
+    import subprocess
+
+    L = _lib.load()
+    for name in _lib.ALTERNATE_SYMBOLS:
+        assert not hasattr(L, name), name
+    dyn = subprocess.run(["nm", "-DC", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "rocprim" not in dyn.lower()
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for needle in (b"7rocprim", b"rs_scatter_kernel", b"17embbag_bwd_kernel", b"build_keys_kernel"):       # (mangled names: code, not messages)
+        assert needle not in blob, needle
+    assert needle in open(_lib.ALT_LIB_PATH, "rb").read()                   # (the probe does find them where they are)
+    for impl in (1, 2):
+        assert L.pm_set_backward_tuning(impl, -1, -1, -1) == _lib.PM_ERR_UNSUPPORTED and b"alternates build" in L.pm_last_error()
+    assert L.pm_set_backward_tuning(-1, -1, -1, -1) == _lib.PM_OK
 
 
 def test_struct_layout_matches_header():
@@ -61,12 +92,13 @@ def test_argument_validation_without_gpu():
     assert L.pm_set_tuning(0, 0, -1, -1) == _lib.PM_OK
     assert L.pm_set_backward_tuning(3, 0, 0, -1) == _lib.PM_ERR_INVALID and L.pm_set_sort_tuning(4) == _lib.PM_ERR_INVALID and L.pm_set_sort_tuning(-1) == _lib.PM_OK and L.pm_set_backward_tuning(-1, -1, -1, -1) == _lib.PM_OK
     in_b = ctypes.c_int32(-1)
-    assert L.pm_radix_sort_pairs(None, None, None, None, 0, None, 4, 0, 24, 0, None, 0, ctypes.byref(in_b), None) == _lib.PM_OK
+    A = _lib.load_alternates()                                    # round 2's sort: the alternates build
+    assert A.pm_radix_sort_pairs(None, None, None, None, 0, None, 4, 0, 24, 0, None, 0, ctypes.byref(in_b), None) == _lib.PM_OK
     assert in_b.value == 1                                        # 3 passes: the result would be in the b buffers
-    assert L.pm_radix_sort_pairs(None, None, None, None, 10, None, 3, 0, 24, 0, None, 0, ctypes.byref(in_b), None) == _lib.PM_ERR_INVALID
-    assert L.pm_radix_sort_pairs(None, None, None, None, 8192, None, 4, 0, 24, 1000, None, 0, ctypes.byref(in_b), None) == _lib.PM_ERR_INVALID
-    assert b"segment_len" in L.pm_last_error()
-    assert L.pm_radix_sort_scratch_bytes(1 << 20) > 0 and L.pm_radix_sort_scratch_bytes(-1) == _lib.PM_ERR_INVALID
+    assert A.pm_radix_sort_pairs(None, None, None, None, 10, None, 3, 0, 24, 0, None, 0, ctypes.byref(in_b), None) == _lib.PM_ERR_INVALID
+    assert A.pm_radix_sort_pairs(None, None, None, None, 8192, None, 4, 0, 24, 1000, None, 0, ctypes.byref(in_b), None) == _lib.PM_ERR_INVALID
+    assert b"segment_len" in A.pm_last_error()
+    assert A.pm_radix_sort_scratch_bytes(1 << 20) > 0 and A.pm_radix_sort_scratch_bytes(-1) == _lib.PM_ERR_INVALID
     assert L.pm_fill_random(None, -1, _lib.PM_F32, 0, 0.0, 1.0, 0, None) == _lib.PM_ERR_INVALID
     # empty request: nothing to launch, succeeds without a device
     op.batch = op.bag_begin = op.bag_count = 0
@@ -191,7 +223,8 @@ def test_sort_plan_decisions_on_the_host():
     assert _plan(L, 26, 8192, 8, 10_000_000)["radix_bits"] == "8" and _plan(L, 4, 512, 8, 200_000)["passes"] == "2"
     assert _plan(L, 1024, 64, 64, 1 << 30)["key_bytes"] == "8"
     assert L.pm_set_sort_tuning(-1) == _lib.PM_OK
-    # round 2's host-side plans (sort_impl 2), kept as the measured alternative
+    # round 2's host-side plans (sort_impl 2), kept as the measured alternative -- in the alternates build
+    L = _lib.load_alternates()
     assert L.pm_set_backward_tuning(2, -1, -1, -1) == _lib.PM_OK
     bench = _plan(L, 48, 8192, 20, 10_000_000)                       # the benchmark step
     assert bench["sort"] == "own" and bench["key_bytes"] == "4" and bench["rbits"] == "24" and bench["kbits"] == "30"

@@ -1,5 +1,9 @@
-"""The build's own radix sort (param_amd/csrc/radix_sort.hip, C ABI pm_radix_sort_pairs) against numpy's stable argsort,
-and the sorted backward under every sort / order / XCD-mapping setting against the CPU oracle."""
+"""Round 2's radix sort (param_amd/csrc/radix_sort.hip, C ABI pm_radix_sort_pairs) against numpy's stable argsort,
+and the sorted backward under every sort / order / XCD-mapping setting against the CPU oracle.
+
+The whole module runs on the ALTERNATES build (libparam_amd_alt.so, `make -C param_amd/csrc alt`): round 2's sort, rocPRIM's
+radix sort and the `sort_impl` knob left the product library in round 6; here they are cross-checks of the product path (sort_impl 0
+rows of the matrix below are the product's own sort, compiled from the same sources)."""
 import ctypes
 import os
 
@@ -15,10 +19,13 @@ DEV = "cuda:0"
 def _need_gpu_and_lib():
     import param_amd
 
+    from param_amd import _lib
+
     assert torch.cuda.is_available(), "gpu-marked tests need a ROCm device"
     param_amd.load_library()
-    yield
-    param_amd.set_backward_tuning()
+    with _lib.use_alternates():
+        yield
+        param_amd.set_backward_tuning()
 
 
 def _sort(keys: np.ndarray, begin: int, end: int, count=None, seg_len: int = 0):

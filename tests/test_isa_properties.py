@@ -140,8 +140,8 @@ def test_no_kernel_of_the_path_spills_and_register_budgets_hold(bundles):
     (a spill in a row loop would cost HBM traffic that no parity test sees), and the families whose occupancy the design counts
     on stay inside their register budgets -- forward <= 128 VGPRs in every instantiation (>= 4 waves per SIMD; the default
     fp32 path 42), sorted apply main kernel <= 128, bag-major apply <= 128, look-back pass <= 136 and LDS under 64 KB (two
-    workgroups per CU by LDS), all-pass histogram <= 64; the flat-walk forward keeps 6 KB of static LDS (round 6: the tables' tile sizes and the prefix of their tile
-    counts).  (Sorted apply main kernel, round 5: + kBlock x VEC floats of LDS for the
+    workgroups per CU by LDS), all-pass histogram <= 64 (the flat-walk forward's per-table tile sizes and prefix, round 6, live in DYNAMIC LDS sized for the
+    request's tables: as 6 KB of static arrays they cost it its seventh workgroup per CU).  (Sorted apply main kernel, round 5: + kBlock x VEC floats of LDS for the
     tile-level partial sums -- 25.6 KB in its largest instance, six workgroups per CU by LDS where its registers allow five.)  The bounds are the round-4 build's values with a small margin: a
     compiler or source change that moves them shows up here, not as an unexplained 5 % on the GPU."""
     res = _kernel_resources(bundles)
@@ -149,7 +149,7 @@ def test_no_kernel_of_the_path_spills_and_register_budgets_hold(bundles):
     assert len(own) > 1000, len(own)                       # every template instantiation is there
     spilled = {n: v[2] for n, v in own.items() if v[2] != 0}
     assert not spilled, spilled
-    budgets = {"17embbag_fwd_kernel": (128, 4096), "22embbag_fwd_flat_kernel": (128, 8192), "22bwd_sorted_main_kernel": (128, 26624),
+    budgets = {"17embbag_fwd_kernel": (128, 4096), "22embbag_fwd_flat_kernel": (128, 1024), "22bwd_sorted_main_kernel": (128, 26624),
                "17bwd_unique_kernel": (128, 1024), "24seg_lookback_pass_kernel": (136, 65536), "19seg_hist_all_kernel": (64, 16384),
                "15hyb_mark_kernel": (64, 16384)}
     seen = {k: 0 for k in budgets}

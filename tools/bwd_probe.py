@@ -50,6 +50,11 @@ def timed(fn, n):
 CONFIGS = [(1, 1, 0, 1), (0, 0, 0, 1), (0, 1, 0, 1), (0, 1, 1, 1), (0, 1, 1, 2), (0, 1, 0, 2), (1, 1, 1, 2)]
 if a.configs:
     CONFIGS = [tuple(int(x) for x in c.split(",")) for c in a.configs.split(";")]
+# (round 6: sort_impl 1 / 2 -- rocPRIM, round 2's sort -- exist in the alternates build only; the whole matrix runs on it)
+from param_amd import _lib  # noqa: E402
+
+_alt = _lib.use_alternates()
+_alt.__enter__()
 for sort_impl, order, xcd, ph in CONFIGS:
     param_amd.set_backward_tuning(sort_impl, order, xcd, ph)
     param_amd.set_tuning(nt_loads=a.nt)

@@ -21,6 +21,7 @@ ap.add_argument("--subsets", default="all,128,64,32,16,narrow")
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--batch", type=int, default=8192)
 ap.add_argument("--backward", action="store_true")
+ap.add_argument("--hybrid", default="", help="comma-separated pm_set_hybrid_tuning values for the backward, taking turns (default: the library's)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 B = a.batch
@@ -81,9 +82,12 @@ for subset in a.subsets.split(","):
             print(json.dumps(rec), flush=True)
         if a.backward:
             i, o = reqs[0]
-            s = timed(lambda: m.scatter_add_(grad, i, o, alpha=-1e-6, batch=B), max(10, a.iters // 2))
-            st = m.sort_status(i, o, batch=B)
-            print(json.dumps({"exp": "mixed_bwd", "subset": subset, "tables": len(sel), "indices": name, "lookups": n, "us": round(s * 1e6, 2),
-                              "alg_frac": round(bwd_bytes / s / 8e12, 4), "alg_MB": round(bwd_bytes / 1e6, 1), **st}), flush=True)
+            for hyb in ([int(x) for x in a.hybrid.split(",")] if a.hybrid else [-1]):
+                param_amd.set_hybrid_tuning(hyb)
+                s = timed(lambda: m.scatter_add_(grad, i, o, alpha=-1e-6, batch=B), max(10, a.iters // 2))
+                st = m.sort_status(i, o, batch=B)
+                print(json.dumps({"exp": "mixed_bwd", "subset": subset, "tables": len(sel), "indices": name, "lookups": n, "hybrid": hyb,
+                                  "us": round(s * 1e6, 2), "alg_frac": round(bwd_bytes / s / 8e12, 4), "alg_MB": round(bwd_bytes / 1e6, 1), **st}), flush=True)
+            param_amd.set_hybrid_tuning()
     del m, out, grad
     torch.cuda.empty_cache()
