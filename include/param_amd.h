@@ -447,6 +447,16 @@ int pm_set_hybrid_tuning(int32_t enable, int64_t lookback_spin_cap);
 int pm_set_hybrid_rest(int32_t mode);
 
 /*
+ * ABI v7.  The hybrid backward is offered only to requests whose bag-major launch fills the chip: the kernel tiles 128 bags, so a
+ * request has num_tables * ceil(bag_count / 128) of its workgroups, and with few of them each workgroup pools its 128 bags' lookups
+ * one bag after the other while most of the device idles (ONE 10 M-row table, batch 8192, pooling 20: 254 us against the sorted path's
+ * 96).  tiles = the fewest such workgroups for which the path is offered: -1 = default (1024: measured break-even at 768 - 1024,
+ * profiles/r06_few_tables_hybrid.jsonl), 0 = no lower bound (tests that drive the hybrid kernels with small requests).  A rule on the
+ * request's sizes, read when a request is sorted; results are the same either way (rows looked up at most 256 times: bit for bit).
+ */
+int pm_set_hybrid_min_tiles(int32_t tiles);
+
+/*
  * Forward with a row-wise QUANTISED output: the pooled vector of (bag b, table t) is written as one quantised row
  * (formats below, bitwidth 16 / 8 / 4 / 2) instead of max_dim floats -- what a quantised all-to-all of pooled embeddings
  * sends (--bitwidth of the reference's comms drivers), produced inside the lookup kernel's output burst so the fp32

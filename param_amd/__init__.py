@@ -8,7 +8,7 @@ Layout (only what the hot path needs):
   compute/pt/        mirror of the reference train/compute/pt emb driver CLI
   comms/pt/          mirror of the reference train/comms/pt backend plug-in, metrics and drivers
 """
-from ._lib import LIB_PATH, ParamAmdError, load as load_library, set_backward_tuning, set_forward_tuning, set_hybrid_rest, set_hybrid_tuning, set_sort_tuning, set_tuning  # noqa: F401
+from ._lib import LIB_PATH, ParamAmdError, load as load_library, set_backward_tuning, set_forward_tuning, set_hybrid_min_tiles, set_hybrid_rest, set_hybrid_tuning, set_sort_tuning, set_tuning  # noqa: F401
 from .embedding_bag import (  # noqa: F401
     BatchedEmbeddingBagMI355,
     EmbeddingBagMI355,

@@ -55,6 +55,7 @@ EXPORTED_SYMBOLS = (
     "pm_embbag_sort_status",
     "pm_set_hybrid_tuning",
     "pm_set_hybrid_rest",
+    "pm_set_hybrid_min_tiles",
 )
 
 
@@ -210,6 +211,8 @@ def _open(path: str, alternates: bool) -> ctypes.CDLL:
     L.pm_set_hybrid_tuning.argtypes = [i32, i64]
     L.pm_set_hybrid_rest.restype = ctypes.c_int
     L.pm_set_hybrid_rest.argtypes = [i32]
+    L.pm_set_hybrid_min_tiles.restype = ctypes.c_int
+    L.pm_set_hybrid_min_tiles.argtypes = [i32]
     if alternates:
         L.pm_embbag_bwd.restype = ctypes.c_int
         L.pm_embbag_bwd.argtypes = [ctypes.POINTER(pm_embbag_batch), vp, vp, i32, ctypes.c_float, vp]
@@ -310,6 +313,13 @@ def set_hybrid_tuning(enable: int = -1, lookback_spin_cap: int = 0) -> None:
     enable 0 off / 1 on (default; tables classified on the device at every sort) / 2 every structurally eligible table (tests);
     lookback_spin_cap > 0 lowers the number of polls after which a look-back walk counts for its predecessor (tests)."""
     check(load().pm_set_hybrid_tuning(enable, lookback_spin_cap))
+
+
+def set_hybrid_min_tiles(tiles: int = -1) -> None:
+    """``pm_set_hybrid_min_tiles``: the hybrid backward is offered to requests of at least this many bag-major workgroups
+    (``num_tables * ceil(bag_count / 128)``): -1 = default (1024: below, a handful of workgroups pool while the chip idles and the
+    sorted path is up to 4 x faster), 0 = no lower bound (tests that drive the hybrid kernels with small requests)."""
+    check(load().pm_set_hybrid_min_tiles(tiles))
 
 
 def set_hybrid_rest(mode: int = -1) -> None:

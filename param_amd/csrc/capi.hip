@@ -392,6 +392,12 @@ int pm_set_hybrid_rest(int32_t mode) {
     return PM_OK;
 }
 
+int pm_set_hybrid_min_tiles(int32_t tiles) {
+    if (tiles < -1) return fail(PM_ERR_INVALID, "tiles must be -1 (default) or >= 0");
+    pm::set_hybrid_min_tiles(tiles);
+    return PM_OK;
+}
+
 int pm_embbag_sort_status(const pm_embbag_batch* op, int64_t max_rows, const void* workspace, pm_sort_status* out, pm_stream_t stream) {
     pm::KParams p;
     int rc = make_params(op, op ? op->weight_dtype : -1, p);

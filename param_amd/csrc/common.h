@@ -351,6 +351,7 @@ hipError_t launch_rows_dequantize(const void* src, int64_t n_rows, int dim, int 
 void set_backward_tuning(int sort_impl, int order, int xcd, int max_phases);   // -1 = default (environment)
 void set_sort_tuning(int mode);                                                // segmented sort: -1 default, 0 / 1 / 2
 void set_hybrid_tuning(int enable, uint32_t spin_cap);            // hybrid backward (embbag_bwd_sorted.hip); -1 = default
+void set_hybrid_min_tiles(int tiles);                             // ... offered from this many bag-major workgroups on: -1 default (1024)
 void set_hybrid_rest(int mode);                                   // ... its left-overs finished in LDS (hyb_rest_kernel): -1 default, 0 / 1
 hipError_t sort_status(const KParams& p, int64_t max_rows, int max_dim, const void* workspace, hipStream_t stream, uint32_t out[6]);
 

@@ -218,6 +218,7 @@ int hyb_enable_knob() { return knob(g_hyb_enable, [] { return env_int("PARAM_AMD
 //  pays for the fork and join, 0.957 / 0.957 / 0.972-0.981: two cross-stream event hand-offs cost more than the overlap returns.
 //  Removed; profiles/r06_rest_kernel_ab.md.)
 std::atomic<int> g_hyb_rest{-1};
+std::atomic<int> g_hyb_min_tiles{-1};      // pm_set_hybrid_min_tiles: bag-major workgroups from which the hybrid path is offered (-1: kHybMinTiles)
 int hyb_rest_knob() { return knob(g_hyb_rest, [] { return env_int("PARAM_AMD_HYB_REST", 1) != 0 ? 1 : 0; }); }
 bool want_xcd() { return knob(g_bwd_xcd, [] { return env_is("PARAM_AMD_BWD_XCD", "0") ? 0 : 1; }) == 1; }
 //   max_phases 1 (default): one apply launch; 2: a phases = 2 sort lays a fixed-pooling request out for the two-phase
@@ -498,8 +499,18 @@ hipError_t sort_indices(const KParams& p, int64_t max_rows, int max_dim, int64_t
         // the request's indices and offsets AGAIN (bag-major kernel, compaction), so a sort issued on its own -- possibly on a side
         // stream, with the caller free to refill the index buffer before the apply -- consumes the request completely, as before round 4.
         const int64_t uniq_tiles = (p.bag_count + kUniqueBags - 1) / kUniqueBags;     // the bag-major apply's tiles per table
+        // ... and only to requests whose bag-major launch fills the chip (round 6): the kernel tiles 128 bags, and a request of few
+        // tables is a handful of workgroups each pooling 128 bags' lookups in turn -- ONE 10 M-row table, batch 8192, pooling 20: 64
+        // workgroups, 254 us against the sorted path's 96; the 40 M-row 100-hot Criteo table on its own 1.29 ms against 0.29.  Same
+        // process, hybrid off / on taking turns (tools/r6_few_tables_probe.py, profiles/r06_few_tables_hybrid.jsonl; tables x batch,
+        // sorted / hybrid us): 512 tiles 353 / 405 and 326 / 362, 768 tiles 467 / 470, 1024 tiles 653 / 637, 1536 tiles 860 / 830,
+        // 2048 tiles 1185 / 1136.  A rule on the request's sizes, like the others here.
+        // pm_set_hybrid_min_tiles(0) lifts it (tests drive the hybrid kernels with small requests).
+        constexpr int64_t kHybMinTiles = 1024;
+        const int min_tiles_knob = g_hyb_min_tiles.load();
+        const bool fills = uniq_tiles * p.T >= (min_tiles_knob < 0 ? kHybMinTiles : static_cast<int64_t>(min_tiles_knob));
         if (defer_ok && g.v2 && en > 0 && !g.weighted && p.N >= static_cast<int64_t>(kHybMinCount) && uniq_tiles >= 1 &&
-            uniq_tiles <= kCompactMaxTiles && (even_req || en >= 2) && seg_sort_hybrid_available())
+            uniq_tiles <= kCompactMaxTiles && ((even_req && fills) || en >= 2) && seg_sort_hybrid_available())
             g.hyb = en >= 2 ? 2 : 1;
         std::lock_guard<std::mutex> lock(g_plan_mutex);
         // bound the record table: the OLDEST record goes (a clear() would also drop plans of workspaces that are sorted
@@ -731,6 +742,7 @@ hipError_t bwd_sorted_apply(const KParams& p, int64_t max_rows, int dst_dtype, i
 }
 
 void set_hybrid_rest(int mode) { g_hyb_rest.store(mode); }
+void set_hybrid_min_tiles(int tiles) { g_hyb_min_tiles.store(tiles); }
 
 // workgroups per table of hyb_rest_kernel: enough to put a workgroup on every CU (T_h x parts ~ 256): a staged table's sorted
 // positions are dealt out over them

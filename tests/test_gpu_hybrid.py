@@ -22,7 +22,11 @@ def _need_gpu_and_lib():
 
     assert torch.cuda.is_available(), "gpu-marked tests need a ROCm device"
     param_amd.load_library()
+    # (round 6: the library offers the hybrid path to requests of >= 1024 bag-major workgroups only; these tests drive its kernels with
+    # small requests, so the bound is lifted here -- test_small_requests_are_not_offered_the_hybrid_path pins the product rule)
+    param_amd.set_hybrid_min_tiles(0)
     yield
+    param_amd.set_hybrid_min_tiles()
     param_amd.set_hybrid_tuning()
     param_amd.set_hybrid_rest()
     param_amd.set_sort_tuning()
@@ -493,3 +497,32 @@ def test_rows_dealt_out_to_slice_queues_overflow_and_batch_slices(idt):
         assert (out[2][0][7] - out[0][0][7]).abs().max() <= tol, kw
     param_amd.set_hybrid_tuning()
 
+
+
+def test_small_requests_are_not_offered_the_hybrid_path(coracle):
+    """Round 6: the bag-major kernel tiles 128 bags, so a request of few tables is a handful of workgroups pooling in turn while the
+    chip idles (one 10 M-row table, batch 8192: 254 us against the sorted path's 96; profiles/r06_few_tables_hybrid.jsonl).  The
+    library offers the hybrid path from 1024 such workgroups on -- a rule on the request's sizes: 8 tables x batch 4096 = 256 of them
+    sort everything by default, go hybrid with the bound lifted (pm_set_hybrid_min_tiles(0)) or lowered below the request, and give
+    the oracle's tables, bit for bit, every time."""
+    import param_amd
+
+    rows, D, B, L = [400_000] * 8, 64, 4096, 4
+    idx, off = _request(rows, B, L, 0.0, 11)
+    grad = torch.randn(B, len(rows) * D, device=DEV)
+    ref = _model(rows, D, seed=9)
+    tabs = [ref.table(t).cpu().numpy() for t in range(len(rows))]
+    exp = _oracle_tables(coracle, tabs, idx, off, B, grad, D, -0.25)
+    try:
+        for tiles, hybrid in ((-1, False), (0, True), (256, True), (257, False)):
+            param_amd.set_hybrid_min_tiles(tiles)
+            m = _model(rows, D, seed=9)
+            m.scatter_add_(grad, idx, off, alpha=-0.25, batch=B)
+            st = m.sort_status(idx, off, batch=B)
+            assert (st["hybrid_launched"] == 1 and st["hybrid_tables"] == len(rows)) == hybrid, (tiles, st)
+            if not hybrid:
+                assert st["hybrid_launched"] == 0 and st["pairs_sorted"] == idx.numel(), (tiles, st)
+            for t in range(len(rows)):
+                assert np.array_equal(m.table(t).cpu().numpy(), exp[t]), (tiles, t)
+    finally:
+        param_amd.set_hybrid_min_tiles(0)               # (the module's setting)

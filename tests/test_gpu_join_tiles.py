@@ -22,7 +22,11 @@ def _need_gpu_and_lib():
 
     assert torch.cuda.is_available(), "gpu-marked tests need a ROCm device"
     param_amd.load_library()
+    # (round 6: the library offers the hybrid path to requests of >= 1024 bag-major workgroups only; these tests drive its kernels with
+    # small requests, so the bound is lifted here -- test_small_requests_are_not_offered_the_hybrid_path pins the product rule)
+    param_amd.set_hybrid_min_tiles(0)
     yield
+    param_amd.set_hybrid_min_tiles()
     param_amd.set_hybrid_tuning()
 
 
