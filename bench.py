@@ -873,7 +873,8 @@ def main():
         "note": "hot rows are served by L2, so algorithmic bytes exceed HBM bytes: alg_frac is a cache-assisted rate, not a roofline fraction",
         "fabric_side_frac": (prof["hbm_bytes_per_launch"] / zipf_s / 1e9 / HBM_PEAK_GBPS) if prof.get("hbm_bytes_per_launch") else None,
         "fabric_side_frac_note": "L2 -> fabric bytes (Infinity-Cache hits included) of the committed profile / this run's launch time: an "
-                                 "UPPER bound on the HBM-side rate -- the bench replays one request, and 2.2 GB of Zipf rows partly stay in the 256 MB memory-side cache",
+                                 "UPPER bound on the HBM-side rate (what the 256 MB memory-side cache serves is in it); profile and window both rotate "
+                                 "REQUESTS_ROTATED requests since round 6",
         "fabric_side_frac_source": ("profiles/pmc_traffic.json[%s] (rocprofv3 --pmc bytes of a committed profile) / this run's launch time" % key)
         if prof.get("hbm_bytes_per_launch") else None}
     # PMC counters are not collected inside a bench run (separate rocprofv3 --pmc passes: profiles/): `traffic` is the committed
@@ -1142,7 +1143,7 @@ def main():
                     result[key] = {"skipped": f"needs {need / 1e9:.0f} GB of free HBM, {free_now / 1e9:.0f} available after the fp32 block"}
                     continue
                 result[key] = extra_block(dev, rows_x, pools_x, dims_x, dt_x, B_local, a.alpha, n_sub, barrier, lay_x,
-                                          pmc_key={"bf16_T64": "bf16", "criteo": "criteo"}.get(key))
+                                          pmc_key={"bf16_T64": "bf16", "criteo": "criteo", "criteo_mixed": "mixed"}.get(key))
             except Exception as exc:
                 result[key] = {"error": str(exc)[:300]}
             gc.collect()

@@ -283,8 +283,9 @@ def set_forward_tuning(stage_out: int = -1, flat_grid: int = -1) -> None:
 
 def set_backward_tuning(sort_impl: int = -1, order: int = -1, xcd_affine: int = -1, max_phases: int = -1) -> None:
     """sorted-backward knobs (``pm_set_backward_tuning``): sort_impl 0 segmented sort (segments / pooling established on the
-    device) / 1 rocPRIM / 2 round 2's own LSD sort with host-side plans, order 1 (table, row) / 0 (row, table) and
-    max_phases 2 / 1 for sort_impl 1 and 2, xcd_affine 1 / 0; -1 = default.  Read when a request is sorted; its apply follows."""
+    device) / 1 rocPRIM / 2 round 2's own LSD sort with host-side plans (1 and 2: inside ``use_alternates()`` only -- the product
+    library refuses them), order 1 (table, row) / 0 (row, table) and max_phases 2 / 1 for sort_impl 1 and 2, xcd_affine 1 / 0;
+    -1 = default.  Read when a request is sorted; its apply follows."""
     global _sort_impl
     check(load().pm_set_backward_tuning(sort_impl, order, xcd_affine, max_phases))
     _sort_impl = sort_impl
@@ -297,6 +298,8 @@ def needs_pooling_hint() -> bool:
     """True when the selected key sort is one of the alternatives that read ``pm_embbag_batch.fixed_pooling`` (sort_impl 1 /
     2, by knob or ``PARAM_AMD_SORT``); the default segmented sort establishes pooling on the device and the Python layer then
     neither computes nor caches a verdict about the offsets' contents"""
+    if _alt is None or _lib is not _alt:
+        return False                      # the product library has the segmented sort and nothing else
     if _sort_impl >= 0:
         return _sort_impl != 0
     return os.environ.get("PARAM_AMD_SORT", "") in ("rocprim", "legacy")

@@ -373,6 +373,7 @@ def _bwd(ts: _TableSet, grad, indices, offsets, B, dst_ptrs_dev, dst_dtype, alph
     if not presorted and not _lib.needs_pooling_hint():
         # sort + apply sequenced by the library itself: the one form in which it may defer part of the sort into the apply
         # (hybrid backward: rows looked up once skip the sort)
+        op.fixed_pooling = 0       # (the cached descriptor may carry a hint from an alternates-build run: the segmented sort takes none)
         _lib.check(L.pm_embbag_bwd_fused(ctypes.byref(op), grad.data_ptr(), dst_ptrs_dev.data_ptr(), _WDTYPE[dst_dtype],
                                          float(alpha), max(ts.rows), ws.data_ptr(), ws.numel(), _stream_ptr()))
         return
@@ -415,6 +416,7 @@ def _adagrad(ts: _TableSet, grad, indices, offsets, B, mom_ptrs_dev, lr: float, 
     opt = _lib.pm_rowwise_adagrad(float(lr), float(eps), float(weight_decay), _WD_MODES[weight_decay_mode],
                                   1 if stochastic_rounding else 0, 0, int(seed) & (2**64 - 1))
     if not presorted and not _lib.needs_pooling_hint():
+        op.fixed_pooling = 0
         _lib.check(L.pm_embbag_bwd_fused_adagrad(ctypes.byref(op), grad.data_ptr(), ts.d_ptrs.data_ptr(), _WDTYPE[ts.dtype],
                                                  mom_ptrs_dev.data_ptr(), ctypes.byref(opt), max(ts.rows),
                                                  ws.data_ptr(), ws.numel(), _stream_ptr()))

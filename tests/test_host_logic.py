@@ -483,8 +483,10 @@ def test_comms_compute_bench_report_equals_reference_text(golden_dir, monkeypatc
     monkeypatch.setattr(MI355XBackend, "emb_lookup", lambda self, ca: None)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_SIZE"):
         monkeypatch.delenv(k, raising=False)
-    from tests.dist_workers import free_port
+    from tests.dist_workers import _torch_host_row_codec, free_port
 
+    # (the --bitwidth 8 invocation below quantises HOST tensors: the product backend has no host codec, the test injects torch's)
+    monkeypatch.setattr(MI355XBackend, "host_row_codec", staticmethod(_torch_host_row_codec))
     res = C.main(["--master-ip", "127.0.0.1", "--master-port", str(free_port()), "--b", "1K", "--e", "4K", "--f", "4", "--n", "3",
                   "--w", "1", "--collective", "all_to_allv", "--device", "cpu", "--backend", "gloo", "--num-compute", "2",
                   "--ntables", "2", "--batch-size", "8", "--bag-size", "3", "--tag", "x"])

@@ -1,0 +1,36 @@
+#!/bin/bash
+# tools/r6_visit_record.sh [tag]: round 6's record on one GPU box -- GPU tests, smoke, the default bench line twice, the N > 1 path on a
+# 1-rank RCCL group (26 tables, Criteo, Criteo with mixed dims), rocprofv3 kernel stats of the headline launches (Zipf, uniform) and of
+# every phase of the fp32 / bf16 / Criteo / mixed-dim blocks, the --pmc passes of the same phases (requests rotated), the reference
+# driver's shapes with kernel times.  Everything lands in gpurun_out/<tag>/; what is to be judged is copied to profiles/r06_*.
+tag=${1:-r6_record}
+out=gpurun_out/$tag; mkdir -p "$out"; export TMPDIR=/tmp
+timeout 2400 python -m pytest tests -q -m gpu > "$out/pytest.log" 2>&1; grep -E "passed|failed" "$out/pytest.log" | tail -2
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.log" 2>&1; tail -1 "$out/smoke.log"
+timeout 900 python bench.py > "$out/bench_line.json" 2> "$out/bench_line.err"
+timeout 900 python bench.py > "$out/bench_line_run2.json" 2> "$out/bench_line_run2.err"
+timeout 900 python bench.py --dist-debug --tables 26 --no-cpu-baseline --steps 20 > "$out/distdebug_26tables.json" 2> "$out/dd26.err"
+timeout 900 python bench.py --dist-debug --workload criteo --no-cpu-baseline --steps 20 > "$out/distdebug_criteo.json" 2> "$out/ddc.err"
+timeout 900 python bench.py --dist-debug --workload criteo --mixed-dims --no-cpu-baseline --steps 20 > "$out/distdebug_criteo_mixed.json" 2> "$out/ddm.err"
+for v in zipf:--only-headline uniform:--only-headline,--alpha,0; do
+  name=${v%%:*}; bargs=${v#*:}
+  d=/tmp/${tag}_$name; rm -rf "$d"
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$d" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --steps 200 --warmup 5 ${bargs//,/ } > "$GRAFT_REPO_ROOT/$out/headline_${name}_under_rocprofv3.json" 2> "$d.err")
+  f=$(find "$d" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$out/headline_${name}_kernel_stats.csv"
+  python tools/r4_kstats.py stats "$out/headline_${name}_kernel_stats.csv" | head -3
+done
+bash tools/r6_kstats.sh $tag fp32,bf16,criteo,mixed
+bash tools/r6_pmc.sh $tag fp32,bf16,criteo,mixed
+# the reference driver's shapes: wall numbers un-profiled, kernel durations from a kernel trace of the same command
+for ds in A B; do
+  timeout 300 python -m param_amd.compute.pt.driver --steps 50 --warmups 5 --device gpu emb -d $ds --json > "$out/driver_$ds.txt" 2>&1
+  d=/tmp/${tag}_driver_$ds; rm -rf "$d"
+  (cd /tmp && PYTHONPATH=$GRAFT_REPO_ROOT timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$d" -o drv -- python -m param_amd.compute.pt.driver --steps 50 --warmups 5 --device gpu emb -d $ds --json > "$d.out" 2> "$d.err")
+  f=$(find "$d" -name "*kernel_trace.csv" | head -1)
+  echo "emb dataset $ds (steps 50, warmups 5)" >> "$out/driver_emb_datasets.txt"
+  [ -n "$f" ] && PYTHONPATH=$GRAFT_REPO_ROOT python tools/r6_driver_table.py "$out/driver_$ds.txt" "$f" 5 50 >> "$out/driver_emb_datasets.txt"
+done
+cat "$out/driver_emb_datasets.txt"
+timeout 300 python tools/r6_host_call_probe.py > "$out/host_call.json" 2>> "$out/err.txt"; cat "$out/host_call.json"
+for n in bench_line bench_line_run2; do echo "== $n"; python -c "
+import json,sys; d=json.load(open('$out/$n.json')); print(json.dumps(d['summary'])); print(d['value'], d['roofline']['frac'], d['roofline'].get('traffic_over_algorithmic'))"; done
