@@ -362,9 +362,11 @@ int pm_set_tuning(int32_t unroll, int32_t bags_per_block, int32_t xcd_affine, in
  * (short-bag and mixed-dim requests).  0 = one workgroup per (table, smallest tile): workgroups past their table's tile count
  * leave (round 3's form); 1 = one set of workgroups sized by the library, each walking the table-major tile order b, b + grid, ...
  * after establishing every table's tile count from the offsets (no workgroup is dispatched for a tile that does not exist);
- * N > 1 = exactly N workgroups (sweeps).  Results are bit-identical in every setting.
+ * N > 1 = exactly N workgroups (sweeps).
+ * flat_target (ABI v7; -1 = default 256, PARAM_AMD_FLAT_TARGET in the environment changes it): lookups per tile the flat-walk forward
+ * aims at when it sizes a table's tile from the table's average bag (sweeps).  Results are bit-identical in every setting.
  */
-int pm_set_forward_tuning(int32_t stage_out, int32_t flat_grid);
+int pm_set_forward_tuning(int32_t stage_out, int32_t flat_grid, int32_t flat_target);
 
 /*
  * Tuning knobs of the sorted backward (process-wide; -1 = default, which the environment can change:

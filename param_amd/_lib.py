@@ -197,7 +197,7 @@ def _open(path: str, alternates: bool) -> ctypes.CDLL:
     L.pm_set_tuning.restype = ctypes.c_int
     L.pm_set_tuning.argtypes = [i32, i32, i32, i32]
     L.pm_set_forward_tuning.restype = ctypes.c_int
-    L.pm_set_forward_tuning.argtypes = [i32, i32]
+    L.pm_set_forward_tuning.argtypes = [i32, i32, i32]
     L.pm_set_backward_tuning.restype = ctypes.c_int
     L.pm_set_backward_tuning.argtypes = [i32, i32, i32, i32]
     L.pm_embbag_sorted_pairs.restype = ctypes.c_int
@@ -274,11 +274,11 @@ def set_tuning(unroll: int = 0, bags_per_block: int = 0, xcd_affine: int = -1, n
     check(load().pm_set_tuning(unroll, bags_per_block, xcd_affine, nt_loads))
 
 
-def set_forward_tuning(stage_out: int = -1, flat_grid: int = -1) -> None:
+def set_forward_tuning(stage_out: int = -1, flat_grid: int = -1, flat_target: int = -1) -> None:
     """``pm_set_forward_tuning``: stage_out 1 (default) = LDS-staged output burst per tile, 0 = one row store per finished bag;
     flat_grid (flat-walk forward: short-bag / mixed-dim requests) 1 (default) = workgroups walking the tile order, 0 = one workgroup
-    per (table, smallest tile), N > 1 = exactly N workgroups"""
-    check(load().pm_set_forward_tuning(stage_out, flat_grid))
+    per (table, smallest tile), N > 1 = exactly N workgroups; flat_target = lookups per flat-walk tile (default 256)"""
+    check(load().pm_set_forward_tuning(stage_out, flat_grid, flat_target))
 
 
 def set_backward_tuning(sort_impl: int = -1, order: int = -1, xcd_affine: int = -1, max_phases: int = -1) -> None:

@@ -20,6 +20,7 @@ std::atomic<int> g_bags_per_block{0};
 std::atomic<int> g_xcd_affine{-1};
 std::atomic<int> g_nt_loads{-1};
 std::atomic<int> g_stage_out{-1};
+std::atomic<int> g_flat_target{-1}; // pm_set_forward_tuning: lookups per flat-walk tile (-1: PARAM_AMD_FLAT_TARGET, default 256)
 std::atomic<int> g_flat_grid{-1};   // pm_set_forward_tuning: launch shape of the flat-walk forward (-1: PARAM_AMD_FLAT_COMPACT, default 1)
 // destination-row cache policy of the sorted backward when pm_set_tuning leaves nt_loads at its default: plain loads,
 // agent-scope (sc1) stores.  The store writes through and drops the row's lines from the XCD's L2, so a row occupies L2 only
@@ -64,6 +65,8 @@ const FwdEnv& fwd_env() {
     }();
     return e;
 }
+
+int flat_target_knob(const FwdEnv& env) { const int k = g_flat_target.load(); return k > 0 ? k : env.flat_target; }
 
 bool dtype_is_weight(int d) { return d == PM_F32 || d == PM_BF16 || d == PM_F16; }
 
@@ -235,7 +238,7 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
             p.stage_out > 0) {
             const int64_t tiles_ng = (op->bag_count + NG - 1) / NG;
             if (tiles_ng * op->num_tables <= 0x7fffffffLL) {
-                const int tgt2 = env.flat_target;
+                const int tgt2 = flat_target_knob(env);
                 p.flat_bags = 32;
                 p.flat_target = tgt2;
                 p.tiles_per_table = static_cast<int32_t>(tiles_ng);
@@ -246,7 +249,7 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
         }
         if (flat_on && !even && !p.ordered && g_bags_per_block.load() <= 0 && bpb == NG && p.stage_out > 0) {
             const int cap_env = env.flat_bags;
-            const int tgt_env = env.flat_target;
+            const int tgt_env = flat_target_knob(env);
             p.flat_bags = cap_env < NG ? NG : (cap_env > 1024 ? 1024 : cap_env / NG * NG);
             p.flat_target = tgt_env < 1 ? 1 : tgt_env;
             p.bags_per_block = p.flat_bags;   // sizes the LDS offsets array; stage_bags (the burst buffer) stays at NG rows
@@ -264,7 +267,7 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
                 if (tiles_ng * op->num_tables <= 0x7fffffffLL) {
                     if (p.flat_bags < ng_max) p.flat_bags = ng_max;
                     if (p.flat_bags < 32) p.flat_bags = 32;
-                    if (p.flat_target <= 0) p.flat_target = env.flat_target < 1 ? 1 : env.flat_target;
+                    if (p.flat_target <= 0) p.flat_target = flat_target_knob(env) < 1 ? 1 : flat_target_knob(env);
                     p.tiles_per_table = static_cast<int32_t>(tiles_ng);
                     p.bags_per_block = p.flat_bags;
                     p.stage_out = op->max_dim;
@@ -352,11 +355,13 @@ int pm_set_tuning(int32_t unroll, int32_t bags_per_block, int32_t xcd_affine, in
     return PM_OK;
 }
 
-int pm_set_forward_tuning(int32_t stage_out, int32_t flat_grid) {
+int pm_set_forward_tuning(int32_t stage_out, int32_t flat_grid, int32_t flat_target) {
     if (stage_out < -1 || stage_out > 1) return fail(PM_ERR_INVALID, "stage_out must be -1, 0 or 1");
     if (flat_grid < -1 || flat_grid > (1 << 20)) return fail(PM_ERR_INVALID, "flat_grid must be -1 (default), 0, 1 or a workgroup count up to 2^20");
+    if (flat_target < -1 || flat_target == 0 || flat_target > 4096) return fail(PM_ERR_INVALID, "flat_target must be -1 (default) or 1 .. 4096");
     g_stage_out.store(stage_out);
     g_flat_grid.store(flat_grid);
+    g_flat_target.store(flat_target);
     return PM_OK;
 }
 

@@ -18,6 +18,7 @@ from param_amd.indices import tbe_request  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--grids", default="0,1,1024,1536,2048,3072,4096,6144,8192")
 ap.add_argument("--workloads", default="all128,mixed")
+ap.add_argument("--targets", default="", help="lookups per tile (pm_set_forward_tuning(flat_target)) taking turns at the library's grid, instead of the grids")
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--batch", type=int, default=8192)
@@ -55,10 +56,11 @@ for wl in a.workloads.split(","):
             m.lookup(i, o, out=out, batch=B)
 
         for rnd in range(a.rounds):
-            for grid in [int(x) for x in a.grids.split(",")]:
-                param_amd.set_forward_tuning(flat_grid=grid)
+            for val in [int(x) for x in (a.targets or a.grids).split(",")]:
+                grid, target = (1, val) if a.targets else (val, -1)
+                param_amd.set_forward_tuning(flat_grid=grid, flat_target=target)
                 s = timed(f, a.iters)
-                print(json.dumps({"exp": "flat_grid", "workload": wl, "indices": name, "grid": grid, "round": rnd, "us": round(s * 1e6, 2),
+                print(json.dumps({"exp": "flat_grid", "workload": wl, "indices": name, "grid": grid, "target": target, "round": rnd, "us": round(s * 1e6, 2),
                                   "alg_frac": round(fwd_bytes / s / 8e12, 4)}), flush=True)
     param_amd.set_forward_tuning()
     del m, out
