@@ -6,6 +6,8 @@ needs a smaller lane group than its widest, the forward runs the flat-walk kerne
 device (sub-groups of 4 .. G lanes).  Bar: bit-exact against the C oracle and against the same request launched without the
 hint (one lane-group width for every table) -- a bag is pooled by one sub-group, additions in index order from zero.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -37,7 +39,10 @@ def _request(rows, B, pools, alpha, seed, idt=torch.int64):
     return tbe_request(rows, B, pools, alpha=alpha, device=DEV, seed=seed, index_dtype=idt)
 
 
-@pytest.mark.parametrize("seed", range(16))
+_MIXED_SEEDS = int(os.environ.get("PARAM_AMD_MIXED_SEEDS", "16"))      # soak runs raise it
+
+
+@pytest.mark.parametrize("seed", range(_MIXED_SEEDS))
 def test_mixed_dim_requests_bit_exact_vs_oracle_and_vs_one_width(seed, coracle):
     """Random requests whose tables mix D in {8, 16, 32, 64, 128} (fp32; 16-bit tables: multiples of 8): fixed pooling or per-table
     pooling factors (1 .. 40), some weighted, int32 / int64 indices, uniform or Zipf rows, batch slices.  The forward with the hint
