@@ -266,6 +266,11 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
                 const int64_t tiles_ng = (op->bag_count + NG - 1) / NG;   // the grid of the smallest tile: the widest table's NG bags
                 if (tiles_ng * op->num_tables <= 0x7fffffffLL) {
                     if (p.flat_bags < ng_max) p.flat_bags = ng_max;
+                    // (256 bags at most per tile: a one-hot narrow table then reaches the ~flat_target lookups per tile the wide tables
+                    // have -- its 64-bag tiles were three round trips of set-up around 4 KB of rows.  Criteo tables with mixed dims, one
+                    // process per setting, two each: cap 64: 143.3-143.9 us, 128: 142.3-142.9, 256: 141.5-142.1; the narrow tables alone
+                    // 24.3 -> 21.6 us: profiles/r06_flat_bags_cap_sweep.jsonl)
+                    if (p.flat_bags < 256 && env.flat_bags <= 32) p.flat_bags = 256;
                     if (p.flat_bags < 32) p.flat_bags = 32;
                     if (p.flat_target <= 0) p.flat_target = flat_target_knob(env) < 1 ? 1 : flat_target_knob(env);
                     p.tiles_per_table = static_cast<int32_t>(tiles_ng);
