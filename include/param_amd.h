@@ -108,7 +108,8 @@ typedef struct pm_embbag_batch {
        bag a D = 16 fp32 table of a request whose widest table has D = 128 would keep 4 of every 32 lanes busy.  When
        min_dim says the request is MIXED (its narrowest table needs a smaller power-of-two lane group than its widest) the
        forward runs the flat-walk kernel with the lane group chosen PER TABLE on the device from dims[t] (sub-groups of 4 .. G
-       lanes: a D = 16 row is one 64-byte load by 4 lanes, eight bags per 32-lane slot) and tiles sized per table by their lookups.
+       lanes: a D = 16 row is one 64-byte load by 4 lanes, eight bags per 32-lane slot) and tiles sized per table by their lookups
+       (~256 lookups, at most 256 bags).
        Results are bit-identical to a max_dim-wide launch (a bag is pooled by one sub-group, additions in index order).  A table
        narrower than min_dim merely wastes lanes.  Reference: mixed embedding dims, train/comms/pt/dlrm.py:384-385 (`mixed_dim`
        -> torch.cat(ly, dim=1)), :506-557. */

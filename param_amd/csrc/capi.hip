@@ -58,7 +58,7 @@ const FwdEnv& fwd_env() {
         r.flat = num("PARAM_AMD_FWD_FLAT", 1);
         r.flat_maxl = num("PARAM_AMD_FLAT_MAXL", 0);
         r.flat_target = num("PARAM_AMD_FLAT_TARGET", 256);
-        r.flat_bags = num("PARAM_AMD_FLAT_BAGS", 32);
+        r.flat_bags = num("PARAM_AMD_FLAT_BAGS", 256);
         r.tile_major = num("PARAM_AMD_FWD_TILE_MAJOR", -1);
         r.flat_compact = num("PARAM_AMD_FLAT_COMPACT", 1);
         return r;
@@ -227,6 +227,10 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
         // r3_criteo_flat (Zipf G lookups/s / uniform fraction; run-to-run +-1.5 %): 8-bag tiles 15.7-15.9 / 0.69-0.71; flat walk
         // target 512 cap 64: 16.4-16.5 / 0.705-0.716; **256 / 32: 16.6 / 0.719**; 128: 16.1 / 0.695; 1024 / 128: 14.1 / 0.64.
         // PARAM_AMD_FWD_FLAT=0 turns it off (PARAM_AMD_FLAT_TARGET / _BAGS: sweeps).
+        // (Round 6: that cap of 32 bags was chosen under round 3's grid, where a larger cap also meant more surplus workgroups.  With
+        // the compact launch a one-hot table's 32-bag tile is three round trips of set-up around 32 row loads; one process per setting,
+        // three each, us uniform / Zipf: cap 32: 192-193 / 118; 64: 182 / 114; 128: 186 / 112; **256: 181 / 111.6**
+        // -- profiles/r06_flat_bags_cap_sweep_all128.jsonl.  The cap is 256 bags on every flat-walk path now.)
         const int flat_env = env.flat;
         const bool flat_on = flat_env != 0;
         // ... and so do fixed-pooling requests of one or two lookups per bag (one-hot tables): bag by bag a lane group has one or
@@ -239,7 +243,7 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
             const int64_t tiles_ng = (op->bag_count + NG - 1) / NG;
             if (tiles_ng * op->num_tables <= 0x7fffffffLL) {
                 const int tgt2 = flat_target_knob(env);
-                p.flat_bags = 32;
+                p.flat_bags = env.flat_bags < 32 ? 32 : (env.flat_bags > 1024 ? 1024 : env.flat_bags / NG * NG);
                 p.flat_target = tgt2;
                 p.tiles_per_table = static_cast<int32_t>(tiles_ng);
                 p.stage_bags = NG;
@@ -270,7 +274,7 @@ int make_params(const pm_embbag_batch* op, int elem_dtype, pm::KParams& p, bool 
                     // have -- its 64-bag tiles were three round trips of set-up around 4 KB of rows.  Criteo tables with mixed dims, one
                     // process per setting, two each: cap 64: 143.3-143.9 us, 128: 142.3-142.9, 256: 141.5-142.1; the narrow tables alone
                     // 24.3 -> 21.6 us: profiles/r06_flat_bags_cap_sweep.jsonl)
-                    if (p.flat_bags < 256 && env.flat_bags <= 32) p.flat_bags = 256;
+                    if (p.flat_bags < 256) p.flat_bags = 256;
                     if (p.flat_bags < 32) p.flat_bags = 32;
                     if (p.flat_target <= 0) p.flat_target = flat_target_knob(env) < 1 ? 1 : flat_target_knob(env);
                     p.tiles_per_table = static_cast<int32_t>(tiles_ng);
