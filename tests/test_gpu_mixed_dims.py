@@ -131,3 +131,45 @@ def test_criteo_mixed_dims_full_size_vs_live_torch_rocm():
         err = (out[:, c0:c0 + dims[t]] - ref).abs()
         assert bool((err <= 1e-5 * mag + 1e-30).all()), t
         c0 += dims[t]
+
+
+@pytest.mark.parametrize("T", [300, 1100])
+def test_flat_walk_launch_with_many_tables_empty_tables_and_slices(T, coracle):
+    """The compact flat-walk launch keeps one prefix entry per table in LDS (requests of up to 1024 tables; larger ones keep the
+    T x tiles grid): hundreds of one-hot / short-bag tables of mixed widths, some of them with EMPTY bags only and some ragged, a batch
+    slice with bag_begin > 0, int32 indices -- the forward equals the C oracle bit for bit in every launch shape
+    (pm_set_forward_tuning(flat_grid) 0 = round 3's grid, 1 = the library's, 64 = few workgroups walking many tiles each)."""
+    import param_amd
+
+    rng = np.random.default_rng(77 + T)
+    dims = [int(rng.choice([8, 16, 32, 64])) for _ in range(T)]
+    dims[0], dims[-1] = 64, 8
+    rows = [int(rng.choice([3, 50, 4000])) for _ in range(T)]
+    B = 96
+    lens = []
+    for t in range(T):
+        kind = rng.random()
+        if kind < 0.1:
+            lens.append(np.zeros(B, dtype=np.int64))                         # a table nobody looks up
+        elif kind < 0.6:
+            lens.append(np.ones(B, dtype=np.int64))                          # one-hot
+        else:
+            lens.append(rng.integers(0, 4, B))                               # ragged, empty bags among them
+    lens = np.concatenate(lens)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    idx = np.concatenate([rng.integers(0, rows[t], int(lens[t * B:(t + 1) * B].sum())) for t in range(T)]).astype(np.int64)
+    m = _model(rows, dims, seed=5)
+    it, ot = torch.from_numpy(idx).to(DEV).to(torch.int32), torch.from_numpy(off).to(DEV).to(torch.int32)
+    tabs = [m.table(t).cpu().numpy() for t in range(T)]
+    ref = coracle.fwd_batched(tabs, idx, off, B)
+    try:
+        for grid in (1, 0, 64):
+            param_amd.set_forward_tuning(flat_grid=grid)
+            for b0, bc in ((0, B), (17, 60)):
+                out = torch.full((B, sum(dims)), -7.0, device=DEV)
+                m.lookup(it, ot, out=out, batch=B, bag_begin=b0, bag_count=bc)
+                got = out.cpu().numpy()
+                assert np.array_equal(got[b0:b0 + bc], ref[b0:b0 + bc]), (T, grid, b0)
+                assert (got[:b0] == -7.0).all() and (got[b0 + bc:] == -7.0).all()       # bags outside the slice are not written
+    finally:
+        param_amd.set_forward_tuning()
