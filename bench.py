@@ -481,7 +481,7 @@ def _summary(r: dict) -> dict:
                 "bwd_u": g(b, "bwd_scatter_add", "uniform", "frac"), "bwd_z_ms": ms(b, "bwd_scatter_add", "zipf", "avg_s_sort_plus_apply"),
                 "fwdbwd_u": g(b, "bwd_scatter_add", "uniform", "fwd_bwd_frac")}
 
-    s = {"fwd_u": g(r, "roofline", "frac"), "fwd_u_1req": g(r, "roofline", "single_request_frac"), "fwd_bd_u": g(r, "other_layout", "uniform_frac"),
+    s = {"fwd_z_G": (round(r["value"] / 1e9, 2) if isinstance(r.get("value"), (int, float)) else None), "fwd_u": g(r, "roofline", "frac"), "fwd_u_1req": g(r, "roofline", "single_request_frac"), "fwd_bd_u": g(r, "other_layout", "uniform_frac"),
          "bwd_u": g(r, "bwd_scatter_add", "uniform", "frac"), "bwd_z_ms": ms(r, "bwd_scatter_add", "avg_s_sort_plus_apply"),
          "fwdbwd_u": g(r, "fwd_bwd_step", "uniform", "frac"), "fwdbwd_z_ms": ms(r, "fwd_bwd_step", "avg_s"),
          "sort_ms": ms(r, "bwd_scatter_add", "avg_s_whole_key_sort")}
