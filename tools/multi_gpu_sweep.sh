@@ -27,6 +27,9 @@ if [ "$DEVICE" != cpu ]; then
   run bench bench.py --gpus "$N" --steps 50 --warmup 5
   run bench_26 bench.py --gpus "$N" --tables 26 --steps 50 --warmup 5
   run bench_criteo bench.py --gpus "$N" --workload criteo --steps 50 --warmup 5
+  run bench_criteo_mixed bench.py --gpus "$N" --workload criteo --mixed-dims --steps 50 --warmup 5
+  run bench_masked bench.py --gpus "$N" --lookup-cus 224 --steps 50 --warmup 5     # (the default picks the compute stream by a trial in the run:
+  run bench_unmasked bench.py --gpus "$N" --lookup-cus 0 --steps 50 --warmup 5     #  both fixed settings beside it, for the record)
   big=256M; graphs="--graph-launches 10"
 else
   big=1M; graphs=""
